@@ -1,0 +1,338 @@
+"""ctypes binding of the CPU ORACLE (oracle/liborc.so) and, when built, of the
+real-reference library (oracle/_ref/libref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBORC = os.path.join(HERE, "liborc.so")
+LIBREF = os.path.join(HERE, "_ref", "libref.so")
+REFERENCE_ROOT = "/root/reference"
+
+NODE_DTYPE = np.dtype(
+    [("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("size", "<i4"),
+     ("isLeaf", "<i4"), ("isSolid", "<i4"), ("isUniform", "<i4"), ("child", "<i4", (8,))]
+)
+assert NODE_DTYPE.itemsize == 60
+
+
+class _Grid(C.Structure):
+    _fields_ = [("dimX", C.c_int32), ("dimY", C.c_int32), ("dimZ", C.c_int32),
+                ("minX", C.c_float), ("minY", C.c_float), ("minZ", C.c_float),
+                ("voxelSize", C.c_float), ("data", C.c_void_p)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("pops", C.c_uint64), ("hits", C.c_uint64),
+                ("capped", C.c_uint64), ("internal", C.c_uint64),
+                ("max_stack", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class _Camera(C.Structure):
+    _fields_ = [("theta", C.c_float), ("phi", C.c_float), ("radius", C.c_float), ("target", C.c_float * 3)]
+
+
+@dataclass
+class Grid:
+    """Host-side VoxelGrid (453-skeleton/OctreeVoxel.h:28-42) as numpy."""
+    dims: tuple
+    min: np.ndarray          # float32[3]
+    voxel_size: np.float32
+    data: np.ndarray         # uint8[dimZ, dimY, dimX] (x fastest)
+
+    def c(self) -> _Grid:
+        d = np.ascontiguousarray(self.data, dtype=np.uint8)
+        self._keep = d
+        g = _Grid(self.dims[0], self.dims[1], self.dims[2],
+                  float(self.min[0]), float(self.min[1]), float(self.min[2]),
+                  float(self.voxel_size), d.ctypes.data)
+        return g
+
+
+def build(ref: bool = False) -> None:
+    """(Re)build liborc.so, and libref.so when asked and the reference is present."""
+    subprocess.run(["make", "-s", "-C", HERE, "liborc.so"], check=True)
+    if ref and os.path.isdir(REFERENCE_ROOT):
+        subprocess.run(["make", "-s", "-C", HERE, "ref"], check=True)
+
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBORC):
+        build()
+    L = C.CDLL(LIBORC)
+    L.orc_generate_test_sphere.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_recenter_filled_voxels.argtypes = [C.POINTER(_Grid)]
+    L.orc_recenter_filled_voxels.restype = C.c_int
+    L.orc_load_voxel_grid.argtypes = [C.c_char_p, C.POINTER(_Grid)]
+    L.orc_load_voxel_grid.restype = C.c_int
+    L.orc_build_flat_octree.argtypes = [C.POINTER(_Grid), C.POINTER(C.c_void_p)]
+    L.orc_build_flat_octree.restype = C.c_int64
+    L.orc_free.argtypes = [C.c_void_p]
+    L.orc_mat4_inverse.argtypes = [_f32p, _f32p]
+    L.orc_mat4_mul.argtypes = [_f32p, _f32p, _f32p]
+    L.orc_perspective.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, _f32p]
+    L.orc_look_at.argtypes = [_f32p, _f32p, _f32p, _f32p]
+    L.orc_radians.argtypes = [C.c_float]
+    L.orc_radians.restype = C.c_float
+    L.orc_camera_init.argtypes = [C.POINTER(_Camera), C.c_float, C.c_float, C.c_float]
+    L.orc_camera_pos.argtypes = [C.POINTER(_Camera), _f32p]
+    L.orc_camera_view.argtypes = [C.POINTER(_Camera), _f32p]
+    L.orc_camera_pan.argtypes = [C.POINTER(_Camera), C.c_float, C.c_float]
+    L.orc_frustum_planes.argtypes = [_f32p, _f32p]
+    L.orc_frustum_test_aabb.argtypes = [_f32p, _f32p, _f32p, C.c_float]
+    L.orc_frustum_test_aabb.restype = C.c_int
+    L.orc_cull_compact.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, C.c_float, C.c_float,
+                                   C.c_void_p, C.c_void_p]
+    L.orc_cull_compact.restype = C.c_int64
+    L.orc_render.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float,
+                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_Stats), C.c_int]
+    L.orc_render_steps.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float,
+                                   C.c_int, C.c_int, C.c_void_p]
+    L.orc_octree_ray_skip.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float]
+    L.orc_octree_ray_skip.restype = C.c_float
+    L.orc_max_threads.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+# ---------------------------------------------------------------- scene
+def test_sphere_grid(dim: int) -> Grid:
+    """453-skeleton/main.cpp:337-372,1052-1070,1074: shell sphere, min -0.5, voxelSize 1/dim, recentered."""
+    data = np.empty((dim, dim, dim), dtype=np.uint8)
+    lib().orc_generate_test_sphere(dim, dim, dim, data.ctypes.data)
+    g = Grid((dim, dim, dim), np.array([-0.5, -0.5, -0.5], np.float32), np.float32(1.0) / np.float32(dim), data)
+    recenter(g)
+    return g
+
+
+def recenter(g: Grid) -> bool:
+    cg = g.c()
+    ok = lib().orc_recenter_filled_voxels(C.byref(cg))
+    g.min = np.array([cg.minX, cg.minY, cg.minZ], np.float32)
+    return bool(ok)
+
+
+def load_voxel_grid(path: str) -> Grid:
+    cg = _Grid()
+    if not lib().orc_load_voxel_grid(path.encode(), C.byref(cg)):
+        raise IOError(f"cannot read voxel grid {path}")
+    n = cg.dimX * cg.dimY * cg.dimZ
+    data = np.ctypeslib.as_array(C.cast(cg.data, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+    lib().orc_free(cg.data)
+    return Grid((cg.dimX, cg.dimY, cg.dimZ), np.array([cg.minX, cg.minY, cg.minZ], np.float32),
+                np.float32(cg.voxelSize), data.reshape(cg.dimZ, cg.dimY, cg.dimX))
+
+
+def build_flat_octree(g: Grid) -> np.ndarray:
+    out = C.c_void_p()
+    cg = g.c()
+    n = lib().orc_build_flat_octree(C.byref(cg), C.byref(out))
+    if n == 0:
+        return np.zeros(0, NODE_DTYPE)
+    arr = np.frombuffer(C.string_at(out.value, n * 60), dtype=NODE_DTYPE).copy()
+    lib().orc_free(out)
+    return arr
+
+
+# ---------------------------------------------------------------- camera / glm
+class Camera:
+    """453-skeleton/Camera.h:5-44 (orbit camera) -- oracle flavour."""
+
+    def __init__(self, theta, phi, radius):
+        self._c = _Camera()
+        lib().orc_camera_init(C.byref(self._c), theta, phi, radius)
+
+    def pan(self, dx, dy):
+        lib().orc_camera_pan(C.byref(self._c), dx, dy)
+
+    def get_view(self) -> np.ndarray:
+        out = np.zeros(16, np.float32)
+        lib().orc_camera_view(C.byref(self._c), out)
+        return out
+
+    def get_pos(self) -> np.ndarray:
+        out = np.zeros(3, np.float32)
+        lib().orc_camera_pos(C.byref(self._c), out)
+        return out
+
+    @property
+    def target(self):
+        return np.array(list(self._c.target), np.float32)
+
+
+def mat4_inverse(m):
+    out = np.zeros(16, np.float32)
+    lib().orc_mat4_inverse(_f32(m).reshape(16), out)
+    return out
+
+
+def mat4_mul(a, b):
+    out = np.zeros(16, np.float32)
+    lib().orc_mat4_mul(_f32(a).reshape(16), _f32(b).reshape(16), out)
+    return out
+
+
+def perspective(fovy_rad, aspect, zn, zf):
+    out = np.zeros(16, np.float32)
+    lib().orc_perspective(fovy_rad, aspect, zn, zf, out)
+    return out
+
+
+def radians(deg):
+    return np.float32(lib().orc_radians(deg))
+
+
+def frustum_planes(vp):
+    out = np.zeros(24, np.float32)
+    lib().orc_frustum_planes(_f32(vp).reshape(16), out)
+    return out
+
+
+def frustum_test(planes, bmin, bmax, margin):
+    return lib().orc_frustum_test_aabb(_f32(planes), _f32(bmin), _f32(bmax), margin)
+
+
+def cull_compact(nodes, grid_min, voxel_size, view, fov_deg, aspect):
+    nodes = np.ascontiguousarray(nodes)
+    out = np.zeros(len(nodes), NODE_DTYPE)
+    vis = np.zeros(len(nodes), np.uint8)
+    n = lib().orc_cull_compact(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size), _f32(view),
+                               float(fov_deg), float(aspect), out.ctypes.data, vis.ctypes.data)
+    return out[:n].copy(), vis.astype(bool)
+
+
+# ---------------------------------------------------------------- the kernel
+def render(nodes, grid_min, voxel_size, view, cam_pos, aspect, fov_deg, W, H, rows=None, nthreads=1,
+           out=None):
+    """Restatement of 453-skeleton/RayTracerBVH.cpp:226-368. Returns (image[H,W,4] float32, stats dict)."""
+    nodes = np.ascontiguousarray(nodes)
+    if out is None:
+        out = np.zeros((H, W, 4), np.float32)
+    y0, y1 = rows if rows is not None else (0, H)
+    st = _Stats()
+    lib().orc_render(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size), _f32(view), _f32(cam_pos),
+                     float(aspect), float(fov_deg), W, H, y0, y1, out.ctypes.data, C.byref(st), nthreads)
+    stats = {k: getattr(st, k) for k in ("rays", "pops", "hits", "capped", "internal", "max_stack")}
+    return out, stats
+
+
+def render_steps(nodes, grid_min, voxel_size, view, cam_pos, aspect, fov_deg, W, H):
+    nodes = np.ascontiguousarray(nodes)
+    steps = np.zeros((H, W), np.int32)
+    lib().orc_render_steps(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size), _f32(view),
+                           _f32(cam_pos), float(aspect), float(fov_deg), W, H, steps.ctypes.data)
+    return steps
+
+
+def octree_ray_skip(nodes, grid_min, voxel_size, ro, rd, tmin=0.0, tmax=1e30):
+    nodes = np.ascontiguousarray(nodes)
+    return lib().orc_octree_ray_skip(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size),
+                                     _f32(ro), _f32(rd), tmin, tmax)
+
+
+def max_threads() -> int:
+    return lib().orc_max_threads()
+
+
+# ---------------------------------------------------------------- real reference (optional)
+_ref = None
+
+
+def ref_available() -> bool:
+    return os.path.exists(LIBREF)
+
+
+def ref():
+    """The compiled reference (oracle/_ref/libref.so); only exists where `make -C oracle ref` ran."""
+    global _ref
+    if _ref is not None:
+        return _ref
+    R = C.CDLL(LIBREF)
+    R.ref_build_flat_octree.argtypes = [C.POINTER(_Grid), C.POINTER(C.c_void_p)]
+    R.ref_build_flat_octree.restype = C.c_int64
+    R.ref_free.argtypes = [C.c_void_p]
+    R.ref_get_voxel_safe.argtypes = [C.POINTER(_Grid), C.c_int, C.c_int, C.c_int]
+    R.ref_get_voxel_safe.restype = C.c_int
+    R.ref_camera.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, _f32p, _f32p, _f32p]
+    R.ref_glm_inverse.argtypes = [_f32p, _f32p]
+    R.ref_glm_mul.argtypes = [_f32p, _f32p, _f32p]
+    R.ref_glm_perspective.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, _f32p]
+    R.ref_glm_radians.argtypes = [C.c_float]
+    R.ref_glm_radians.restype = C.c_float
+    R.ref_glm_normalize3.argtypes = [_f32p, _f32p]
+    R.ref_glm_normalize4.argtypes = [_f32p, _f32p]
+    R.ref_glm_mat_vec.argtypes = [_f32p, _f32p, _f32p]
+    R.ref_frustum_test.argtypes = [_f32p, _f32p, _f32p, C.c_int64, C.c_float, C.c_void_p]
+    R.ref_load_voxel_grid.argtypes = [C.c_char_p, C.POINTER(_Grid)]
+    R.ref_load_voxel_grid.restype = C.c_int
+    R.ref_local_mc.argtypes = [C.POINTER(_Grid), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    R.ref_local_mc.restype = C.c_int64
+    _ref = R
+    return R
+
+
+def ref_build_flat_octree(g: Grid) -> np.ndarray:
+    out = C.c_void_p()
+    cg = g.c()
+    n = ref().ref_build_flat_octree(C.byref(cg), C.byref(out))
+    if n == 0:
+        return np.zeros(0, NODE_DTYPE)
+    arr = np.frombuffer(C.string_at(out.value, n * 60), dtype=NODE_DTYPE).copy()
+    ref().ref_free(out)
+    return arr
+
+
+def ref_camera(theta, phi, radius, pan=None):
+    view = np.zeros(16, np.float32)
+    pos = np.zeros(3, np.float32)
+    tgt = np.zeros(3, np.float32)
+    ref().ref_camera(theta, phi, radius, 1 if pan else 0, pan[0] if pan else 0.0, pan[1] if pan else 0.0, view, pos, tgt)
+    return view, pos, tgt
+
+
+def ref_load_voxel_grid(path: str) -> Grid:
+    cg = _Grid()
+    if not ref().ref_load_voxel_grid(path.encode(), C.byref(cg)):
+        raise IOError(path)
+    n = cg.dimX * cg.dimY * cg.dimZ
+    data = np.ctypeslib.as_array(C.cast(cg.data, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+    ref().ref_free(cg.data)
+    return Grid((cg.dimX, cg.dimY, cg.dimZ), np.array([cg.minX, cg.minY, cg.minZ], np.float32),
+                np.float32(cg.voxelSize), data.reshape(cg.dimZ, cg.dimY, cg.dimX))
+
+
+def ref_frustum_test(vp, mins, maxs, margin):
+    mins = _f32(mins).reshape(-1, 3)
+    maxs = _f32(maxs).reshape(-1, 3)
+    out = np.zeros(len(mins), np.int32)
+    ref().ref_frustum_test(_f32(vp).reshape(16), mins.reshape(-1), maxs.reshape(-1), len(mins), margin, out.ctypes.data)
+    return out
+
+
+def ref_local_mc(g: Grid, x0, y0, z0, size) -> np.ndarray:
+    out = C.c_void_p()
+    cg = g.c()
+    n = ref().ref_local_mc(C.byref(cg), x0, y0, z0, size, C.byref(out))
+    arr = np.frombuffer(C.string_at(out.value, max(n, 0) * 72), dtype=np.float32).copy().reshape(-1, 18)
+    ref().ref_free(out)
+    return arr
