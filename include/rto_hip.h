@@ -1,0 +1,143 @@
+/*
+ * rto_hip.h -- C ABI of librto_hip.so: the MI355X (gfx950) replacement for the
+ * device side of the reference's RayTracerBVH.
+ *
+ * The reference (abodthedude25/Ray_Tracing_Octrees, 453-skeleton/ = S/) has no
+ * FFI: its "device boundary" is the OpenGL driver.  Each entry point below
+ * replaces the GL calls named next to it; the C++ class in
+ * ray_tracing_octrees_amd/host/RayTracerBVH.h keeps the reference's own
+ * signatures (S/RayTracerBVH.h:28-80) on top of this ABI, and INTEGRATION.md
+ * shows the binding a maintainer of the reference would add.
+ *
+ * Plain C types only: pointers, sizes, floats.  Matrices are column-major
+ * float[16] exactly as glm::mat4 lays them out (&view[0][0],
+ * S/RayTracerBVH.cpp:671).  All functions return RTO_OK (0) or a negative
+ * RTO_E* code; rto_last_error() gives the message.  A context is bound to one
+ * GPU; calls on one context must be serialised by the caller (the reference is
+ * single-threaded, S/main.cpp), different contexts may be driven concurrently.
+ */
+#ifndef RTO_HIP_H
+#define RTO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTO_OK            0
+#define RTO_E_INVALID    -1   /* bad argument                                  */
+#define RTO_E_NO_OCTREE  -2   /* render before rto_upload_octree               */
+#define RTO_E_HIP        -3   /* HIP runtime error (message has the hipError)  */
+#define RTO_E_NO_DEVICE  -4   /* no usable gfx950 device / ordinal out of range */
+#define RTO_E_UNSUPPORTED -5  /* e.g. packed kernel requested for a non-canonical array */
+
+/* == struct GPUNodes, S/RayTracerBVH.h:21-26 / GLSL OctreeNodeGPUStruct S/RayTracerBVH.cpp:195-204 */
+typedef struct rto_node {
+    int32_t x, y, z, size;
+    int32_t isLeaf, isSolid, isUniform;
+    int32_t child[8];              /* -1 = none */
+} rto_node;                        /* 60 bytes, stride 60 */
+
+/* The uniforms of S/RayTracerBVH.cpp:652-680 that the shader actually reads
+ * (numNodes and invVP are set by the reference but unused by the GLSL). */
+typedef struct rto_frame {
+    float   view[16];              /* camera.getView(), column-major           :668,:671 */
+    float   cam_pos[3];            /* camera.getPos()                          :673-674 */
+    float   aspect;                /*                                          :676     */
+    float   fov_deg;               /* degrees                                  :677     */
+    int32_t width, height;         /*                                          :679-680 */
+} rto_frame;
+
+/* Screen-space partition for multi-GPU rendering (no reference counterpart,
+ * SURVEY.md section 8e): the image is cut into bands of band_rows rows; band b
+ * belongs to part (b % num_parts).  A part's bands are stored back to back in
+ * its compact buffer.  {1, 0, any} = the whole frame. */
+typedef struct rto_partition {
+    int32_t num_parts;
+    int32_t part;
+    int32_t band_rows;             /* multiple of 8 */
+} rto_partition;
+
+/* Which traversal kernel runs. AUTO = PACKED when the uploaded array is a
+ * canonical BFS octree (what setOctree produces), else GENERIC. */
+#define RTO_KERNEL_AUTO    0
+#define RTO_KERNEL_GENERIC 1       /* 60-byte nodes, explicit child indices, per-thread stack[128] */
+#define RTO_KERNEL_PACKED  2       /* 8-byte child descriptors, LDS level stack                    */
+
+typedef struct rto_stats {         /* per-frame counters, same meaning as the oracle's */
+    uint64_t rays, pops, hits, capped;
+} rto_stats;
+
+typedef struct rto_octree_info {
+    int64_t num_nodes;             /* as uploaded                                         */
+    int64_t num_internal;          /* nodes that push children                            */
+    int32_t root_size;
+    int32_t depth;                 /* log2(root_size)                                     */
+    int32_t canonical;             /* 1 if the packed kernel can be used                  */
+    int32_t culling_active;        /* 1 after rto_update_frustum(enable=1)                */
+    int64_t visible_nodes;         /* count kept by the last frustum update (== num_nodes if none) */
+} rto_octree_info;
+
+typedef struct rto_context rto_context;
+
+/* ---- lifetime -------------------------------------------------------------
+ * replaces: GL context + RayTracerBVH::ensureComputeInitialized (S/RayTracerBVH.cpp:508-612). */
+int  rto_create(int device_ordinal, rto_context** out);
+void rto_destroy(rto_context* ctx);
+const char* rto_last_error(const rto_context* ctx);     /* ctx may be NULL: error of the last failed rto_create */
+int  rto_device_name(const rto_context* ctx, char* buf, size_t buflen);
+
+/* ---- octree upload --------------------------------------------------------
+ * replaces: glBufferData(GL_SHADER_STORAGE_BUFFER, numNodes*sizeof(GPUNodes), ...) in
+ * RayTracerBVH::setOctree (S/RayTracerBVH.cpp:495-504).  The array is copied; the
+ * library additionally repacks canonical arrays into child descriptors. */
+int  rto_upload_octree(rto_context* ctx, const rto_node* nodes, int64_t num_nodes,
+                       const float grid_min[3], float voxel_size);
+int  rto_octree_info_get(const rto_context* ctx, rto_octree_info* out);
+int  rto_set_kernel(rto_context* ctx, int kernel /* RTO_KERNEL_* */);
+
+/* ---- frustum culling ------------------------------------------------------
+ * replaces: the CPU loop + compaction + SSBO re-upload of
+ * renderSceneComputeWithCulling(updateFrustum=true) (S/RayTracerBVH.cpp:725-813).
+ * The test runs on the GPU over the resident array; rendering afterwards behaves as
+ * if the compacted array had been uploaded.  enable=0 restores the full array. */
+int  rto_update_frustum(rto_context* ctx, const float view[16], float fov_deg, float aspect, int enable);
+/* Copies the compacted array (== m_visibleNodes, S/RayTracerBVH.cpp:775-802) to the host for parity
+ * checks.  out may be NULL to query the count only. */
+int  rto_download_visible_nodes(rto_context* ctx, rto_node* out, int64_t capacity, int64_t* count);
+
+/* ---- render ---------------------------------------------------------------
+ * replaces: glTexImage2D(RGBA32F) + uniforms + glDispatchCompute + glMemoryBarrier
+ * (S/RayTracerBVH.cpp:630-688).  Output: RGBA32F, row-major, row 0 = top, alpha 1. */
+
+/* Asynchronous: renders this part's bands into d_out (device pointer,
+ * rto_partition_rows()*width*16 bytes) on hip_stream (a hipStream_t, NULL = the
+ * context's own stream). */
+int  rto_render_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part /* NULL = whole frame */,
+                       void* d_out, void* hip_stream);
+/* Synchronous convenience: whole frame into host memory (the one API addition the
+ * reference lacks: its texture is never read back). */
+int  rto_render_host(rto_context* ctx, const rto_frame* frame, float* host_rgba);
+/* Number of rows part `part` owns. */
+int  rto_partition_rows(const rto_frame* frame, const rto_partition* part);
+/* Reassembles num_parts compact buffers laid end to end (as a gather delivers them;
+ * every part padded to rto_partition_rows(part 0) rows) into a row-major frame. */
+int  rto_assemble_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part,
+                         const void* d_gathered, void* d_frame, void* hip_stream);
+
+/* ---- instrumentation ------------------------------------------------------*/
+/* Renders the frame once with counting enabled (synchronous). */
+int  rto_frame_stats(rto_context* ctx, const rto_frame* frame, rto_stats* out);
+/* Per-pixel traversalSteps: +steps for a hit, -steps for a miss (width*height int32, host). */
+int  rto_render_steps_host(rto_context* ctx, const rto_frame* frame, int32_t* host_steps);
+/* Device time in ms of the most recent traversal kernel launched by this context
+ * (hipEvent pair on the launch stream; synchronises on that event). */
+int  rto_last_kernel_ms(rto_context* ctx, float* ms);
+int  rto_synchronize(rto_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,69 @@
+"""In-tree native builds (gfx950 only).
+
+`build_hip()`  -> ray_tracing_octrees_amd/librto_hip.so   (hipcc, device + C ABI)
+`build_host()` -> ray_tracing_octrees_amd/librto_host.so  (g++, the C++ drop-in host layer + its C shim)
+
+The .so files are git-ignored but travel with the tree to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+LIB_HIP = os.path.join(PKG, "librto_hip.so")
+LIB_HOST = os.path.join(PKG, "librto_host.so")
+
+# -ffp-contract=off: one IEEE operation per source operator (the exactness contract).
+# HIP's default -fhip-fp32-correctly-rounded-divide-sqrt stays on; no fast-math anywhere.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+HOST_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wextra"]
+
+
+def _newer(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _sources(d: str, exts: tuple[str, ...]) -> list[str]:
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts))
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    deps = _sources(CSRC, (".hip", ".h")) + [os.path.join(HOST, "rtmath.h"), os.path.join(ROOT, "include", "rto_hip.h")]
+    if not force and _newer(LIB_HIP, deps):
+        return LIB_HIP
+    cmd = [hipcc, *HIP_FLAGS, os.path.join(CSRC, "rto_api.hip"), "-o", LIB_HIP]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_HIP
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    srcs = _sources(HOST, (".cpp",))
+    deps = srcs + _sources(HOST, (".h",)) + [os.path.join(ROOT, "include", "rto_hip.h")]
+    if not force and _newer(LIB_HOST, deps):
+        return LIB_HOST
+    cmd = ["g++", *HOST_FLAGS, "-I", os.path.join(ROOT, "include"), *srcs, "-o", LIB_HOST, "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_HOST
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_hip(force, verbose)
+    if os.path.isdir(HOST) and _sources(HOST, (".cpp",)):
+        build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force=True, verbose=True)

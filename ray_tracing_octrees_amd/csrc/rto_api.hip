@@ -1,0 +1,478 @@
+// rto_api.hip -- implementation of the C ABI in include/rto_hip.h (librto_hip.so).
+// Host side: argument checks, the canonical-octree repack, uniform hoisting
+// (inverse(view), tan(fov/2), frustum planes) and kernel launches.  No torch, no
+// oracle, no CPU fallback: every entry point needs a gfx950 device.
+#include "rto_device.hip.h"
+
+#include "../host/rtmath.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rto;
+
+struct rto_context {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string deviceName;
+
+    // resident octree
+    rto_node* d_nodes = nullptr;
+    int64_t numNodes = 0;
+    uint2* d_desc = nullptr;
+    int* d_descFirstChild = nullptr;
+    int64_t numInternal = 0;
+    int rootSize = 0, depth = 0;
+    bool canonical = false;
+    float gridMin[3] = { 0, 0, 0 };
+    float voxelSize = 1.f;
+    int kernelMode = RTO_KERNEL_AUTO;
+
+    // frustum culling state
+    bool culling = false;
+    int rootVisible = 1;
+    uint8_t* d_vis = nullptr;
+    int* d_remap = nullptr;
+    int* d_blockCount = nullptr;
+    int* d_blockBase = nullptr;
+    int64_t* d_visibleCount = nullptr;
+    rto_node* d_compact = nullptr;
+    int64_t visibleNodes = 0;
+
+    // outputs / instrumentation
+    float4* d_frame = nullptr;
+    size_t frameCap = 0;
+    int* d_steps = nullptr;
+    size_t stepsCap = 0;
+    Counters* d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+static thread_local std::string g_createError;
+
+static int fail(rto_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_createError = msg;
+    return code;
+}
+
+#define RTO_HIP(ctx, call)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, RTO_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+static void free_octree(rto_context* c) {
+    (void)hipFree(c->d_nodes); c->d_nodes = nullptr;
+    (void)hipFree(c->d_desc); c->d_desc = nullptr;
+    (void)hipFree(c->d_descFirstChild); c->d_descFirstChild = nullptr;
+    (void)hipFree(c->d_vis); c->d_vis = nullptr;
+    (void)hipFree(c->d_remap); c->d_remap = nullptr;
+    (void)hipFree(c->d_blockCount); c->d_blockCount = nullptr;
+    (void)hipFree(c->d_blockBase); c->d_blockBase = nullptr;
+    (void)hipFree(c->d_compact); c->d_compact = nullptr;
+    c->numNodes = c->numInternal = 0;
+    c->canonical = false; c->culling = false; c->rootVisible = 1; c->visibleNodes = 0;
+}
+
+extern "C" {
+
+int rto_create(int device_ordinal, rto_context** out) {
+    if (!out) return fail(nullptr, RTO_E_INVALID, "rto_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, RTO_E_NO_DEVICE, std::string("rto_create: no HIP device (") + hipGetErrorString(e) + ")");
+    if (device_ordinal < 0 || device_ordinal >= count)
+        return fail(nullptr, RTO_E_NO_DEVICE, "rto_create: device ordinal out of range");
+    rto_context* c = new rto_context();
+    c->device = device_ordinal;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, RTO_E_HIP, std::string("rto_create: ") + hipGetErrorString(e));
+    }
+    c->deviceName = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        std::string msg = "rto_create: device is " + c->deviceName + ", this library carries gfx950 code only";
+        delete c;
+        return fail(nullptr, RTO_E_NO_DEVICE, msg);
+    }
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipMalloc(&c->d_counters, sizeof(Counters))) != hipSuccess ||
+        (e = hipMalloc(&c->d_visibleCount, sizeof(int64_t))) != hipSuccess) {
+        std::string msg = std::string("rto_create: ") + hipGetErrorString(e);
+        rto_destroy(c);
+        return fail(nullptr, RTO_E_HIP, msg);
+    }
+    *out = c;
+    return RTO_OK;
+}
+
+void rto_destroy(rto_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_octree(c);
+    (void)hipFree(c->d_frame);
+    (void)hipFree(c->d_steps);
+    (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_visibleCount);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* rto_last_error(const rto_context* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
+
+int rto_device_name(const rto_context* ctx, char* buf, size_t buflen) {
+    if (!ctx || !buf || buflen == 0) return RTO_E_INVALID;
+    std::snprintf(buf, buflen, "%s", ctx->deviceName.c_str());
+    return RTO_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- canonical repack
+// A flat array is canonical when it is what setOctree's BFS emits for a tree built by
+// createOctreeFromVoxelGrid: root (0,0,0,2^d) at index 0; every internal node has its 8
+// children at 8 consecutive indices, in child order, each with the derived position/size.
+static inline bool is_terminal(const rto_node& n) { return n.isUniform == 1 || n.isLeaf == 1; }
+
+static bool build_descriptors(const rto_node* nodes, int64_t n, std::vector<uint2>& desc,
+                              std::vector<int>& firstChild, int& rootSize, int& depth) {
+    desc.clear(); firstChild.clear();
+    if (n <= 0) return false;
+    const rto_node& root = nodes[0];
+    rootSize = root.size; depth = 0;
+    if (is_terminal(root) || root.x != 0 || root.y != 0 || root.z != 0) return false;
+    if (root.size < 2 || (root.size & (root.size - 1)) != 0) return false;
+    while ((1 << depth) < root.size) depth++;
+    if (depth > kMaxDepth) return false;
+    std::vector<int> rank((size_t)n + 1);   // rank[i] = internal nodes among [0, i)
+    int r = 0;
+    for (int64_t i = 0; i < n; i++) { rank[(size_t)i] = r; r += is_terminal(nodes[i]) ? 0 : 1; }
+    rank[(size_t)n] = r;
+    desc.resize((size_t)r); firstChild.resize((size_t)r);
+    for (int64_t i = 0; i < n; i++) {
+        const rto_node& nd = nodes[i];
+        if (is_terminal(nd)) continue;
+        if (nd.size < 2 || (nd.size & (nd.size - 1)) != 0) return false;
+        const int half = nd.size / 2;
+        const int64_t c0 = nd.child[0];
+        if (c0 <= i || c0 + 7 >= n) return false;
+        unsigned imask = 0, smask = 0;
+        for (int k = 0; k < 8; k++) {
+            if (nd.child[k] != c0 + k) return false;
+            const rto_node& ch = nodes[c0 + k];
+            if (ch.size != half || ch.x != nd.x + ((k & 1) ? half : 0) || ch.y != nd.y + ((k & 2) ? half : 0) ||
+                ch.z != nd.z + ((k & 4) ? half : 0))
+                return false;
+            if (!is_terminal(ch)) imask |= 1u << k;
+            else if (ch.isSolid == 1) smask |= 1u << k;
+        }
+        const int d = rank[(size_t)i];
+        desc[(size_t)d] = make_uint2(imask | (smask << 8) | 0xff0000u, (unsigned)rank[(size_t)c0]);
+        firstChild[(size_t)d] = (int)c0;
+    }
+    return true;
+}
+
+extern "C" {
+
+int rto_upload_octree(rto_context* c, const rto_node* nodes, int64_t n, const float grid_min[3], float voxel_size) {
+    if (!c) return RTO_E_INVALID;
+    if (!nodes || n <= 0 || !grid_min) return fail(c, RTO_E_INVALID, "rto_upload_octree: empty node array");
+    if (n > 0x7fffffff) return fail(c, RTO_E_INVALID, "rto_upload_octree: node indices are int32 (GPUNodes.child)");
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    free_octree(c);
+    std::memcpy(c->gridMin, grid_min, sizeof c->gridMin);
+    c->voxelSize = voxel_size;
+    c->numNodes = n;
+    c->visibleNodes = n;
+    RTO_HIP(c, hipMalloc(&c->d_nodes, (size_t)n * sizeof(rto_node)));
+    RTO_HIP(c, hipMemcpy(c->d_nodes, nodes, (size_t)n * sizeof(rto_node), hipMemcpyHostToDevice));
+
+    std::vector<uint2> desc;
+    std::vector<int> firstChild;
+    c->canonical = build_descriptors(nodes, n, desc, firstChild, c->rootSize, c->depth);
+    if (c->canonical) {
+        c->numInternal = (int64_t)desc.size();
+        RTO_HIP(c, hipMalloc(&c->d_desc, desc.size() * sizeof(uint2)));
+        RTO_HIP(c, hipMemcpy(c->d_desc, desc.data(), desc.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        RTO_HIP(c, hipMalloc(&c->d_descFirstChild, firstChild.size() * sizeof(int)));
+        RTO_HIP(c, hipMemcpy(c->d_descFirstChild, firstChild.data(), firstChild.size() * sizeof(int), hipMemcpyHostToDevice));
+    } else {
+        int64_t internal = 0;
+        for (int64_t i = 0; i < n; i++) internal += is_terminal(nodes[i]) ? 0 : 1;
+        c->numInternal = internal;
+        c->rootSize = nodes[0].size;
+    }
+    return RTO_OK;
+}
+
+int rto_octree_info_get(const rto_context* c, rto_octree_info* out) {
+    if (!c || !out) return RTO_E_INVALID;
+    out->num_nodes = c->numNodes;
+    out->num_internal = c->numInternal;
+    out->root_size = c->rootSize;
+    out->depth = c->depth;
+    out->canonical = c->canonical ? 1 : 0;
+    out->culling_active = c->culling ? 1 : 0;
+    out->visible_nodes = c->visibleNodes;
+    return RTO_OK;
+}
+
+int rto_set_kernel(rto_context* c, int kernel) {
+    if (!c) return RTO_E_INVALID;
+    if (kernel != RTO_KERNEL_AUTO && kernel != RTO_KERNEL_GENERIC && kernel != RTO_KERNEL_PACKED)
+        return fail(c, RTO_E_INVALID, "rto_set_kernel: unknown kernel id");
+    if (kernel == RTO_KERNEL_PACKED && c->numNodes > 0 && !c->canonical)
+        return fail(c, RTO_E_UNSUPPORTED, "rto_set_kernel: packed kernel needs a canonical BFS octree");
+    c->kernelMode = kernel;
+    return RTO_OK;
+}
+
+// ---------------------------------------------------------------- frustum culling
+int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, float aspect, int enable) {
+    if (!c) return RTO_E_INVALID;
+    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_update_frustum: no octree uploaded");
+    RTO_HIP(c, hipSetDevice(c->device));
+    const int64_t n = c->numNodes;
+    const int nb = (int)((n + kBlock - 1) / kBlock);
+    const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
+    if (!enable) {
+        if (c->culling && c->canonical && nbInt > 0)
+            hipLaunchKernelGGL(k_desc_visall, dim3(nbInt), dim3(kBlock), 0, c->stream, c->numInternal, c->d_desc);
+        RTO_HIP(c, hipGetLastError());
+        c->culling = false; c->rootVisible = 1; c->visibleNodes = n;
+        return RTO_OK;
+    }
+    if (!view) return fail(c, RTO_E_INVALID, "rto_update_frustum: view is NULL");
+    if (!c->d_vis) {
+        RTO_HIP(c, hipMalloc(&c->d_vis, (size_t)n));
+        RTO_HIP(c, hipMalloc(&c->d_remap, (size_t)n * sizeof(int)));
+        RTO_HIP(c, hipMalloc(&c->d_blockCount, (size_t)nb * sizeof(int)));
+        RTO_HIP(c, hipMalloc(&c->d_blockBase, (size_t)nb * sizeof(int)));
+        RTO_HIP(c, hipMalloc(&c->d_compact, (size_t)n * sizeof(rto_node)));
+    }
+    // S/RT:731-734: Frustum(perspective(radians(fov), aspect, 0.01, 5000) * view)
+    CullParams C;
+    rtmath::mat4 proj = rtmath::perspective(rtmath::radians(fov_deg), aspect, 0.01f, 5000.f);
+    rtmath::mat4 vp = proj * rtmath::mat4::from(view);
+    rtmath::frustum_planes(vp, C.planes);
+    std::memcpy(C.gridMin, c->gridMin, sizeof C.gridMin);
+    C.voxelSize = c->voxelSize;
+    C.margin = 150.0f;
+    hipLaunchKernelGGL(k_cull_flags, dim3(nb), dim3(kBlock), 0, c->stream, C, c->d_nodes, n, c->d_vis, c->d_blockCount);
+    hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, c->stream, c->d_blockCount, nb, c->d_blockBase, c->d_visibleCount);
+    hipLaunchKernelGGL(k_cull_remap, dim3(nb), dim3(kBlock), 0, c->stream, c->d_vis, n, c->d_blockBase, c->d_remap);
+    hipLaunchKernelGGL(k_cull_compact, dim3(nb), dim3(kBlock), 0, c->stream, c->d_nodes, n, c->d_remap, c->d_compact);
+    if (c->canonical && nbInt > 0)
+        hipLaunchKernelGGL(k_desc_vismask, dim3(nbInt), dim3(kBlock), 0, c->stream, c->d_vis, c->d_descFirstChild, c->numInternal, c->d_desc);
+    RTO_HIP(c, hipGetLastError());
+    int64_t visible = 0;
+    uint8_t rootVis = 0;
+    RTO_HIP(c, hipMemcpyAsync(&visible, c->d_visibleCount, sizeof visible, hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipMemcpyAsync(&rootVis, c->d_vis, 1, hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    c->visibleNodes = visible;
+    c->rootVisible = rootVis ? 1 : 0;
+    c->culling = true;
+    return RTO_OK;
+}
+
+int rto_download_visible_nodes(rto_context* c, rto_node* out, int64_t capacity, int64_t* count) {
+    if (!c || !count) return RTO_E_INVALID;
+    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_download_visible_nodes: no octree uploaded");
+    RTO_HIP(c, hipSetDevice(c->device));
+    *count = c->visibleNodes;
+    if (!out) return RTO_OK;
+    if (capacity < c->visibleNodes) return fail(c, RTO_E_INVALID, "rto_download_visible_nodes: capacity too small");
+    const rto_node* src = c->culling ? c->d_compact : c->d_nodes;
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    RTO_HIP(c, hipMemcpy(out, src, (size_t)c->visibleNodes * sizeof(rto_node), hipMemcpyDeviceToHost));
+    return RTO_OK;
+}
+
+// ---------------------------------------------------------------- render
+int rto_partition_rows(const rto_frame* f, const rto_partition* p) {
+    if (!f || f->height <= 0) return 0;
+    if (!p || p->num_parts <= 1) return f->height;
+    if (p->band_rows <= 0 || p->part < 0 || p->part >= p->num_parts) return 0;
+    const int bands = (f->height + p->band_rows - 1) / p->band_rows;
+    int rows = 0;
+    for (int b = p->part; b < bands; b += p->num_parts) {
+        int lo = b * p->band_rows, hi = lo + p->band_rows;
+        rows += (hi < f->height ? hi : f->height) - lo;
+    }
+    return rows;
+}
+
+}  // extern "C"
+
+static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* p, RenderParams& P) {
+    if (!f) return fail(c, RTO_E_INVALID, "render: frame is NULL");
+    if (f->width <= 0 || f->height <= 0) return fail(c, RTO_E_INVALID, "render: width/height must be positive");
+    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "render: no octree uploaded (setOctree first)");
+    if (p && p->num_parts > 1 && (p->band_rows <= 0 || (p->band_rows % 8) != 0 || p->part < 0 || p->part >= p->num_parts))
+        return fail(c, RTO_E_INVALID, "render: partition needs band_rows % 8 == 0 and 0 <= part < num_parts");
+    rtmath::mat4 inv = rtmath::inverse(rtmath::mat4::from(f->view));        // S/RT:348
+    std::memcpy(P.invView, inv.data(), sizeof P.invView);
+    std::memcpy(P.camPos, f->cam_pos, sizeof P.camPos);
+    P.aspect = f->aspect;
+    P.tanHalfFov = std::tan(rtmath::radians(f->fov_deg) * 0.5f);               // S/RT:340,344
+    std::memcpy(P.gridMin, c->gridMin, sizeof P.gridMin);
+    P.voxelSize = c->voxelSize;
+    rtmath::vec3 l = rtmath::normalize(rtmath::vec3(-1.0f, -1.0f, -1.0f));     // S/RT:333
+    P.lightNeg[0] = -l.x; P.lightNeg[1] = -l.y; P.lightNeg[2] = -l.z;
+    P.W = f->width; P.H = f->height;
+    P.rootSize = c->rootSize; P.depth = c->depth > 0 ? c->depth : 1;
+    P.numParts = (p && p->num_parts > 1) ? p->num_parts : 1;
+    P.part = P.numParts > 1 ? p->part : 0;
+    P.bandRows = P.numParts > 1 ? p->band_rows : f->height;
+    P.localRows = rto_partition_rows(f, p);
+    P.tilesX = (P.W + 7) / 8;
+    P.tilesY = (P.localRows + 7) / 8;
+    P.rootVisible = c->rootVisible;
+    return RTO_OK;
+}
+
+template <int MODE>
+static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hipStream_t s) {
+    const int tiles = P.tilesX * P.tilesY;
+    if (tiles <= 0) return RTO_OK;
+    const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
+    bool packed = c->kernelMode == RTO_KERNEL_PACKED || (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
+    if (packed && !c->canonical) return fail(c, RTO_E_UNSUPPORTED, "render: packed kernel needs a canonical BFS octree");
+    RTO_HIP(c, hipEventRecord(c->ev0, s));
+    if (packed) {
+        const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint2);
+        hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
+    } else {
+        const rto_node* nodes = c->culling ? c->d_compact : c->d_nodes;
+        RenderParams Q = P;
+        if (c->culling && c->visibleNodes == 0) Q.rootVisible = 0;   // empty SSBO: nothing to traverse
+        else if (c->culling) Q.rootVisible = 1;                      // compacted index 0 is whatever survived first (S/RT:765-772)
+        hipLaunchKernelGGL(k_trace_generic<MODE>, dim3(blocks), dim3(kBlock), 0, s, Q, nodes, d_out, c->d_steps, c->d_counters);
+    }
+    RTO_HIP(c, hipGetLastError());
+    RTO_HIP(c, hipEventRecord(c->ev1, s));
+    c->timed = true;
+    return RTO_OK;
+}
+
+static int ensure_frame(rto_context* c, size_t pixels) {
+    if (c->frameCap >= pixels) return RTO_OK;
+    (void)hipFree(c->d_frame); c->d_frame = nullptr; c->frameCap = 0;
+    RTO_HIP(c, hipMalloc(&c->d_frame, pixels * sizeof(float4)));
+    c->frameCap = pixels;
+    return RTO_OK;
+}
+
+static int ensure_steps(rto_context* c, size_t pixels) {
+    if (c->stepsCap >= pixels) return RTO_OK;
+    (void)hipFree(c->d_steps); c->d_steps = nullptr; c->stepsCap = 0;
+    RTO_HIP(c, hipMalloc(&c->d_steps, pixels * sizeof(int)));
+    c->stepsCap = pixels;
+    return RTO_OK;
+}
+
+extern "C" {
+
+int rto_render_device(rto_context* c, const rto_frame* f, const rto_partition* p, void* d_out, void* hip_stream) {
+    if (!c) return RTO_E_INVALID;
+    if (!d_out) return fail(c, RTO_E_INVALID, "rto_render_device: d_out is NULL");
+    RTO_HIP(c, hipSetDevice(c->device));
+    RenderParams P;
+    int rc = fill_params(c, f, p, P);
+    if (rc != RTO_OK) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    return launch_trace<kModeColor>(c, P, (float4*)d_out, s);
+}
+
+int rto_render_host(rto_context* c, const rto_frame* f, float* host_rgba) {
+    if (!c) return RTO_E_INVALID;
+    if (!host_rgba) return fail(c, RTO_E_INVALID, "rto_render_host: host_rgba is NULL");
+    RTO_HIP(c, hipSetDevice(c->device));
+    RenderParams P;
+    int rc = fill_params(c, f, nullptr, P);
+    if (rc != RTO_OK) return rc;
+    const size_t pixels = (size_t)f->width * f->height;
+    if ((rc = ensure_frame(c, pixels)) != RTO_OK) return rc;
+    if ((rc = launch_trace<kModeColor>(c, P, c->d_frame, c->stream)) != RTO_OK) return rc;
+    RTO_HIP(c, hipMemcpyAsync(host_rgba, c->d_frame, pixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    return RTO_OK;
+}
+
+int rto_assemble_device(rto_context* c, const rto_frame* f, const rto_partition* p, const void* d_gathered,
+                        void* d_frame, void* hip_stream) {
+    if (!c || !f || !p || !d_gathered || !d_frame) return c ? fail(c, RTO_E_INVALID, "rto_assemble_device: NULL argument") : RTO_E_INVALID;
+    if (p->num_parts < 1 || p->band_rows <= 0) return fail(c, RTO_E_INVALID, "rto_assemble_device: bad partition");
+    RTO_HIP(c, hipSetDevice(c->device));
+    rto_partition p0 = *p; p0.part = 0;
+    const int partRows = rto_partition_rows(f, &p0);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipLaunchKernelGGL(k_assemble, dim3(2048), dim3(256), 0, s, (const float4*)d_gathered, (float4*)d_frame,
+                       f->width, f->height, p->num_parts, p->num_parts > 1 ? p->band_rows : f->height, partRows);
+    RTO_HIP(c, hipGetLastError());
+    return RTO_OK;
+}
+
+static int run_steps(rto_context* c, const rto_frame* f, rto_stats* st, int32_t* host_steps) {
+    RTO_HIP(c, hipSetDevice(c->device));
+    RenderParams P;
+    int rc = fill_params(c, f, nullptr, P);
+    if (rc != RTO_OK) return rc;
+    const size_t pixels = (size_t)f->width * f->height;
+    if ((rc = ensure_steps(c, pixels)) != RTO_OK) return rc;
+    RTO_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));
+    RTO_HIP(c, hipMemsetAsync(c->d_steps, 0, pixels * sizeof(int), c->stream));
+    if ((rc = launch_trace<kModeSteps>(c, P, nullptr, c->stream)) != RTO_OK) return rc;
+    Counters h;
+    RTO_HIP(c, hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    if (host_steps) RTO_HIP(c, hipMemcpyAsync(host_steps, c->d_steps, pixels * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    if (st) { st->rays = pixels; st->pops = h.pops; st->hits = h.hits; st->capped = h.capped; }
+    return RTO_OK;
+}
+
+int rto_frame_stats(rto_context* c, const rto_frame* f, rto_stats* out) {
+    if (!c) return RTO_E_INVALID;
+    if (!out) return fail(c, RTO_E_INVALID, "rto_frame_stats: out is NULL");
+    return run_steps(c, f, out, nullptr);
+}
+
+int rto_render_steps_host(rto_context* c, const rto_frame* f, int32_t* host_steps) {
+    if (!c) return RTO_E_INVALID;
+    if (!host_steps) return fail(c, RTO_E_INVALID, "rto_render_steps_host: host_steps is NULL");
+    return run_steps(c, f, nullptr, host_steps);
+}
+
+int rto_last_kernel_ms(rto_context* c, float* ms) {
+    if (!c || !ms) return RTO_E_INVALID;
+    if (!c->timed) return fail(c, RTO_E_INVALID, "rto_last_kernel_ms: no kernel launched yet");
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipEventSynchronize(c->ev1));
+    RTO_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return RTO_OK;
+}
+
+int rto_synchronize(rto_context* c) {
+    if (!c) return RTO_E_INVALID;
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    return RTO_OK;
+}
+
+}  // extern "C"

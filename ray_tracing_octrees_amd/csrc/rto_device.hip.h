@@ -1,0 +1,507 @@
+// rto_device.hip.h -- gfx950 device code of librto_hip.so.
+//
+// Replaces the GLSL compute shader of the reference's RayTracerBVH
+// (453-skeleton/RayTracerBVH.cpp:182-369, "S/RT" below).  Two traversal kernels
+// produce bit-identical pixels:
+//
+//   k_trace_generic  walks the uploaded 60-byte GPUNodes array with explicit child
+//                    indices and a private stack[128] -- a direct statement of
+//                    S/RT:239-327, used for arbitrary (e.g. user-compacted) arrays.
+//
+//   k_trace_packed   the MI355X path.  For canonical BFS octrees (what
+//                    setOctree produces, S/RT:443-490) the tree is re-encoded as one
+//                    8-byte child descriptor per INTERNAL node:
+//                        .x = internalMask | solidMask<<8 | visibleMask<<16
+//                        .y = descriptor index of the first internal child
+//                    Leaves need no storage (a 256^3 scene shrinks from 22.5 MB to
+//                    375 KB and lives in every XCD's L2).  One loop iteration = one
+//                    internal node: the 8 child slab tests share 12 per-axis
+//                    half-plane terms, empty leaves are never tested (they only
+//                    advance the step counter, which is all S/RT:257-274 does for
+//                    them), and the per-ray stack is one 8-byte entry per tree LEVEL
+//                    in LDS ([level][lane], bank-conflict free) instead of
+//                    stack[128] per thread.
+//
+// Exactness contract (DESIGN.md "Numerics"): every float expression keeps the
+// operation order of the GLSL/glm source, the TU is compiled with
+// -ffp-contract=off and HIP's default correctly-rounded fp32 divide/sqrt, so the
+// pixels equal the CPU oracle's bit for bit.  min/max follow glm's
+// (y<x)?y:x convention; rays whose reciprocal direction is not finite (the only
+// way a NaN can enter the slab test) take an exact compare/select path, all other
+// rays use v_min_f32/v_max3_f32, which agree with that convention on non-NaN data
+// up to the sign of zero, which no later operation can observe.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rto_hip.h"
+
+namespace rto {
+
+constexpr int kMaxTraversalSteps = 512;   // S/RT:192
+constexpr int kWave = 64;
+constexpr int kBlock = 256;               // 4 waves, each owns one 8x8 pixel tile
+constexpr int kMaxDepth = 20;             // log2(root size) supported by the packed kernel
+
+struct RenderParams {
+    float invView[16];     // glm::inverse(view), hoisted from S/RT:348 (pixel independent)
+    float camPos[3];
+    float aspect;
+    float tanHalfFov;      // tan(radians(fov) * 0.5), hoisted from S/RT:340-344
+    float gridMin[3];
+    float voxelSize;
+    float lightNeg[3];     // -normalize(vec3(-1)), S/RT:333-334
+    int W, H;
+    int rootSize, depth;
+    int numParts, part, bandRows;   // rto_partition
+    int localRows;                  // rows this part owns
+    int tilesX, tilesY;             // 8x8 tiles over W x localRows
+    int rootVisible;                // 0 => frustum update culled the root: black frame
+};
+
+// ---------------------------------------------------------------- scalar helpers
+// glm/detail/func_common.inl: min(x,y) = (y<x)?y:x ; max(x,y) = (x<y)?y:x
+__device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }
+__device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }
+
+template <bool EXACT> struct MinMax;
+template <> struct MinMax<true> {
+    static __device__ __forceinline__ float mn(float x, float y) { return gmin(x, y); }
+    static __device__ __forceinline__ float mx(float x, float y) { return gmax(x, y); }
+};
+template <> struct MinMax<false> {
+    static __device__ __forceinline__ float mn(float x, float y) { return __builtin_fminf(x, y); }
+    static __device__ __forceinline__ float mx(float x, float y) { return __builtin_fmaxf(x, y); }
+};
+
+// sqrtf -> llvm.sqrt.f32 = v_sqrt_f32 + 2 fma fix-ups (correctly rounded); __fsqrt_rn is the bare 1-ulp v_sqrt_f32.
+__device__ __forceinline__ float inversesqrt(float x) { return 1.0f / __builtin_sqrtf(x); }
+
+__device__ __forceinline__ int global_row(const RenderParams& P, int ly) {
+    if (P.numParts == 1) return ly;
+    int band = ly / P.bandRows;
+    int r = ly - band * P.bandRows;
+    return (band * P.numParts + P.part) * P.bandRows + r;
+}
+
+struct Ray {
+    float ox, oy, oz;
+    float dx, dy, dz;
+    float ix, iy, iz;   // 1.0 / d  (S/RT:228, hoisted: it never changes along a ray)
+};
+
+// S/RT:338-355 generateRay
+__device__ __forceinline__ Ray generate_ray(const RenderParams& P, int px, int py) {
+    float nx = ((float)px + 0.5f) / (float)P.W * 2.0f - 1.0f;
+    float ny = 1.0f - ((float)py + 0.5f) / (float)P.H * 2.0f;
+    nx *= P.aspect;
+    nx *= P.tanHalfFov;
+    ny *= P.tanHalfFov;
+    // normalize(vec4(nx, ny, -1, 0)): glm vec4 dot = (x*x + y*y) + (z*z + w*w)
+    float d4 = (nx * nx + ny * ny) + ((-1.0f) * (-1.0f) + 0.0f * 0.0f);
+    float inv4 = inversesqrt(d4);
+    float vx = nx * inv4, vy = ny * inv4, vz = (-1.0f) * inv4, vw = 0.0f * inv4;
+    // invView * v: glm mat4*vec4 = (m0*v0 + m1*v1) + (m2*v2 + m3*v3)
+    const float* m = P.invView;
+    float wx = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
+    float wy = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
+    float wz = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
+    // normalize(vec3): dot = x*x + y*y + z*z
+    float d3 = wx * wx + wy * wy + wz * wz;
+    float inv3 = inversesqrt(d3);
+    Ray r;
+    r.ox = P.camPos[0]; r.oy = P.camPos[1]; r.oz = P.camPos[2];
+    r.dx = wx * inv3; r.dy = wy * inv3; r.dz = wz * inv3;
+    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+    return r;
+}
+
+// S/RT:226-236 intersectAABB + S/RT:265-266 node box, for one node given by integer coords.
+__device__ __forceinline__ bool slab_exact(const RenderParams& P, const Ray& r, int x, int y, int z, int size,
+                                           float& tNear, float& tFar,
+                                           float& mnx, float& mny, float& mnz, float& mxx, float& mxy, float& mxz) {
+    float vs = P.voxelSize;
+    mnx = P.gridMin[0] + (float)x * vs;
+    mny = P.gridMin[1] + (float)y * vs;
+    mnz = P.gridMin[2] + (float)z * vs;
+    float ext = (float)size * vs;
+    mxx = mnx + ext; mxy = mny + ext; mxz = mnz + ext;
+    float t1x = (mnx - r.ox) * r.ix, t1y = (mny - r.oy) * r.iy, t1z = (mnz - r.oz) * r.iz;
+    float t2x = (mxx - r.ox) * r.ix, t2y = (mxy - r.oy) * r.iy, t2z = (mxz - r.oz) * r.iz;
+    float tminx = gmin(t1x, t2x), tminy = gmin(t1y, t2y), tminz = gmin(t1z, t2z);
+    float tmaxx = gmax(t1x, t2x), tmaxy = gmax(t1y, t2y), tmaxz = gmax(t1z, t2z);
+    tNear = gmax(gmax(tminx, tminy), tminz);
+    tFar = gmin(gmin(tmaxx, tmaxy), tmaxz);
+    return (tNear <= tFar && tFar > 0.0f);
+}
+
+// Hit epilogue: S/RT:279-285 (tHit, centre pseudo-normal) + S/RT:331-336 (Lambert).
+__device__ __forceinline__ float4 shade_hit(const RenderParams& P, const Ray& r, int x, int y, int z, int size) {
+    float tNear, tFar, mnx, mny, mnz, mxx, mxy, mxz;
+    slab_exact(P, r, x, y, z, size, tNear, tFar, mnx, mny, mnz, mxx, mxy, mxz);
+    float tHit = gmax(0.0f, tNear);
+    float cx = 0.5f * (mnx + mxx), cy = 0.5f * (mny + mxy), cz = 0.5f * (mnz + mxz);
+    float px = r.ox + r.dx * tHit, py = r.oy + r.dy * tHit, pz = r.oz + r.dz * tHit;
+    float qx = px - cx, qy = py - cy, qz = pz - cz;
+    float inv = inversesqrt(qx * qx + qy * qy + qz * qz);
+    float nx = qx * inv, ny = qy * inv, nz = qz * inv;
+    float ndotl = gmax(0.0f, nx * P.lightNeg[0] + ny * P.lightNeg[1] + nz * P.lightNeg[2]);
+    return make_float4(1.0f * ndotl + 0.1f, 0.8f * ndotl + 0.1f, 0.6f * ndotl + 0.1f, 1.0f);
+}
+
+// Output modes of the traversal kernels.
+constexpr int kModeColor = 0;   // RGBA32F framebuffer
+constexpr int kModeSteps = 1;   // per-pixel +/-steps and frame counters (instrumentation)
+
+struct Counters { unsigned long long pops, hits, capped; };
+
+__device__ __forceinline__ void wave_accumulate(Counters* c, int steps, bool hit, bool valid) {
+    // per-wave reduction, then one atomic per counter per wave
+    unsigned long long pops = valid ? (unsigned long long)steps : 0ull;
+    unsigned long long hits = (valid && hit) ? 1ull : 0ull;
+    unsigned long long capped = (valid && !hit && steps >= kMaxTraversalSteps) ? 1ull : 0ull;
+    for (int off = 32; off > 0; off >>= 1) {
+        pops += __shfl_down(pops, off);
+        hits += __shfl_down(hits, off);
+        capped += __shfl_down(capped, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&c->pops, pops);
+        atomicAdd(&c->hits, hits);
+        atomicAdd(&c->capped, capped);
+    }
+}
+
+// ================================================================ generic kernel
+// Direct statement of S/RT:239-327 over the 60-byte array.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_trace_generic(RenderParams P, const rto_node* __restrict__ nodes,
+                                                           float4* __restrict__ out, int* __restrict__ stepsOut,
+                                                           Counters* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+    const int px = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    const bool inImage = valid && (py < P.H);
+
+    bool hit = false;
+    int steps = 0;
+    float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (inImage && P.rootVisible) {
+        Ray r = generate_ray(P, px, py);
+        int stack[128];                 // S/RT:247
+        int sp = 0;
+        stack[sp++] = 0;
+        const float closestT = 1e30f;   // S/RT:242; only ever written together with the break
+        while (sp > 0 && steps < kMaxTraversalSteps) {
+            sp--;
+            int nodeIdx = stack[sp];
+            if (nodeIdx < 0) continue;
+            steps++;
+            const rto_node nd = nodes[nodeIdx];
+            float tNear, tFar, a0, a1, a2, a3, a4, a5;
+            if (!slab_exact(P, r, nd.x, nd.y, nd.z, nd.size, tNear, tFar, a0, a1, a2, a3, a4, a5)) continue;
+            if (tNear >= closestT) continue;
+            if (nd.isUniform == 1 || nd.isLeaf == 1) {   // S/RT:277-311, both branches have one body
+                if (nd.isSolid == 1) {
+                    float tHit = gmax(0.0f, tNear);
+                    if (tHit < closestT && tHit <= tFar) {
+                        hit = true;
+                        color = shade_hit(P, r, nd.x, nd.y, nd.z, nd.size);
+                        break;
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int c = nd.child[i];
+                if (c >= 0) stack[sp++] = c;
+            }
+        }
+    }
+    if (MODE == kModeColor) {
+        if (valid) out[(size_t)ly * P.W + px] = color;
+    } else {
+        if (inImage) stepsOut[(size_t)py * P.W + px] = hit ? steps : -steps;
+        wave_accumulate(counters, steps, hit, inImage);
+    }
+}
+
+// ================================================================ packed kernel
+// 8 child slab tests of the internal node at integer position (cx,cy,cz) whose children
+// have edge `half`.  Returns the 8-bit mask of children k (bit0=+x, bit1=+y, bit2=+z,
+// S/OctreeVoxel.cpp:751-754) with   tNear <= tFar && tFar > 0 && !(tNear >= 1e30)
+// i.e. the ones that survive S/RT:269-274.
+template <bool EXACT>
+__device__ __forceinline__ unsigned child_pass_mask(const RenderParams& P, const Ray& r, int cx, int cy, int cz, int half) {
+    using M = MinMax<EXACT>;
+    const float vs = P.voxelSize;
+    const float sv = (float)half * vs;                       // vec3(node.size) * voxelSize
+    float tmn[3][2], tmx[3][2];
+    const int c[3] = { cx, cy, cz };
+    const float o[3] = { r.ox, r.oy, r.oz };
+    const float inv[3] = { r.ix, r.iy, r.iz };
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float flo = P.gridMin[a] + (float)c[a] * vs;          // nodeMin of the low children
+        float fhi = P.gridMin[a] + (float)(c[a] + half) * vs; // nodeMin of the high children
+        float mlo = flo + sv, mhi = fhi + sv;                 // their nodeMax
+        float t1 = (flo - o[a]) * inv[a], t2 = (mlo - o[a]) * inv[a];
+        tmn[a][0] = M::mn(t1, t2); tmx[a][0] = M::mx(t1, t2);
+        float u1 = (fhi - o[a]) * inv[a], u2 = (mhi - o[a]) * inv[a];
+        tmn[a][1] = M::mn(u1, u2); tmx[a][1] = M::mx(u1, u2);
+    }
+    unsigned pass = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        float tn = M::mx(M::mx(tmn[0][k & 1], tmn[1][(k >> 1) & 1]), tmn[2][k >> 2]);
+        float tf = M::mn(M::mn(tmx[0][k & 1], tmx[1][(k >> 1) & 1]), tmx[2][k >> 2]);
+        bool ok = (tn <= tf) && (tf > 0.0f) && !(tn >= 1e30f);
+        pass |= ok ? (1u << k) : 0u;
+    }
+    return pass;
+}
+
+// LDS stack entry (one per tree level per lane):
+//   .x = pending (8) | internalMask (8) << 8 | visibleMask (8) << 16      .y = first-internal-child descriptor
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_trace_packed(RenderParams P, const uint2* __restrict__ desc,
+                                                          float4* __restrict__ out, int* __restrict__ stepsOut,
+                                                          Counters* __restrict__ counters) {
+    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;   // entry(level) = stk[level * 64]
+
+    const int tile = blockIdx.x * (kBlock / kWave) + wave;
+    const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+    const int px = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    const bool inImage = valid && (py < P.H);
+
+    bool hit = false;
+    int steps = 0;
+    int hx = 0, hy = 0, hz = 0, hs = 0;   // the solid leaf that was hit
+    Ray r;
+    bool alive = false;
+    if (inImage && P.rootVisible) {
+        r = generate_ray(P, px, py);
+        // pop of the root: S/RT:254-274 with nodeIdx 0
+        float tNear, tFar, a0, a1, a2, a3, a4, a5;
+        steps = 1;
+        alive = slab_exact(P, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+    }
+    // A NaN can only enter a slab test through a non-finite reciprocal direction or origin.
+    const bool risky = alive && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
+                                  __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
+
+    int cur = 0;                 // descriptor of the node whose children are being popped
+    int cx = 0, cy = 0, cz = 0;  // its integer position
+    int half = P.rootSize >> 1;  // its children's edge
+    int sp = 0;                  // == its level
+
+    while (alive) {
+        // ---- the node was popped and is internal: S/RT:313-318 pushes child[0..7], so they pop 7..0
+        const uint2 d = desc[cur];
+        const unsigned vis = (d.x >> 16) & 0xffu;
+        const unsigned imask = d.x & vis & 0xffu;
+        const unsigned smask = (d.x >> 8) & vis & 0xffu;
+        unsigned passMask;
+        if (__builtin_amdgcn_ballot_w64(risky) != 0ull) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
+        else passMask = child_pass_mask<false>(P, r, cx, cy, cz, half);
+        // children that do more than count a step: internal ones that pass the slab test, and solid
+        // leaves that pass it (for those S/RT:279-280 always accepts: tHit=max(0,tNear)<=tFar, <1e30)
+        unsigned pending = (imask | smask) & passMask;
+        const unsigned solidHit = smask & passMask;
+        if (solidHit) pending &= ~((1u << (31 - __builtin_clz(solidHit))) - 1u);   // nothing below the first hit is reached
+        unsigned im = imask, vm = vis, base = d.y;
+        int prev = 8;   // children prev..7 of this node have been popped already
+        // ---- pop children / climb until the next internal node is entered or the ray ends
+        for (;;) {
+            if (pending == 0) {
+                steps += __builtin_popcount(vm & ((1u << prev) - 1u));   // the rest only count steps
+                if (sp == 0 || steps >= kMaxTraversalSteps) { alive = false; break; }
+                sp--;
+                const uint2 e = stk[sp * kWave];
+                pending = e.x & 0xffu; im = (e.x >> 8) & 0xffu; vm = (e.x >> 16) & 0xffu; base = e.y;
+                half <<= 1;
+                prev = ((cx & half) ? 1 : 0) | ((cy & half) ? 2 : 0) | ((cz & half) ? 4 : 0);
+                const int keep = ~((half << 1) - 1);
+                cx &= keep; cy &= keep; cz &= keep;
+                continue;
+            }
+            const int j = 31 - __builtin_clz(pending);
+            const int skipped = __builtin_popcount(vm & ((1u << prev) - 1u) & ~((2u << j) - 1u));
+            if (steps + skipped >= kMaxTraversalSteps) { steps = kMaxTraversalSteps; alive = false; break; }   // S/RT:254 cap
+            steps += skipped + 1;
+            pending &= ~(1u << j);
+            prev = j;
+            const int nx = cx + ((j & 1) ? half : 0), ny = cy + ((j & 2) ? half : 0), nz = cz + ((j & 4) ? half : 0);
+            if (!((im >> j) & 1u)) {   // solid leaf: S/RT:278-288 hit + break
+                hit = true; hx = nx; hy = ny; hz = nz; hs = half;
+                alive = false;
+                break;
+            }
+            // internal child that passed its slab test: enter it
+            stk[sp * kWave] = make_uint2(pending | (im << 8) | (vm << 16), base);
+            sp++;
+            cur = (int)(base + (unsigned)__builtin_popcount(im & ((1u << j) - 1u)));
+            cx = nx; cy = ny; cz = nz;
+            half >>= 1;
+            break;
+        }
+    }
+    if (!hit && steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
+
+    if (MODE == kModeColor) {
+        if (valid) {
+            float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+            if (hit) color = shade_hit(P, r, hx, hy, hz, hs);
+            out[(size_t)ly * P.W + px] = color;
+        }
+    } else {
+        if (inImage) stepsOut[(size_t)py * P.W + px] = hit ? steps : -steps;
+        wave_accumulate(counters, steps, hit, inImage);
+    }
+}
+
+// ================================================================ frustum culling (N3)
+// GPU form of the CPU loop + compaction of renderSceneComputeWithCulling
+// (S/RT:743-802) with Frustum::testAABB (453-skeleton/Frustum.cpp:52-93).
+struct CullParams {
+    float planes[24];      // LEFT, RIGHT, TOP, BOTTOM, NEAR, FAR; normalised (Frustum.cpp:5-48), from the host
+    float gridMin[3];
+    float voxelSize;
+    float margin;          // 150.0f at S/RT:755
+};
+
+// testAABB(...) != -1.  Only the positive-vertex test can return -1 (Frustum.cpp:68-78).
+__device__ __forceinline__ bool node_visible(const CullParams& C, int x, int y, int z, int size) {
+    float mn[3] = { C.gridMin[0] + (float)x * C.voxelSize, C.gridMin[1] + (float)y * C.voxelSize,
+                    C.gridMin[2] + (float)z * C.voxelSize };                     // S/RT:747-751
+    float ext = (float)size * C.voxelSize;                                      // S/RT:752
+    float emn[3], emx[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { emn[a] = mn[a] - C.margin; emx[a] = (mn[a] + ext) + C.margin; }
+    bool inside = true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const float* pl = C.planes + i * 4;
+        float px = pl[0] > 0 ? emx[0] : emn[0];
+        float py = pl[1] > 0 ? emx[1] : emn[1];
+        float pz = pl[2] > 0 ? emx[2] : emn[2];
+        float tx = pl[0] * px, ty = pl[1] * py, tz = pl[2] * pz;
+        if ((tx + ty + tz) + pl[3] < 0) inside = false;
+    }
+    return inside;
+}
+
+// one thread per node: visibility flag + per-block visible count
+__global__ __launch_bounds__(kBlock) void k_cull_flags(CullParams C, const rto_node* __restrict__ nodes, int64_t n,
+                                                        uint8_t* __restrict__ vis, int* __restrict__ blockCount) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool v = false;
+    if (i < n) {
+        const rto_node* nd = nodes + i;
+        v = node_visible(C, nd->x, nd->y, nd->z, nd->size);
+        vis[i] = v ? 1 : 0;
+    }
+    int cnt = __syncthreads_count(v ? 1 : 0);
+    if (threadIdx.x == 0) blockCount[blockIdx.x] = cnt;
+}
+
+// single block: exclusive scan of the per-block counts; total -> *visibleCount
+__global__ __launch_bounds__(1024) void k_scan_block_counts(const int* __restrict__ blockCount, int nb,
+                                                             int* __restrict__ blockBase, int64_t* __restrict__ visibleCount) {
+    __shared__ int partial[1024];
+    const int t = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int lo = t * per, hi = min(lo + per, nb);
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += blockCount[i];
+    partial[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+        int v = (t >= off) ? partial[t - off] : 0;
+        __syncthreads();
+        partial[t] += v;
+        __syncthreads();
+    }
+    int run = partial[t] - s;   // exclusive prefix of this thread's chunk
+    for (int i = lo; i < hi; i++) { blockBase[i] = run; run += blockCount[i]; }
+    if (t == 1023) *visibleCount = partial[1023];
+}
+
+// old index -> new index (-1 if culled): S/RT:765-772
+__global__ __launch_bounds__(kBlock) void k_cull_remap(const uint8_t* __restrict__ vis, int64_t n,
+                                                        const int* __restrict__ blockBase, int* __restrict__ remap) {
+    __shared__ int waveTotal[kBlock / kWave];
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool v = (i < n) && vis[i];
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int before = __builtin_popcountll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) waveTotal[wave] = __builtin_popcountll(b);
+    __syncthreads();
+    int base = blockBase[blockIdx.x];
+    for (int w = 0; w < wave; w++) base += waveTotal[w];
+    if (i < n) remap[i] = v ? base + before : -1;
+}
+
+// S/RT:778-802: copy visible nodes, remap children of non-leaf nodes (culled child -> -1)
+__global__ __launch_bounds__(kBlock) void k_cull_compact(const rto_node* __restrict__ nodes, int64_t n,
+                                                          const int* __restrict__ remap, rto_node* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int dst = remap[i];
+    if (dst < 0) return;
+    rto_node nd = nodes[i];
+    if (!nd.isLeaf) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            int oc = nd.child[c];
+            nd.child[c] = (oc >= 0 && oc < n) ? remap[oc] : -1;
+        }
+    }
+    out[dst] = nd;
+}
+
+// packed tree: visibility of the 8 children of every internal node -> descriptor bits 16..23
+__global__ __launch_bounds__(kBlock) void k_desc_vismask(const uint8_t* __restrict__ vis, const int* __restrict__ descFirstChild,
+                                                          int64_t nInternal, uint2* __restrict__ desc) {
+    int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (d >= nInternal) return;
+    const int c0 = descFirstChild[d];
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) m |= vis[c0 + k] ? (1u << k) : 0u;
+    desc[d].x = (desc[d].x & 0xffffu) | (m << 16);
+}
+
+__global__ __launch_bounds__(kBlock) void k_desc_visall(int64_t nInternal, uint2* __restrict__ desc) {
+    int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (d < nInternal) desc[d].x |= 0xff0000u;
+}
+
+// ================================================================ multi-GPU reassembly
+// d_gathered: numParts compact buffers, each padded to partRows rows of W pixels.
+__global__ void k_assemble(const float4* __restrict__ gathered, float4* __restrict__ frame,
+                           int W, int H, int numParts, int bandRows, int partRows) {
+    const size_t n = (size_t)W * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        int gband = y / bandRows, r = y - gband * bandRows;
+        int part = gband % numParts, band = gband / numParts;
+        size_t src = ((size_t)part * partRows + (size_t)band * bandRows + r) * W + x;
+        frame[i] = gathered[src];
+    }
+}
+
+}  // namespace rto

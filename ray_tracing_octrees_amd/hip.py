@@ -1,0 +1,219 @@
+"""ctypes binding of the C ABI in include/rto_hip.h (librto_hip.so).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is
+usable, `load()` / `Context()` raise `RtoError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+RTO_OK = 0
+RTO_E_INVALID, RTO_E_NO_OCTREE, RTO_E_HIP, RTO_E_NO_DEVICE, RTO_E_UNSUPPORTED = -1, -2, -3, -4, -5
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED = 0, 1, 2
+
+# struct GPUNodes (453-skeleton/RayTracerBVH.h:21-26)
+NODE_DTYPE = np.dtype(
+    [("x", "<i4"), ("y", "<i4"), ("z", "<i4"), ("size", "<i4"),
+     ("isLeaf", "<i4"), ("isSolid", "<i4"), ("isUniform", "<i4"), ("child", "<i4", (8,))]
+)
+
+# every symbol include/rto_hip.h declares
+SYMBOLS = (
+    "rto_create", "rto_destroy", "rto_last_error", "rto_device_name",
+    "rto_upload_octree", "rto_octree_info_get", "rto_set_kernel",
+    "rto_update_frustum", "rto_download_visible_nodes",
+    "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
+    "rto_frame_stats", "rto_render_steps_host", "rto_last_kernel_ms", "rto_synchronize",
+)
+
+
+class RtoError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rto error {code}: {msg}")
+        self.code = code
+
+
+class Frame(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("cam_pos", C.c_float * 3), ("aspect", C.c_float),
+                ("fov_deg", C.c_float), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Partition(C.Structure):
+    _fields_ = [("num_parts", C.c_int32), ("part", C.c_int32), ("band_rows", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("pops", C.c_uint64), ("hits", C.c_uint64), ("capped", C.c_uint64)]
+
+
+class OctreeInfo(C.Structure):
+    _fields_ = [("num_nodes", C.c_int64), ("num_internal", C.c_int64), ("root_size", C.c_int32),
+                ("depth", C.c_int32), ("canonical", C.c_int32), ("culling_active", C.c_int32),
+                ("visible_nodes", C.c_int64)]
+
+
+_lib = None
+
+
+def _f(x) -> float:
+    """A Python float that holds exactly the binary32 value of x."""
+    return float(np.float32(x))
+
+
+def lib_path() -> str:
+    return _build.LIB_HIP
+
+
+def load():
+    """dlopen librto_hip.so and declare prototypes.  Raises RtoError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RtoError(RTO_E_NO_DEVICE, f"{path} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.rto_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rto_destroy.argtypes = [vp]
+    L.rto_destroy.restype = None
+    L.rto_last_error.argtypes = [vp]
+    L.rto_last_error.restype = C.c_char_p
+    L.rto_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.rto_upload_octree.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_float), C.c_float]
+    L.rto_octree_info_get.argtypes = [vp, C.POINTER(OctreeInfo)]
+    L.rto_set_kernel.argtypes = [vp, C.c_int]
+    L.rto_update_frustum.argtypes = [vp, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int]
+    L.rto_download_visible_nodes.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.rto_render_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp]
+    L.rto_render_host.argtypes = [vp, C.POINTER(Frame), vp]
+    L.rto_partition_rows.argtypes = [C.POINTER(Frame), C.POINTER(Partition)]
+    L.rto_assemble_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp, vp]
+    L.rto_frame_stats.argtypes = [vp, C.POINTER(Frame), C.POINTER(Stats)]
+    L.rto_render_steps_host.argtypes = [vp, C.POINTER(Frame), vp]
+    L.rto_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.rto_synchronize.argtypes = [vp]
+    for s in SYMBOLS:
+        if getattr(L, s).restype is C.c_int:   # default
+            getattr(L, s).restype = C.c_int
+    _lib = L
+    return L
+
+
+def make_frame(view, cam_pos, aspect, fov_deg, width, height) -> Frame:
+    f = Frame()
+    v = np.asarray(view, dtype=np.float32).reshape(16)
+    p = np.asarray(cam_pos, dtype=np.float32).reshape(3)
+    v = np.ascontiguousarray(v)
+    p = np.ascontiguousarray(p)
+    C.memmove(f.view, v.ctypes.data, 64)       # bit copies: no double rounding
+    C.memmove(f.cam_pos, p.ctypes.data, 12)
+    f.aspect = _f(aspect)
+    f.fov_deg = _f(fov_deg)
+    f.width, f.height = int(width), int(height)
+    return f
+
+
+class Context:
+    """One rto_context == one GPU."""
+
+    def __init__(self, device: int = 0):
+        self._L = load()
+        h = C.c_void_p()
+        rc = self._L.rto_create(device, C.byref(h))
+        if rc != RTO_OK:
+            raise RtoError(rc, self._L.rto_last_error(None).decode())
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rto_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != RTO_OK:
+            raise RtoError(rc, self._L.rto_last_error(self._h).decode())
+
+    @property
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self._check(self._L.rto_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    # -- octree ------------------------------------------------------------
+    def upload_octree(self, nodes: np.ndarray, grid_min, voxel_size):
+        nodes = np.ascontiguousarray(nodes)
+        if nodes.dtype.itemsize != 60:
+            raise RtoError(RTO_E_INVALID, "nodes must be an array of 60-byte GPUNodes records")
+        gm = (C.c_float * 3)(*[_f(x) for x in grid_min])
+        self._check(self._L.rto_upload_octree(self._h, nodes.ctypes.data, len(nodes), gm, _f(voxel_size)))
+
+    def info(self) -> OctreeInfo:
+        o = OctreeInfo()
+        self._check(self._L.rto_octree_info_get(self._h, C.byref(o)))
+        return o
+
+    def set_kernel(self, kernel: int):
+        self._check(self._L.rto_set_kernel(self._h, kernel))
+
+    # -- culling -----------------------------------------------------------
+    def update_frustum(self, view, fov_deg, aspect, enable=True):
+        v = np.ascontiguousarray(np.asarray(view, dtype=np.float32).reshape(16))
+        self._check(self._L.rto_update_frustum(self._h, v.ctypes.data_as(C.POINTER(C.c_float)),
+                                               _f(fov_deg), _f(aspect), 1 if enable else 0))
+
+    def download_visible_nodes(self) -> np.ndarray:
+        cnt = C.c_int64()
+        self._check(self._L.rto_download_visible_nodes(self._h, None, 0, C.byref(cnt)))
+        out = np.zeros(cnt.value, NODE_DTYPE)
+        if cnt.value:
+            self._check(self._L.rto_download_visible_nodes(self._h, out.ctypes.data, cnt.value, C.byref(cnt)))
+        return out
+
+    # -- render ------------------------------------------------------------
+    def render_host(self, frame: Frame) -> np.ndarray:
+        out = np.empty((frame.height, frame.width, 4), np.float32)
+        self._check(self._L.rto_render_host(self._h, C.byref(frame), out.ctypes.data))
+        return out
+
+    def render_device(self, frame: Frame, d_out: int, part: Partition | None = None, stream: int = 0):
+        self._check(self._L.rto_render_device(self._h, C.byref(frame), C.byref(part) if part else None,
+                                              C.c_void_p(d_out), C.c_void_p(stream) if stream else None))
+
+    def assemble_device(self, frame: Frame, part: Partition, d_gathered: int, d_frame: int, stream: int = 0):
+        self._check(self._L.rto_assemble_device(self._h, C.byref(frame), C.byref(part), C.c_void_p(d_gathered),
+                                                C.c_void_p(d_frame), C.c_void_p(stream) if stream else None))
+
+    def partition_rows(self, frame: Frame, part: Partition | None) -> int:
+        return self._L.rto_partition_rows(C.byref(frame), C.byref(part) if part else None)
+
+    def frame_stats(self, frame: Frame) -> dict:
+        s = Stats()
+        self._check(self._L.rto_frame_stats(self._h, C.byref(frame), C.byref(s)))
+        return {"rays": s.rays, "pops": s.pops, "hits": s.hits, "capped": s.capped}
+
+    def render_steps(self, frame: Frame) -> np.ndarray:
+        out = np.zeros((frame.height, frame.width), np.int32)
+        self._check(self._L.rto_render_steps_host(self._h, C.byref(frame), out.ctypes.data))
+        return out
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self._L.rto_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def synchronize(self):
+        self._check(self._L.rto_synchronize(self._h))
