@@ -24,6 +24,24 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-sha
 HOST_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wextra"]
 
 
+def preload_torch_runtime() -> bool:
+    """Load torch's bundled ROCm runtime BEFORE librto_hip.so when torch is installed.
+
+    PyTorch wheels ship their own libamdhip64.so/libhsa-runtime64.so and libtorch_hip.so asks for the
+    unversioned name, so a system copy that is already mapped is not reused: the process ends up with two
+    HIP runtimes and the second one finds no GPU.  In the other order glibc resolves our
+    NEEDED libamdhip64.so.7 to torch's already-loaded copy by SONAME and both sides share one runtime --
+    which is also what makes torch tensors' data_ptr()/streams valid arguments of the C ABI.
+    Set RTO_NO_TORCH=1 to skip (pure C/C++ processes never need this)."""
+    if os.environ.get("RTO_NO_TORCH") == "1":
+        return False
+    try:
+        import torch  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
 def _newer(target: str, sources: list[str]) -> bool:
     if not os.path.exists(target):
         return False

@@ -268,7 +268,7 @@ __device__ __forceinline__ unsigned child_pass_mask(const RenderParams& P, const
 }
 
 // LDS stack entry (one per tree level per lane):
-//   .x = pending (8) | internalMask (8) << 8 | visibleMask (8) << 16      .y = first-internal-child descriptor
+//   .x = pending (8) | internalMask, unmasked (8) << 8 | visibleMask (8) << 16      .y = first-internal-child descriptor
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_trace_packed(RenderParams P, const uint2* __restrict__ desc,
                                                           float4* __restrict__ out, int* __restrict__ stepsOut,
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed(RenderParams P, const u
         // ---- the node was popped and is internal: S/RT:313-318 pushes child[0..7], so they pop 7..0
         const uint2 d = desc[cur];
         const unsigned vis = (d.x >> 16) & 0xffu;
-        const unsigned imask = d.x & vis & 0xffu;
+        const unsigned imaskAll = d.x & 0xffu;          // every internal child owns a descriptor, visible or not
+        const unsigned imask = imaskAll & vis;
         const unsigned smask = (d.x >> 8) & vis & 0xffu;
         unsigned passMask;
         if (__builtin_amdgcn_ballot_w64(risky) != 0ull) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed(RenderParams P, const u
         unsigned pending = (imask | smask) & passMask;
         const unsigned solidHit = smask & passMask;
         if (solidHit) pending &= ~((1u << (31 - __builtin_clz(solidHit))) - 1u);   // nothing below the first hit is reached
-        unsigned im = imask, vm = vis, base = d.y;
+        unsigned im = imaskAll, vm = vis, base = d.y;   // im ranks descriptors and tells internal from solid
         int prev = 8;   // children prev..7 of this node have been popped already
         // ---- pop children / climb until the next internal node is entered or the ray ends
         for (;;) {

@@ -78,6 +78,7 @@ def load():
     if not os.path.exists(path):
         raise RtoError(RTO_E_NO_DEVICE, f"{path} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                         "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _build.preload_torch_runtime()     # one HIP runtime per process (see _build.preload_torch_runtime)
     L = C.CDLL(path)
     vp = C.c_void_p
     L.rto_create.argtypes = [C.c_int, C.POINTER(vp)]

@@ -1,0 +1,198 @@
+// RayTracerBVH.cpp -- host side of the drop-in class; see RayTracerBVH.h.
+// Call structure follows 453-skeleton/RayTracerBVH.cpp:393-892; every GL call there maps to one
+// rto_* call here (table in INTEGRATION.md).
+#include "RayTracerBVH.h"
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+namespace {
+
+// The C ABI, resolved at run time so this translation unit builds with a plain C++ compiler.
+struct HipApi {
+    void* handle = nullptr;
+    decltype(&rto_create) create = nullptr;
+    decltype(&rto_destroy) destroy = nullptr;
+    decltype(&rto_last_error) last_error = nullptr;
+    decltype(&rto_upload_octree) upload_octree = nullptr;
+    decltype(&rto_update_frustum) update_frustum = nullptr;
+    decltype(&rto_render_host) render_host = nullptr;
+    std::string error;
+
+    bool load() {
+        if (handle) return true;
+        std::vector<std::string> candidates;
+        if (const char* env = std::getenv("RTO_HIP_LIB")) candidates.emplace_back(env);
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(&anchor), &info) && info.dli_fname) {   // next to this library
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.find_last_of('/');
+            dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+            candidates.push_back(dir + "/librto_hip.so");
+        }
+        candidates.emplace_back("librto_hip.so");
+        for (const std::string& path : candidates) {
+            handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+            error = dlerror();
+        }
+        if (!handle) return false;
+        bool ok = true;
+        auto sym = [&](const char* name) {
+            void* p = dlsym(handle, name);
+            if (!p) { ok = false; error = std::string("missing symbol ") + name; }
+            return p;
+        };
+        create = reinterpret_cast<decltype(create)>(sym("rto_create"));
+        destroy = reinterpret_cast<decltype(destroy)>(sym("rto_destroy"));
+        last_error = reinterpret_cast<decltype(last_error)>(sym("rto_last_error"));
+        upload_octree = reinterpret_cast<decltype(upload_octree)>(sym("rto_upload_octree"));
+        update_frustum = reinterpret_cast<decltype(update_frustum)>(sym("rto_update_frustum"));
+        render_host = reinterpret_cast<decltype(render_host)>(sym("rto_render_host"));
+        if (!ok) { dlclose(handle); handle = nullptr; }
+        return ok;
+    }
+    static void anchor() {}
+};
+
+HipApi& api() {
+    static HipApi a;
+    return a;
+}
+
+}  // namespace
+
+RayTracerBVH::RayTracerBVH()
+    : m_octreeRoot(nullptr), m_numNodes(0), m_computeInited(false), m_computeOk(false),
+      m_frustumCullingEnabled(true), m_device(0), m_ctx(nullptr), m_frameW(0), m_frameH(0) {}
+
+RayTracerBVH::~RayTracerBVH() {
+    if (m_ctx) api().destroy(m_ctx);
+}
+
+std::vector<GPUNodes> RayTracerBVH::flatten(const OctreeNode* root) {
+    // Breadth-first; a child receives the next free index at the moment its parent is dequeued, so the 8
+    // children of an internal node are consecutive and the root is 0 (RayTracerBVH.cpp:443-490).
+    std::vector<GPUNodes> flat;
+    if (!root) return flat;
+    std::vector<const OctreeNode*> order;
+    order.push_back(root);
+    for (size_t head = 0; head < order.size(); head++) {
+        const OctreeNode* nd = order[head];
+        GPUNodes g;
+        g.x = nd->x; g.y = nd->y; g.z = nd->z; g.size = nd->size;
+        g.isLeaf = nd->isLeaf ? 1 : 0;
+        g.isSolid = nd->isSolid ? 1 : 0;
+        g.isUniform = nd->isUniform ? 1 : 0;
+        for (int& c : g.child) c = -1;
+        if (!nd->isLeaf)
+            for (int i = 0; i < 8; i++)
+                if (const OctreeNode* c = nd->children[i]) {
+                    g.child[i] = static_cast<int>(order.size());
+                    order.push_back(c);
+                }
+        flat.push_back(g);
+    }
+    return flat;
+}
+
+void RayTracerBVH::setOctree(OctreeNode* root, const VoxelGrid& grid) {
+    m_octreeRoot = root;
+    m_grid = grid;                      // the reference copies the grid too (RayTracerBVH.cpp:433)
+    m_flatNodes.clear();
+    m_numNodes = 0;
+    if (!root) return;                  // :439
+    m_flatNodes = flatten(root);
+    m_numNodes = static_cast<int>(m_flatNodes.size());
+    if (!m_ctx) return;                 // uploaded by ensureComputeInitialized() once the device exists
+    const float gridMin[3] = { m_grid.minX, m_grid.minY, m_grid.minZ };
+    if (api().upload_octree(m_ctx, reinterpret_cast<const rto_node*>(m_flatNodes.data()), m_numNodes, gridMin,
+                            m_grid.voxelSize) != RTO_OK) {
+        m_lastError = api().last_error(m_ctx);
+        std::cerr << "[RayTracerBVH] octree upload failed: " << m_lastError << std::endl;
+        m_computeOk = false;
+    }
+}
+
+void RayTracerBVH::ensureComputeInitialized() {
+    if (m_computeInited) return;
+    m_computeInited = true;
+    if (!api().load()) {
+        m_lastError = "cannot load librto_hip.so: " + api().error;
+        std::cerr << "[RayTracerBVH] " << m_lastError << std::endl;
+        return;
+    }
+    if (api().create(m_device, &m_ctx) != RTO_OK) {
+        m_lastError = api().last_error(nullptr);
+        std::cerr << "[RayTracerBVH] " << m_lastError << std::endl;
+        m_ctx = nullptr;
+        return;
+    }
+    m_computeOk = true;
+    if (m_numNodes > 0) {               // setOctree() came first
+        const float gridMin[3] = { m_grid.minX, m_grid.minY, m_grid.minZ };
+        if (api().upload_octree(m_ctx, reinterpret_cast<const rto_node*>(m_flatNodes.data()), m_numNodes, gridMin,
+                                m_grid.voxelSize) != RTO_OK) {
+            m_lastError = api().last_error(m_ctx);
+            std::cerr << "[RayTracerBVH] octree upload failed: " << m_lastError << std::endl;
+            m_computeOk = false;
+        }
+    }
+}
+
+bool RayTracerBVH::render(const Camera& camera, int width, int height, float aspect, float fovDeg) {
+    rto_frame f;
+    const rtmath::mat4 view = camera.getView();
+    std::memcpy(f.view, view.data(), sizeof f.view);
+    const rtmath::vec3 pos = camera.getPos();
+    f.cam_pos[0] = pos.x; f.cam_pos[1] = pos.y; f.cam_pos[2] = pos.z;
+    f.aspect = aspect;
+    f.fov_deg = fovDeg;
+    f.width = width;
+    f.height = height;
+    if (width <= 0 || height <= 0) return false;
+    m_frame.resize(static_cast<size_t>(width) * height * 4);
+    m_frameW = width; m_frameH = height;
+    if (api().render_host(m_ctx, &f, m_frame.data()) != RTO_OK) {
+        m_lastError = api().last_error(m_ctx);
+        std::cerr << "[RayTracerBVH] render failed: " << m_lastError << std::endl;
+        return false;
+    }
+    return true;
+}
+
+void RayTracerBVH::renderSceneCompute(const Camera& camera, int width, int height, float aspect, float fovDeg) {
+    if (!m_computeInited || !m_computeOk) {
+        std::cerr << "[RayTracerBVH] Compute pipeline not initialized or failed.\n";
+        return;
+    }
+    if (m_numNodes <= 0) return;
+    render(camera, width, height, aspect, fovDeg);
+}
+
+void RayTracerBVH::renderSceneComputeWithCulling(const Camera& camera, int width, int height, float aspect,
+                                                 float fovDeg, bool updateFrustum) {
+    if (!m_computeInited || !m_computeOk) {
+        std::cerr << "[RayTracerBVH] Compute pipeline not initialized or failed.\n";
+        return;
+    }
+    if (m_numNodes <= 0) {
+        std::printf("No nodes to render.\n");
+        return;
+    }
+    if (updateFrustum) {
+        // the reference recomputes visibility on the CPU and re-uploads the compacted array
+        // (RayTracerBVH.cpp:725-813); here the same test and compaction run on the GPU.
+        const rtmath::mat4 view = camera.getView();
+        if (api().update_frustum(m_ctx, view.data(), fovDeg, aspect, 1) != RTO_OK) {
+            m_lastError = api().last_error(m_ctx);
+            std::cerr << "[RayTracerBVH] frustum update failed: " << m_lastError << std::endl;
+            return;
+        }
+    }
+    render(camera, width, height, aspect, fovDeg);
+}

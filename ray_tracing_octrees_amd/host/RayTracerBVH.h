@@ -1,0 +1,77 @@
+// RayTracerBVH.h -- drop-in for the reference class of the same name
+// (453-skeleton/RayTracerBVH.h:28-80; used at 453-skeleton/main.cpp:1127-1131 and :1357-1363).
+// Same public methods, same argument meaning, same error behaviour (void + a line on std::cerr);
+// the OpenGL compute dispatch is replaced by hand-written gfx950 kernels behind the C ABI of
+// include/rto_hip.h, loaded from librto_hip.so.  If that library or a gfx950 device is missing,
+// ensureComputeInitialized() reports it on std::cerr and every render call keeps printing the
+// reference's "[RayTracerBVH] Compute pipeline not initialized or failed." -- there is no CPU path.
+//
+// One addition: the reference leaves the image in a GL texture and never reads it back; here the
+// last frame is available through framebuffer() (RGBA32F, row-major, row 0 = top).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "Camera.h"
+#include "Frustum.h"
+#include "OctreeVoxel.h"
+#include "rto_hip.h"
+
+// GPU-side node record, same name and layout as the reference's (RayTracerBVH.h:21-26)
+struct GPUNodes {
+    int x, y, z, size;
+    int isLeaf, isSolid;
+    int isUniform;
+    int child[8];
+};
+static_assert(sizeof(GPUNodes) == sizeof(rto_node), "GPUNodes must stay 60 bytes");
+
+struct Ray {
+    rtmath::vec3 origin;
+    rtmath::vec3 direction;
+};
+
+class RayTracerBVH {
+public:
+    RayTracerBVH();
+    ~RayTracerBVH();
+    RayTracerBVH(const RayTracerBVH&) = delete;
+    RayTracerBVH& operator=(const RayTracerBVH&) = delete;
+
+    void setOctree(OctreeNode* root, const VoxelGrid& grid);
+    void ensureComputeInitialized();
+    void renderSceneCompute(const Camera& camera, int width, int height, float aspect, float fovDeg);
+    void setFrustumCullingEnabled(bool enabled) { m_frustumCullingEnabled = enabled; }
+    void renderSceneComputeWithCulling(const Camera& camera, int width, int height, float aspect, float fovDeg,
+                                       bool updateFrustum);
+
+    // ---- additions (not in the reference) ----
+    // BFS numbering of setOctree (RayTracerBVH.cpp:443-490) without touching the GPU.
+    static std::vector<GPUNodes> flatten(const OctreeNode* root);
+    const std::vector<GPUNodes>& flatNodes() const { return m_flatNodes; }
+    const std::vector<float>& framebuffer() const { return m_frame; }   // width*height*4 floats of the last render
+    int frameWidth() const { return m_frameW; }
+    int frameHeight() const { return m_frameH; }
+    void setDevice(int ordinal) { m_device = ordinal; }                  // before ensureComputeInitialized()
+    rto_context* context() const { return m_ctx; }
+    const std::string& lastError() const { return m_lastError; }
+
+private:
+    bool render(const Camera& camera, int width, int height, float aspect, float fovDeg);
+
+    OctreeNode* m_octreeRoot;
+    VoxelGrid m_grid;
+    std::vector<GPUNodes> m_flatNodes;
+    int m_numNodes;
+
+    bool m_computeInited;
+    bool m_computeOk;
+    bool m_frustumCullingEnabled;
+    int m_device;
+    rto_context* m_ctx;
+    std::string m_lastError;
+
+    std::vector<float> m_frame;
+    int m_frameW, m_frameH;
+};

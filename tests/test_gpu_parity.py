@@ -1,0 +1,347 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ray_tracing_octrees_amd.hip.Context
+is a 1:1 ctypes binding of include/rto_hip.h), against the CPU oracle on the same inputs.
+
+Bar: BIT-EXACT RGBA32F pixels (stricter than BASELINE.json's 1e-4 per channel -- the tolerance written in
+the north star is 1e-4; every comparison below asserts equality of the float bit patterns) and exact
+per-pixel traversal step counts (the reference's first-hit-in-DFS-order + 512-pop-cap semantics)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ray_tracing_octrees_amd as rto
+from ray_tracing_octrees_amd import hip
+from conftest import assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4   # north-star tolerance; never reached: see assert_bit_exact
+
+KERNELS = [("packed", rto.KERNEL_PACKED), ("generic", rto.KERNEL_GENERIC)]
+
+
+def oracle_frame(orc, s, view, pos, W, H, aspect=None, fov=45.0):
+    out = np.zeros((H, W, 4), np.float32)
+    return orc.render(s.nodes, s.min, s.voxel, view, pos, (W / H) if aspect is None else aspect, fov, W, H,
+                      nthreads=min(16, orc.max_threads()), out=out)
+
+
+def upload(ctx, s):
+    ctx.set_kernel(rto.KERNEL_AUTO)
+    ctx.upload_octree(s.nodes, s.min, s.voxel)
+
+
+@pytest.mark.parametrize("kname,kernel", KERNELS)
+@pytest.mark.parametrize("scene,W,H", [("sphere16", 64, 64), ("sphere32", 96, 64), ("sphere64", 512, 512),
+                                       ("odd", 200, 120), ("sphere32", 1, 1), ("sphere32", 7, 13), ("sphere32", 250, 9)])
+def test_pixels_and_steps_match_oracle(ctx, orc, scenes, camera, scene, W, H, kname, kernel):
+    s = scenes(scene)
+    if scene == "odd":
+        cam = orc.Camera(0.4, 0.9, 9.0)
+        view, pos = cam.get_view(), cam.get_pos()
+    else:
+        view, pos = camera("sphere")
+    upload(ctx, s)
+    ctx.set_kernel(kernel)
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, st = oracle_frame(orc, s, view, pos, W, H)
+    got = ctx.render_host(f)
+    assert np.abs(got - want).max() <= TOL
+    assert_bit_exact(got, want, f"{scene} {W}x{H} {kname}")
+    np.testing.assert_array_equal(ctx.render_steps(f), orc.render_steps(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H))
+    gs = ctx.frame_stats(f)
+    assert (gs["rays"], gs["pops"], gs["hits"], gs["capped"]) == (W * H, st["pops"], st["hits"], st["capped"])
+
+
+@pytest.mark.parametrize("kname,kernel", KERNELS)
+def test_golden_images(ctx, scenes, camera, golden, kname, kernel):
+    z = golden("orc_images_small.npz")
+    view, pos = camera("sphere")
+    for dim, (W, H) in ((16, (64, 64)), (32, (96, 64))):
+        upload(ctx, scenes(f"sphere{dim}"))
+        ctx.set_kernel(kernel)
+        f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+        assert_bit_exact(ctx.render_host(f), z[f"sphere{dim}_{W}x{H}_rgba"], f"golden sphere{dim} {kname}")
+        np.testing.assert_array_equal(ctx.render_steps(f), z[f"sphere{dim}_{W}x{H}_steps"])
+
+
+@pytest.mark.parametrize("kname,kernel", KERNELS)
+def test_config2_full_size_256_1080p(ctx, orc, scenes, camera, golden_meta, kname, kernel):
+    """BASELINE config 2 at full size: 256^3 shell sphere, 1920x1080, including the 434 capped rays."""
+    s = scenes("sphere256")
+    view, pos = camera("sphere")
+    W, H = 1920, 1080
+    upload(ctx, s)
+    ctx.set_kernel(kernel)
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, st = oracle_frame(orc, s, view, pos, W, H)
+    got = ctx.render_host(f)
+    assert_bit_exact(got, want, f"config2 {kname}")
+    gs = ctx.frame_stats(f)
+    m = golden_meta["images"]["sphere256_1920x1080"]
+    assert (gs["pops"], gs["hits"], gs["capped"]) == (m["pops"], m["hits"], m["capped"]) == (st["pops"], st["hits"], st["capped"])
+    # size-independent properties of any frame of this path
+    assert (got[..., 3] == 1.0).all()
+    miss = (got[..., :3] == 0).all(axis=-1)
+    assert int((~miss).sum()) == st["hits"]
+    lit = got[~miss][:, :3]
+    assert lit.min() >= np.float32(0.1) and lit.max() <= np.float32(1.1)
+
+
+@pytest.mark.parametrize("cam_name,W,H", [("calgary_default", 1300, 1300), ("calgary_oblique", 1920, 1080)])
+def test_config4_calgary(ctx, orc, scenes, camera, golden_meta, cam_name, W, H):
+    """BASELINE config 4: the shipped sceneCache.bin grid (425x243x29, root 512); default app camera (eye
+    inside a solid leaf: every ray hits at t=0) and the oblique, divergent camera."""
+    s = scenes("calgary")
+    view, pos = camera(cam_name)
+    upload(ctx, s)
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, st = oracle_frame(orc, s, view, pos, W, H)
+    m = golden_meta["images"][f"{cam_name}_{W}x{H}"]
+    assert (st["pops"], st["hits"]) == (m["pops"], m["hits"])
+    for kname, kernel in KERNELS:
+        ctx.set_kernel(kernel)
+        assert_bit_exact(ctx.render_host(f), want, f"calgary {cam_name} {kname}")
+        gs = ctx.frame_stats(f)
+        assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"])
+
+
+def test_config5_primary_rays_512_4k(ctx, orc, scenes, camera):
+    """BASELINE config 5, primary rays only (the triangle/shadow extension has no reference): 512^3, 3840x2160."""
+    s = scenes("sphere512")
+    view, pos = camera("sphere")
+    W, H = 3840, 2160
+    upload(ctx, s)
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, st = oracle_frame(orc, s, view, pos, W, H)
+    assert_bit_exact(ctx.render_host(f), want, "config5 primary")
+    gs = ctx.frame_stats(f)
+    assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"])
+    assert st["capped"] > 10000      # ~15.7k rays run into the 512-pop cap here
+
+
+def test_axis_aligned_rays_take_the_exact_nan_path(ctx, orc, scenes):
+    """Rays with zero direction components give 1/0 = inf and 0*inf = NaN in the slab test (S/RT:228-230).
+    An axis-aligned camera at odd resolution puts such rays through grid-plane-aligned origins."""
+    s = scenes("sphere32")
+    upload(ctx, s)
+    W, H = 65, 33
+    for (t, p, r, target) in ((0.0, 0.0, 1.5, (0.0, 0.0, 0.0)), (0.0, np.float32(np.pi / 2), 2.0, (0.0, 0.0, 0.0)),
+                              (0.0, 0.0, 1.0, (float(s.min[0] + 8 * s.voxel), float(s.min[1] + 16 * s.voxel), 0.0))):
+        cam = orc.Camera(t, p, r)
+        cam._c.target[0], cam._c.target[1], cam._c.target[2] = target
+        view, pos = cam.get_view(), cam.get_pos()
+        want, st = oracle_frame(orc, s, view, pos, W, H)
+        f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+        for kname, kernel in KERNELS:
+            ctx.set_kernel(kernel)
+            assert_bit_exact(ctx.render_host(f), want, f"axis-aligned {kname}")
+            np.testing.assert_array_equal(ctx.render_steps(f), orc.render_steps(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H))
+        assert st["hits"] > 0
+
+
+def test_eye_inside_solid_and_far_away(ctx, orc, scenes):
+    s = scenes("sphere32")
+    upload(ctx, s)
+    W, H = 96, 64
+    for radius in (0.3, 0.05, 40.0):     # inside the shell material (tHit = 0), inside the hollow core, sub-pixel sphere
+        cam = orc.Camera(0.2, 0.3, radius)
+        view, pos = cam.get_view(), cam.get_pos()
+        want, _ = oracle_frame(orc, s, view, pos, W, H)
+        f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+        for kname, kernel in KERNELS:
+            ctx.set_kernel(kernel)
+            assert_bit_exact(ctx.render_host(f), want, f"r={radius} {kname}")
+
+
+def test_aspect_and_fov_are_the_callers(ctx, orc, scenes, camera):
+    s = scenes("sphere32")
+    view, pos = camera("sphere")
+    upload(ctx, s)
+    W, H = 120, 50
+    for aspect, fov in ((1.0, 45.0), (2.4, 45.0), (W / H, 20.0), (0.5, 100.0)):
+        want, _ = oracle_frame(orc, s, view, pos, W, H, aspect=aspect, fov=fov)
+        assert_bit_exact(ctx.render_host(rto.make_frame(view, pos, aspect, fov, W, H)), want, f"aspect {aspect} fov {fov}")
+
+
+def test_single_node_and_noncanonical_arrays_fall_back_to_generic(ctx, orc, scenes, camera):
+    view, pos = camera("sphere")
+    W, H = 64, 48
+    # (a) a one-node tree: the whole grid is one solid leaf
+    for fill in (1, 0):
+        g = orc.Grid((4, 4, 4), np.array([-0.5, -0.5, -0.5], np.float32), np.float32(0.25), np.full((4, 4, 4), fill, np.uint8))
+        nodes = orc.build_flat_octree(g)
+        assert len(nodes) == 1
+        ctx.set_kernel(rto.KERNEL_AUTO)
+        ctx.upload_octree(nodes, g.min, g.voxel_size)
+        assert ctx.info().canonical == 0
+        want, _ = orc.render(nodes, g.min, g.voxel_size, view, pos, W / H, 45.0, W, H)
+        assert_bit_exact(ctx.render_host(rto.make_frame(view, pos, W / H, 45.0, W, H)), want, "single node")
+        with pytest.raises(rto.RtoError) as e:
+            ctx.set_kernel(rto.KERNEL_PACKED)
+        assert e.value.code == hip.RTO_E_UNSUPPORTED
+    # (b) a frustum-compacted array uploaded as-is: children no longer consecutive, some are -1
+    cal = scenes("calgary")
+    cview, cpos = camera("calgary_oblique")
+    compact, _ = orc.cull_compact(cal.nodes, cal.min, cal.voxel, cview, 45.0, W / H)
+    ctx.set_kernel(rto.KERNEL_AUTO)
+    ctx.upload_octree(compact, cal.min, cal.voxel)
+    assert ctx.info().canonical == 0
+    want, _ = orc.render(compact, cal.min, cal.voxel, cview, cpos, W / H, 45.0, W, H)
+    assert_bit_exact(ctx.render_host(rto.make_frame(cview, cpos, W / H, 45.0, W, H)), want, "compacted upload")
+
+
+@pytest.mark.parametrize("cam_name", ["calgary_oblique", "calgary_default"])
+def test_frustum_update_equals_reference_compaction(ctx, orc, scenes, camera, cam_name):
+    """renderSceneComputeWithCulling(updateFrustum=true): GPU test + compaction == S/RT:731-802 on the CPU."""
+    cal = scenes("calgary")
+    view, pos = camera(cam_name)
+    W, H = 480, 270
+    aspect = W / H
+    upload(ctx, cal)
+    want_nodes, vis = orc.cull_compact(cal.nodes, cal.min, cal.voxel, view, 45.0, aspect)
+    ctx.update_frustum(view, 45.0, aspect, enable=True)
+    got_nodes = ctx.download_visible_nodes()
+    assert ctx.info().culling_active == 1 and ctx.info().visible_nodes == len(want_nodes) == int(vis.sum())
+    assert got_nodes.tobytes() == want_nodes.tobytes()
+    want, st = orc.render(want_nodes, cal.min, cal.voxel, view, pos, aspect, 45.0, W, H)
+    f = rto.make_frame(view, pos, aspect, 45.0, W, H)
+    for kname, kernel in KERNELS:
+        ctx.set_kernel(kernel)
+        assert_bit_exact(ctx.render_host(f), want, f"culled {cam_name} {kname}")
+        gs = ctx.frame_stats(f)
+        assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"])
+    # a different camera through the culled tree (what the reference shows between frustum updates)
+    cam2 = orc.Camera(0.9, 2.5, 3000.0)
+    v2, p2 = cam2.get_view(), cam2.get_pos()
+    want2, _ = orc.render(want_nodes, cal.min, cal.voxel, v2, p2, aspect, 45.0, W, H)
+    f2 = rto.make_frame(v2, p2, aspect, 45.0, W, H)
+    for kname, kernel in KERNELS:
+        ctx.set_kernel(kernel)
+        assert_bit_exact(ctx.render_host(f2), want2, f"culled, other camera {kname}")
+    # disabling restores the full tree
+    ctx.update_frustum(view, 45.0, aspect, enable=False)
+    full, _ = orc.render(cal.nodes, cal.min, cal.voxel, v2, p2, aspect, 45.0, W, H)
+    for kname, kernel in KERNELS:
+        ctx.set_kernel(kernel)
+        assert_bit_exact(ctx.render_host(f2), full, f"culling off {kname}")
+
+
+def test_frustum_update_that_culls_nothing_and_everything(ctx, orc, scenes, camera):
+    s = scenes("sphere32")
+    view, pos = camera("sphere")
+    upload(ctx, s)
+    ctx.update_frustum(view, 45.0, 1.0, enable=True)           # unit scene, 150-unit margin: all visible
+    assert ctx.info().visible_nodes == len(s.nodes)
+    assert ctx.download_visible_nodes().tobytes() == s.nodes.tobytes()
+    # looking away from a far-off scene culls every node: the reference then dispatches over an empty SSBO
+    far = orc.Camera(0.0, 0.0, 10.0)
+    far._c.target[2] = 9000.0
+    ctx.update_frustum(far.get_view(), 45.0, 1.0, enable=True)
+    assert ctx.info().visible_nodes == 0
+    img = ctx.render_host(rto.make_frame(view, pos, 1.0, 45.0, 32, 32))
+    assert (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+    ctx.update_frustum(view, 45.0, 1.0, enable=False)
+
+
+def test_partitions_assemble_to_the_full_frame(ctx, orc, scenes, camera):
+    """Multi-GPU decomposition on one GPU: every part renders its bands into a compact buffer, the buffers
+    are laid end to end as a gather would, rto_assemble_device rebuilds the frame."""
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere64")
+    view, pos = camera("sphere")
+    upload(ctx, s)
+    for (W, H) in ((640, 360), (333, 250)):
+        f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+        want = ctx.render_host(f)
+        for nparts, band in ((2, 16), (3, 8), (4, 16), (8, 8), (8, 64)):
+            rows0 = ctx.partition_rows(f, hip.Partition(nparts, 0, band))
+            gathered = torch.zeros((nparts, rows0, W, 4), dtype=torch.float32, device="cuda")
+            total = 0
+            for p in range(nparts):
+                part = hip.Partition(nparts, p, band)
+                total += ctx.partition_rows(f, part)
+                ctx.render_device(f, gathered[p].data_ptr(), part)
+            assert total == H
+            frame = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+            ctx.assemble_device(f, hip.Partition(nparts, 0, band), gathered.data_ptr(), frame.data_ptr())
+            ctx.synchronize()
+            assert_bit_exact(frame.cpu().numpy(), want, f"{W}x{H} parts={nparts} band={band}")
+
+
+def test_render_device_on_a_caller_stream(ctx, scenes, camera):
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere32")
+    view, pos = camera("sphere")
+    upload(ctx, s)
+    W, H = 256, 128
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want = ctx.render_host(f)
+    out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx.render_device(f, out.data_ptr(), None, stream.cuda_stream)
+    stream.synchronize()
+    assert_bit_exact(out.cpu().numpy(), want, "caller stream")
+    assert ctx.last_kernel_ms() > 0
+
+
+def test_error_codes(ctx, scenes, camera):
+    fresh = rto.Context(0)
+    view, pos = camera("sphere")
+    f = rto.make_frame(view, pos, 1.0, 45.0, 16, 16)
+    with pytest.raises(rto.RtoError) as e:
+        fresh.render_host(f)
+    assert e.value.code == hip.RTO_E_NO_OCTREE and "setOctree" in str(e.value)
+    with pytest.raises(rto.RtoError) as e:
+        fresh.update_frustum(view, 45.0, 1.0)
+    assert e.value.code == hip.RTO_E_NO_OCTREE
+    with pytest.raises(rto.RtoError) as e:
+        fresh.upload_octree(np.zeros(0, rto.NODE_DTYPE), [0, 0, 0], 1.0)
+    assert e.value.code == hip.RTO_E_INVALID
+    fresh.upload_octree(scenes("sphere16").nodes, scenes("sphere16").min, scenes("sphere16").voxel)
+    with pytest.raises(rto.RtoError) as e:
+        fresh.render_host(rto.make_frame(view, pos, 1.0, 45.0, 0, 16))
+    assert e.value.code == hip.RTO_E_INVALID
+    with pytest.raises(rto.RtoError) as e:
+        fresh.render_device(f, 0)
+    assert e.value.code == hip.RTO_E_INVALID
+    with pytest.raises(rto.RtoError) as e:
+        fresh._check(fresh._L.rto_render_device(fresh._h, C.byref(f), C.byref(hip.Partition(2, 0, 12)), C.c_void_p(8), None))
+    assert e.value.code == hip.RTO_E_INVALID        # band_rows must be a multiple of 8
+    with pytest.raises(rto.RtoError):
+        rto.Context(9999)
+    fresh.close()
+
+
+def test_cpp_dropin_class_end_to_end(orc, scenes, camera):
+    """The C++ RayTracerBVH (reference call sequence, S/main.cpp:1127-1131, 1357-1363) over the product's
+    own VoxelGrid / createOctreeFromVoxelGrid / Camera, checked against the oracle."""
+    W, H = 320, 200
+    g = rto.VoxelGrid.test_sphere(64)
+    root = rto.createOctreeFromVoxelGrid(g)
+    rt = rto.RayTracerBVH()
+    rt.ensureComputeInitialized()
+    rt.setOctree(root, g)
+    assert rt.numNodes == 23561
+    cam = rto.Camera(0.5, 0.7, 1.8)
+    rt.renderSceneComputeWithCulling(cam, W, H, W / H, 45.0, True)
+    got = rt.framebuffer()
+    s = scenes("sphere64")
+    view, pos = camera("sphere")
+    want, _ = oracle_frame(orc, s, view, pos, W, H)
+    assert_bit_exact(got, want, "C++ drop-in, with culling")
+    rt.renderSceneCompute(cam, W, H, W / H, 45.0)
+    assert_bit_exact(rt.framebuffer(), want, "C++ drop-in")
+    # setOctree before ensureComputeInitialized also works (upload is deferred)
+    rt2 = rto.RayTracerBVH()
+    rt2.setOctree(root, g)
+    rt2.ensureComputeInitialized()
+    rt2.renderSceneCompute(cam, W, H, W / H, 45.0)
+    assert_bit_exact(rt2.framebuffer(), want, "C++ drop-in, deferred upload")
+    # null root: silently nothing (S/RT:439, :625)
+    rt3 = rto.RayTracerBVH()
+    rt3.ensureComputeInitialized()
+    rt3.setOctree(None, g)
+    rt3.renderSceneCompute(cam, W, H, W / H, 45.0)
+    assert rt3.framebuffer() is None
+    rto.freeOctree(root)

@@ -1,0 +1,197 @@
+"""The oracle against the golden vectors (CPU only).
+
+ref_* fixtures were produced by the reference's own compiled code (tests/golden/make_golden.py);
+orc_* fixtures pin the oracle's kernel restatement against accidental change.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SPHERE_CAM
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", ["sphere16", "sphere32", "odd"])
+def test_flat_octree_matches_reference_arrays(scenes, golden, name):
+    want = golden("ref_octrees_small.npz")[name]
+    got = scenes(name).nodes
+    assert got.dtype.itemsize == 60
+    assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("name", ["sphere16", "sphere32", "sphere64", "sphere128", "sphere256", "calgary"])
+def test_flat_octree_counts_and_hash(scenes, golden_meta, name):
+    m = golden_meta["octrees"][name]
+    a = scenes(name).nodes
+    assert len(a) == m["nodes"]
+    assert int((a["isLeaf"] == 1).sum()) == m["leaves"]
+    assert int(((a["isLeaf"] == 1) & (a["isSolid"] == 1)).sum()) == m["solid_leaves"]
+    assert int(a["size"][0]) == m["root_size"]
+    assert sha(a) == m["sha256"]
+    np.testing.assert_array_equal(scenes(name).min, np.array(m["grid_min"], np.float32))
+
+
+def test_survey_node_counts(golden_meta):
+    # SURVEY.md section 6 / BASELINE.md: the figures every later report quotes
+    assert golden_meta["octrees"]["sphere64"]["nodes"] == 23561
+    assert golden_meta["octrees"]["sphere256"]["nodes"] == 374921
+    assert golden_meta["octrees"]["sphere512"]["nodes"] == 1500361
+    assert golden_meta["octrees"]["calgary"]["nodes"] == 348409
+    assert golden_meta["octrees"]["calgary"]["filled"] == 141000
+
+
+def test_octree_structure_invariants(scenes):
+    a = scenes("sphere64").nodes
+    internal = a["isLeaf"] == 0
+    assert (a["isLeaf"] == a["isUniform"]).all()                       # leaf <=> uniform (OctreeVoxel.cpp:716-745)
+    assert (a["child"][~internal] == -1).all()
+    c0 = a["child"][internal][:, 0]
+    assert (a["child"][internal] == c0[:, None] + np.arange(8)).all()  # 8 consecutive children (RayTracerBVH.cpp:473-487)
+    assert (c0 % 8 == 1).all()
+    k = np.arange(8)
+    for name, bit in (("x", 1), ("y", 2), ("z", 4)):                   # child order bit0=x, bit1=y, bit2=z
+        child = a[name][a["child"][internal]]
+        half = (a["size"][internal] // 2)[:, None]
+        assert (child == a[name][internal][:, None] + np.where(k & bit, half, 0)).all()
+
+
+def test_camera_and_glm_match_reference(orc, golden):
+    z = golden("ref_cameras.npz")
+    for name in ("sphere", "calgary_default", "calgary_oblique", "panned"):
+        t, p, r, do_pan, dx, dy = [float(v) for v in z[name + "_params"]]
+        cam = orc.Camera(t, p, r)
+        if do_pan:
+            cam.pan(dx, dy)
+        assert cam.get_view().tobytes() == z[name + "_view"].tobytes(), name
+        assert cam.get_pos().tobytes() == z[name + "_pos"].tobytes(), name
+        assert cam.target.tobytes() == z[name + "_target"].tobytes(), name
+        assert orc.mat4_inverse(z[name + "_view"]).tobytes() == z[name + "_inv"].tobytes(), name
+        persp = orc.perspective(orc.radians(45.0), float(np.float32(1920 / 1080)), 0.01, 5000.0)
+        assert persp.tobytes() == z[name + "_persp"].tobytes(), name
+        assert orc.mat4_mul(persp, z[name + "_view"]).tobytes() == z[name + "_vp"].tobytes(), name
+
+
+def test_frustum_matches_reference(orc, golden):
+    z = golden("ref_cameras.npz")
+    mins, maxs = z["frustum_min"], z["frustum_max"]
+    seen = set()
+    for cam in ("calgary_default", "calgary_oblique", "sphere"):
+        planes = orc.frustum_planes(z[cam + "_vp"])
+        for margin in (150.0, 0.0):
+            want = z[f"frustum_{cam}_m{int(margin)}"]
+            got = np.array([orc.frustum_test(planes, mins[i], maxs[i], margin) for i in range(len(mins))], np.int32)
+            np.testing.assert_array_equal(got, want)
+            seen |= set(want.tolist())
+    assert seen == {-1, 0, 1}      # the vectors exercise all three verdicts
+
+
+def test_oracle_kernel_pinned_small_images(orc, scenes, golden, golden_meta):
+    z = golden("orc_images_small.npz")
+    for dim, (W, H) in ((16, (64, 64)), (32, (96, 64))):
+        s = scenes(f"sphere{dim}")
+        cam = orc.Camera(*SPHERE_CAM)
+        img, st = orc.render(s.nodes, s.min, s.voxel, cam.get_view(), cam.get_pos(), W / H, 45.0, W, H)
+        assert img.tobytes() == z[f"sphere{dim}_{W}x{H}_rgba"].tobytes()
+        steps = orc.render_steps(s.nodes, s.min, s.voxel, cam.get_view(), cam.get_pos(), W / H, 45.0, W, H)
+        np.testing.assert_array_equal(steps, z[f"sphere{dim}_{W}x{H}_steps"])
+        m = golden_meta["images"][f"sphere{dim}_{W}x{H}"]
+        assert {k: int(st[k]) for k in ("pops", "hits", "capped", "max_stack")} == {k: m[k] for k in ("pops", "hits", "capped", "max_stack")}
+
+
+@pytest.mark.parametrize("dim,W,H", [(64, 512, 512), (256, 1920, 1080)])
+def test_oracle_kernel_pinned_config_images(orc, scenes, camera, golden_meta, dim, W, H):
+    s = scenes(f"sphere{dim}")
+    view, pos = camera("sphere")
+    out = np.zeros((H, W, 4), np.float32)
+    img, st = orc.render(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H, nthreads=min(8, orc.max_threads()), out=out)
+    m = golden_meta["images"][f"sphere{dim}_{W}x{H}"]
+    assert sha(img) == m["sha256"]
+    assert (st["pops"], st["hits"], st["capped"]) == (m["pops"], m["hits"], m["capped"])
+
+
+def test_survey_render_statistics(golden_meta):
+    # 65,009 hits at config 1; 280,670 hits and 434 capped rays at config 2
+    assert golden_meta["images"]["sphere64_512x512"]["hits"] == 65009
+    assert golden_meta["images"]["sphere256_1920x1080"]["hits"] == 280670
+    assert golden_meta["images"]["sphere256_1920x1080"]["capped"] == 434
+    assert golden_meta["images"]["calgary_default_1300x1300"]["hits"] == 1300 * 1300   # eye inside a solid leaf
+
+
+def test_oracle_threads_and_row_ranges_agree(orc, scenes, camera):
+    s = scenes("sphere32")
+    view, pos = camera("sphere")
+    W, H = 80, 60
+    a, _ = orc.render(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H, nthreads=1)
+    b, _ = orc.render(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H, nthreads=4)
+    assert a.tobytes() == b.tobytes()
+    c = np.zeros_like(a)
+    for y0, y1 in ((0, 7), (7, 33), (33, 60)):
+        orc.render(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H, rows=(y0, y1), out=c)
+    assert a.tobytes() == c.tobytes()
+
+
+def test_cull_compact_properties(orc, scenes, camera):
+    s = scenes("calgary")
+    view, _ = camera("calgary_oblique")
+    out, vis = orc.cull_compact(s.nodes, s.min, s.voxel, view, 45.0, 1920 / 1080)
+    assert 0 < len(out) < len(s.nodes)                     # the oblique camera does cull something
+    assert len(out) == int(vis.sum())
+    kept = s.nodes[vis]
+    for f in ("x", "y", "z", "size", "isLeaf", "isSolid", "isUniform"):
+        np.testing.assert_array_equal(out[f], kept[f])
+    ch = out["child"]
+    assert ((ch >= -1) & (ch < len(out))).all()
+    # with the unit sphere everything lies within the 150-unit margin: nothing is culled
+    sp = scenes("sphere32")
+    v2, _ = camera("sphere")
+    out2, vis2 = orc.cull_compact(sp.nodes, sp.min, sp.voxel, v2, 45.0, 1.0)
+    assert vis2.all() and out2.tobytes() == sp.nodes.tobytes()
+
+
+def test_octree_ray_skip_returns_a_solid_leaf_entry(orc, scenes):
+    """N1 (VolumeRaycastRenderer.cpp:50-155).  The reference orders children by Hamming distance from the
+    octant of the ray's POSITIVE direction bits (:114-152), which is not front-to-back for positive
+    components, so the result is the entry distance of the first solid leaf met in THAT order: some
+    solid leaf the ray really crosses (never closer than the nearest one), or 1e30 when there is none."""
+    s = scenes("sphere16")
+    rng = np.random.default_rng(7)
+    ro = np.array([0.9, 0.7, 1.3], np.float32)
+    leaves = s.nodes[(s.nodes["isLeaf"] == 1) & (s.nodes["isSolid"] == 1)]
+    mn = s.min[None, :] + np.stack([leaves["x"], leaves["y"], leaves["z"]], 1).astype(np.float32) * s.voxel
+    mx = mn + (leaves["size"].astype(np.float32) * s.voxel)[:, None]
+    hits = nearest = 0
+    for _ in range(200):
+        tgt = (rng.random(3).astype(np.float32) - 0.5) * np.float32(0.9)
+        rd = tgt - ro
+        rd = (rd / np.sqrt((rd * rd).sum())).astype(np.float32)
+        t = orc.octree_ray_skip(s.nodes, s.min, s.voxel, ro, rd)
+        inv = np.float32(1.0) / rd
+        t1, t2 = (mn - ro) * inv, (mx - ro) * inv
+        tn = np.minimum(t1, t2).max(axis=1)
+        tf = np.maximum(t1, t2).min(axis=1)
+        ok = (np.maximum(tn, 0) <= tf)
+        if ok.any():
+            hits += 1
+            entries = np.maximum(tn[ok], 0)
+            assert np.abs(entries - t).min() <= 1e-5 * max(1.0, t)      # it is one of the crossed leaves
+            assert t >= float(entries.min()) - 1e-5
+            nearest += int(abs(t - float(entries.min())) <= 1e-5)
+        else:
+            assert t >= 1e30
+    assert hits > 50
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/453-skeleton"), reason="reference checkout not present")
+def test_oracle_against_live_reference_random_grids(orc):
+    """Where the reference sources exist, compare against their compiled code directly on random grids."""
+    assert orc.ref_available()
+    rng = np.random.default_rng(99)
+    for dims, p in (((7, 5, 3), 0.5), ((16, 16, 16), 0.1), ((33, 9, 20), 0.9), ((1, 1, 1), 1.0), ((2, 3, 1), 0.0)):
+        data = (rng.random((dims[2], dims[1], dims[0])) < p).astype(np.uint8)
+        g = orc.Grid(dims, np.array([0.5, -2.0, 3.0], np.float32), np.float32(0.3), data)
+        assert orc.build_flat_octree(g).tobytes() == orc.ref_build_flat_octree(g).tobytes(), dims
