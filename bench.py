@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of BASELINE.json on this repo's HIP path.
+
+Metric   : Mrays/s of primary rays (and ms/frame) at 1920x1080.
+Workload : BASELINE config 2 -- 256^3 shell-sphere voxel grid (main.cpp:337-372 rules), octree to
+           min-leaf 1 (374,921 nodes), Camera(theta 0.5, phi 0.7, r 1.8), fov 45, aspect W/H.
+Step     : one frame = one pass of the hot path over 2,073,600 rays, octree and framebuffer resident in HBM.
+N = 1    : one kernel launch per frame into a device framebuffer.
+N > 1    : launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; every rank
+           holds the octree, renders its round-robin bands and ONE torch.distributed.gather (RCCL over
+           xGMI) per frame lands the image on rank 0, which re-interleaves it (strong scaling).
+
+Prints ONE JSON line on rank 0.  `cpu_baseline` is this repo's own C restatement of the reference's GLSL
+kernel (the reference has no CPU path and publishes no numbers), timed here on the box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+NODE_BYTES = 60                # struct GPUNodes, the reference's node record (constant even if repacked)
+PIXEL_BYTES = 16               # RGBA32F
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dim", type=int, default=256, help="test-sphere grid edge (config 2: 256)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--band-rows", type=int, default=16)
+    ap.add_argument("--kernel", choices=["auto", "packed", "generic"], default="auto")
+    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def host_cores() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(args, grid, nodes, view, pos, gpu_pops):
+    """Oracle (own restatement of the reference GLSL) on the host cores: all cores + one thread."""
+    import numpy as np
+
+    from oracle import orc   # cpu_baseline leg only
+
+    W, H = args.width, args.height
+    cores = host_cores()
+    out = np.zeros((H, W, 4), np.float32)
+    gmin, voxel = grid.min, grid.voxelSize
+    _, st = orc.render(nodes, gmin, voxel, view, pos, W / H, 45.0, W, H, nthreads=cores, out=out)   # warm-up + stats
+    assert st["pops"] == gpu_pops, "GPU and oracle disagree on the pop count"
+    ts = []
+    for _ in range(args.cpu_frames):
+        t = time.perf_counter()
+        orc.render(nodes, gmin, voxel, view, pos, W / H, 45.0, W, H, nthreads=cores, out=out)
+        ts.append(time.perf_counter() - t)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    t = time.perf_counter()
+    orc.render(nodes, gmin, voxel, view, pos, W / H, 45.0, W, H, nthreads=1, out=out)
+    t1 = time.perf_counter() - t
+    return {
+        "value": round(W * H / med / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": f"{args.cpu_frames} full {W}x{H} frames of the same scene/camera, median, OpenMP dynamic over rows; "
+                  f"plus 1 frame on 1 thread",
+        "single_thread_value": round(W * H / t1 / 1e6, 3),
+        "note": "own restatement of reference GLSL; reference has no CPU path and publishes no numbers",
+    }, out
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}`")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+
+    import ray_tracing_octrees_amd as rto
+    from ray_tracing_octrees_amd import tilesplit
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- scene: the product's own host layer (C++), not the oracle --------------------------------
+    W, H = args.width, args.height
+    grid = rto.VoxelGrid.test_sphere(args.dim)
+    root = rto.createOctreeFromVoxelGrid(grid)
+    nodes = root.flatten()
+    rto.freeOctree(root)
+    cam = rto.Camera(0.5, 0.7, 1.8)
+    view, pos = cam.getView(), cam.getPos()
+    frame = rto.make_frame(view, pos, W / H, 45.0, W, H)
+
+    ctx = rto.Context(local_rank)
+    ctx.upload_octree(nodes, grid.min, grid.voxelSize)
+    ctx.set_kernel({"auto": rto.KERNEL_AUTO, "packed": rto.KERNEL_PACKED, "generic": rto.KERNEL_GENERIC}[args.kernel])
+    info = ctx.info()
+    renderer = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # a side stream: kernels, events and (for N > 1) the RCCL gather all order themselves on it
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    for _ in range(args.warmup):
+        renderer.render(frame)
+    sync_all()
+
+    # ---- timed region: exactly K frames ------------------------------------------------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if world == 1:
+            ev[k][0].record(stream)          # HIP events on the launch stream: the kernel's own duration
+            img = renderer.render(frame)
+            ev[k][1].record(stream)
+        else:
+            img = renderer.render(frame)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- everything below is outside the timed region ---------------------------------------------
+    rays = W * H
+    result = None
+    if rank == 0:
+        stats = ctx.frame_stats(frame)                       # exact pop count of this frame (instrumented kernel)
+        pops_per_ray = stats["pops"] / stats["rays"]
+        bytes_per_ray = pops_per_ray * NODE_BYTES + PIXEL_BYTES
+        roofline = None
+        if world == 1:
+            kms = sorted(a.elapsed_time(b) for a, b in ev)
+            k_avg = sum(kms) / len(kms)
+            achieved = rays * bytes_per_ray / (k_avg * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("dim") == args.dim and tj.get("width") == W and tj.get("height") == H:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            roofline = {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "k_trace_packed" if (info.canonical and args.kernel != "generic") else "k_trace_generic",
+                "kernel_ms_avg": round(k_avg, 5), "kernel_ms_median": round(kms[len(kms) // 2], 5),
+                "algorithmic_bytes_per_ray": round(bytes_per_ray, 2), "pops_per_ray": round(pops_per_ray, 4),
+                "algorithmic_bytes_per_launch": int(round(rays * bytes_per_ray)),
+                "note": "algorithmic bytes = pops x 60 B reference node + 16 B pixel (SURVEY 8d); the packed kernel "
+                        "reads 8-byte descriptors of internal nodes only, so frac may exceed 1: the real bound is VALU",
+            }
+        cpu = None
+        if world == 1 and args.cpu_frames > 0:
+            cpu, want = cpu_baseline(args, grid, nodes, view, pos, stats["pops"])
+            got = img.cpu().numpy()
+            if got.tobytes() != want.tobytes():
+                sys.exit("bench: the timed frame differs from the oracle's -- result void")
+        result = {
+            "metric": "Mrays/s (primary rays), 1920x1080" if (W, H) == (1920, 1080) else f"Mrays/s (primary rays), {W}x{H}",
+            "value": round(rays * args.steps / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.dim}^3 test-sphere voxel grid, octree to min-leaf 1 ({info.num_nodes} nodes), "
+                            f"{W}x{H} primary rays, Camera(0.5,0.7,1.8), fov 45",
+                "parallelism": "1 GPU" if world == 1 else f"screen split over {world} GPUs, {args.band_rows}-row bands "
+                                                          f"round-robin, 1 RCCL gather per frame",
+                "kernel": args.kernel,
+            },
+            "hit_rays": stats["hits"], "capped_rays": stats["capped"],
+            "device": ctx.device_name,
+        }
+        if roofline is not None:
+            result["roofline"] = roofline
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
+            result["speedup_vs_cpu_all_cores"] = round(result["value"] / cpu["value"], 1)
+        print(json.dumps(result), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,7 +64,8 @@ typedef struct rto_partition {
  * canonical BFS octree (what setOctree produces), else GENERIC. */
 #define RTO_KERNEL_AUTO    0
 #define RTO_KERNEL_GENERIC 1       /* 60-byte nodes, explicit child indices, per-thread stack[128] */
-#define RTO_KERNEL_PACKED  2       /* 8-byte child descriptors, LDS level stack                    */
+#define RTO_KERNEL_PACKED  2       /* 8-byte child descriptors, LDS level stack, low-latency loop  */
+#define RTO_KERNEL_PACKED_V1 3     /* first form of the packed kernel (level-by-level ascent); kept for A/B runs */
 
 typedef struct rto_stats {         /* per-frame counters, same meaning as the oracle's */
     uint64_t rays, pops, hits, capped;
@@ -113,8 +114,9 @@ int  rto_download_visible_nodes(rto_context* ctx, rto_node* out, int64_t capacit
  * (S/RayTracerBVH.cpp:630-688).  Output: RGBA32F, row-major, row 0 = top, alpha 1. */
 
 /* Asynchronous: renders this part's bands into d_out (device pointer,
- * rto_partition_rows()*width*16 bytes) on hip_stream (a hipStream_t, NULL = the
- * context's own stream). */
+ * rto_partition_rows()*width*16 bytes) on hip_stream, a hipStream_t passed as void*.
+ * As everywhere in HIP, NULL is the default (null) stream; rto_stream() returns the
+ * context's own non-blocking stream for callers that want one. */
 int  rto_render_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part /* NULL = whole frame */,
                        void* d_out, void* hip_stream);
 /* Synchronous convenience: whole frame into host memory (the one API addition the
@@ -132,9 +134,17 @@ int  rto_assemble_device(rto_context* ctx, const rto_frame* frame, const rto_par
 int  rto_frame_stats(rto_context* ctx, const rto_frame* frame, rto_stats* out);
 /* Per-pixel traversalSteps: +steps for a hit, -steps for a miss (width*height int32, host). */
 int  rto_render_steps_host(rto_context* ctx, const rto_frame* frame, int32_t* host_steps);
+/* Developer aid: per-wave timeline of one frame of the packed kernel.  8 int32 per 8x8 tile (row-major
+ * tiles): start lo/hi, end lo/hi (100 MHz wall clock), loop iterations, HW_ID, XCC_ID, lanes that entered
+ * the tree.  host_records may be NULL to query *num_tiles. */
+int  rto_debug_timeline(rto_context* ctx, const rto_frame* frame, int32_t* host_records, int64_t capacity_tiles,
+                        int64_t* num_tiles);
 /* Device time in ms of the most recent traversal kernel launched by this context
  * (hipEvent pair on the launch stream; synchronises on that event). */
 int  rto_last_kernel_ms(rto_context* ctx, float* ms);
+/* The context's own hipStream_t (used by the synchronous entry points). */
+void* rto_stream(rto_context* ctx);
+/* Waits for all work on the context's device (hipDeviceSynchronize). */
 int  rto_synchronize(rto_context* ctx);
 
 #ifdef __cplusplus

@@ -31,6 +31,7 @@ struct rto_context {
     float gridMin[3] = { 0, 0, 0 };
     float voxelSize = 1.f;
     int kernelMode = RTO_KERNEL_AUTO;
+    float solidCentre[3] = { 0, 0, 0 };   // centre of the bounding box of the solid leaves, voxel units (launch-order heuristic)
 
     // frustum culling state
     bool culling = false;
@@ -180,7 +181,7 @@ static bool build_descriptors(const rto_node* nodes, int64_t n, std::vector<uint
             else if (ch.isSolid == 1) smask |= 1u << k;
         }
         const int d = rank[(size_t)i];
-        desc[(size_t)d] = make_uint2(imask | (smask << 8) | 0xff0000u, (unsigned)rank[(size_t)c0]);
+        desc[(size_t)d] = make_uint2(smask | (imask << 8) | 0xff0000u, (unsigned)rank[(size_t)c0]);
         firstChild[(size_t)d] = (int)c0;
     }
     return true;
@@ -202,6 +203,19 @@ int rto_upload_octree(rto_context* c, const rto_node* nodes, int64_t n, const fl
     RTO_HIP(c, hipMalloc(&c->d_nodes, (size_t)n * sizeof(rto_node)));
     RTO_HIP(c, hipMemcpy(c->d_nodes, nodes, (size_t)n * sizeof(rto_node), hipMemcpyHostToDevice));
 
+    {   // where the geometry is: tiles nearest its projection are launched first (heavy waves early)
+        long lo[3] = { 1L << 40, 1L << 40, 1L << 40 }, hi[3] = { -(1L << 40), -(1L << 40), -(1L << 40) };
+        for (int64_t i = 0; i < n; i++) {
+            const rto_node& nd = nodes[i];
+            if (!is_terminal(nd) || nd.isSolid != 1) continue;
+            const long mn[3] = { nd.x, nd.y, nd.z };
+            for (int a = 0; a < 3; a++) {
+                if (mn[a] < lo[a]) lo[a] = mn[a];
+                if (mn[a] + nd.size > hi[a]) hi[a] = mn[a] + nd.size;
+            }
+        }
+        for (int a = 0; a < 3; a++) c->solidCentre[a] = lo[a] <= hi[a] ? 0.5f * (float)(lo[a] + hi[a]) : 0.5f * (float)nodes[0].size;
+    }
     std::vector<uint2> desc;
     std::vector<int> firstChild;
     c->canonical = build_descriptors(nodes, n, desc, firstChild, c->rootSize, c->depth);
@@ -234,9 +248,9 @@ int rto_octree_info_get(const rto_context* c, rto_octree_info* out) {
 
 int rto_set_kernel(rto_context* c, int kernel) {
     if (!c) return RTO_E_INVALID;
-    if (kernel != RTO_KERNEL_AUTO && kernel != RTO_KERNEL_GENERIC && kernel != RTO_KERNEL_PACKED)
+    if (kernel != RTO_KERNEL_AUTO && kernel != RTO_KERNEL_GENERIC && kernel != RTO_KERNEL_PACKED && kernel != RTO_KERNEL_PACKED_V1)
         return fail(c, RTO_E_INVALID, "rto_set_kernel: unknown kernel id");
-    if (kernel == RTO_KERNEL_PACKED && c->numNodes > 0 && !c->canonical)
+    if ((kernel == RTO_KERNEL_PACKED || kernel == RTO_KERNEL_PACKED_V1) && c->numNodes > 0 && !c->canonical)
         return fail(c, RTO_E_UNSUPPORTED, "rto_set_kernel: packed kernel needs a canonical BFS octree");
     c->kernelMode = kernel;
     return RTO_OK;
@@ -344,6 +358,24 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     P.tilesX = (P.W + 7) / 8;
     P.tilesY = (P.localRows + 7) / 8;
     P.rootVisible = c->rootVisible;
+    {   // project the centre of the solid geometry; any value is valid, it only orders the launch
+        const rtmath::mat4 V = rtmath::mat4::from(f->view);
+        const float wc[3] = { c->gridMin[0] + c->solidCentre[0] * c->voxelSize, c->gridMin[1] + c->solidCentre[1] * c->voxelSize,
+                              c->gridMin[2] + c->solidCentre[2] * c->voxelSize };
+        const float vx = V[0][0] * wc[0] + V[1][0] * wc[1] + V[2][0] * wc[2] + V[3][0];
+        const float vy = V[0][1] * wc[0] + V[1][1] * wc[1] + V[2][1] * wc[2] + V[3][1];
+        const float vz = V[0][2] * wc[0] + V[1][2] * wc[1] + V[2][2] * wc[2] + V[3][2];
+        float sx = 0.5f * (float)P.W, sy = 0.5f * (float)P.H;
+        if (vz < 0.0f && P.tanHalfFov > 0.0f && P.aspect > 0.0f) {
+            const float ndcx = vx / (-vz) / (P.aspect * P.tanHalfFov), ndcy = vy / (-vz) / P.tanHalfFov;
+            if (std::isfinite(ndcx) && std::isfinite(ndcy)) { sx = (ndcx * 0.5f + 0.5f) * (float)P.W; sy = (0.5f - ndcy * 0.5f) * (float)P.H; }
+        }
+        int tcx = (int)std::floor(sx / 8.0f), tcy = (int)std::floor(sy / 8.0f / (float)P.numParts);
+        P.orderCx = tcx < 0 ? 0 : (tcx >= P.tilesX ? P.tilesX - 1 : tcx);
+        P.orderCy = tcy < 0 ? 0 : (tcy >= P.tilesY ? P.tilesY - 1 : tcy);
+        if (P.tilesX <= 0) P.orderCx = 0;
+        if (P.tilesY <= 0) P.orderCy = 0;
+    }
     return RTO_OK;
 }
 
@@ -352,12 +384,16 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     const int tiles = P.tilesX * P.tilesY;
     if (tiles <= 0) return RTO_OK;
     const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
-    bool packed = c->kernelMode == RTO_KERNEL_PACKED || (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
+    const bool packed = c->kernelMode == RTO_KERNEL_PACKED || c->kernelMode == RTO_KERNEL_PACKED_V1 ||
+                        (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
     if (packed && !c->canonical) return fail(c, RTO_E_UNSUPPORTED, "render: packed kernel needs a canonical BFS octree");
     RTO_HIP(c, hipEventRecord(c->ev0, s));
     if (packed) {
         const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint2);
-        hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
+        if (c->kernelMode == RTO_KERNEL_PACKED_V1)
+            hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
+        else
+            hipLaunchKernelGGL(k_trace_packed2<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
     } else {
         const rto_node* nodes = c->culling ? c->d_compact : c->d_nodes;
         RenderParams Q = P;
@@ -396,8 +432,7 @@ int rto_render_device(rto_context* c, const rto_frame* f, const rto_partition* p
     RenderParams P;
     int rc = fill_params(c, f, p, P);
     if (rc != RTO_OK) return rc;
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    return launch_trace<kModeColor>(c, P, (float4*)d_out, s);
+    return launch_trace<kModeColor>(c, P, (float4*)d_out, (hipStream_t)hip_stream);
 }
 
 int rto_render_host(rto_context* c, const rto_frame* f, float* host_rgba) {
@@ -422,7 +457,7 @@ int rto_assemble_device(rto_context* c, const rto_frame* f, const rto_partition*
     RTO_HIP(c, hipSetDevice(c->device));
     rto_partition p0 = *p; p0.part = 0;
     const int partRows = rto_partition_rows(f, &p0);
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipStream_t s = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(k_assemble, dim3(2048), dim3(256), 0, s, (const float4*)d_gathered, (float4*)d_frame,
                        f->width, f->height, p->num_parts, p->num_parts > 1 ? p->band_rows : f->height, partRows);
     RTO_HIP(c, hipGetLastError());
@@ -459,6 +494,30 @@ int rto_render_steps_host(rto_context* c, const rto_frame* f, int32_t* host_step
     return run_steps(c, f, nullptr, host_steps);
 }
 
+int rto_debug_timeline(rto_context* c, const rto_frame* f, int32_t* host_records, int64_t capacity_tiles, int64_t* num_tiles) {
+    if (!c || !f || !num_tiles) return RTO_E_INVALID;
+    RTO_HIP(c, hipSetDevice(c->device));
+    if (!c->canonical) return fail(c, RTO_E_UNSUPPORTED, "rto_debug_timeline: packed kernel only");
+    RenderParams P;
+    int rc = fill_params(c, f, nullptr, P);
+    if (rc != RTO_OK) return rc;
+    const int64_t tiles = (int64_t)P.tilesX * P.tilesY;
+    *num_tiles = tiles;
+    if (!host_records) return RTO_OK;
+    if (capacity_tiles < tiles) return fail(c, RTO_E_INVALID, "rto_debug_timeline: capacity too small");
+    const size_t pixels = (size_t)f->width * f->height;
+    if ((rc = ensure_frame(c, pixels)) != RTO_OK) return rc;
+    if ((rc = ensure_steps(c, (size_t)tiles * 8 > pixels ? (size_t)tiles * 8 : pixels)) != RTO_OK) return rc;
+    const int saved = c->kernelMode;
+    if (saved != RTO_KERNEL_PACKED_V1) c->kernelMode = RTO_KERNEL_PACKED;
+    rc = launch_trace<kModeTimeline>(c, P, c->d_frame, c->stream);
+    c->kernelMode = saved;
+    if (rc != RTO_OK) return rc;
+    RTO_HIP(c, hipMemcpyAsync(host_records, c->d_steps, (size_t)tiles * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    return RTO_OK;
+}
+
 int rto_last_kernel_ms(rto_context* c, float* ms) {
     if (!c || !ms) return RTO_E_INVALID;
     if (!c->timed) return fail(c, RTO_E_INVALID, "rto_last_kernel_ms: no kernel launched yet");
@@ -468,10 +527,12 @@ int rto_last_kernel_ms(rto_context* c, float* ms) {
     return RTO_OK;
 }
 
+void* rto_stream(rto_context* c) { return c ? (void*)c->stream : nullptr; }
+
 int rto_synchronize(rto_context* c) {
     if (!c) return RTO_E_INVALID;
     RTO_HIP(c, hipSetDevice(c->device));
-    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    RTO_HIP(c, hipDeviceSynchronize());
     return RTO_OK;
 }
 

@@ -11,7 +11,7 @@
 //   k_trace_packed   the MI355X path.  For canonical BFS octrees (what
 //                    setOctree produces, S/RT:443-490) the tree is re-encoded as one
 //                    8-byte child descriptor per INTERNAL node:
-//                        .x = internalMask | solidMask<<8 | visibleMask<<16
+//                        .x = solidMask | internalMask<<8 | visibleMask<<16
 //                        .y = descriptor index of the first internal child
 //                    Leaves need no storage (a 256^3 scene shrinks from 22.5 MB to
 //                    375 KB and lives in every XCD's L2).  One loop iteration = one
@@ -58,6 +58,7 @@ struct RenderParams {
     int localRows;                  // rows this part owns
     int tilesX, tilesY;             // 8x8 tiles over W x localRows
     int rootVisible;                // 0 => frustum update culled the root: black frame
+    int orderCx, orderCy;           // tile nearest the projected scene centre: tiles launch centre-out (heavy first)
 };
 
 // ---------------------------------------------------------------- scalar helpers
@@ -153,6 +154,7 @@ __device__ __forceinline__ float4 shade_hit(const RenderParams& P, const Ray& r,
 // Output modes of the traversal kernels.
 constexpr int kModeColor = 0;   // RGBA32F framebuffer
 constexpr int kModeSteps = 1;   // per-pixel +/-steps and frame counters (instrumentation)
+constexpr int kModeTimeline = 2; // per-wave {start, end (100 MHz wall clock), loop iterations, HW_ID} in stepsOut (8 ints / tile)
 
 struct Counters { unsigned long long pops, hits, capped; };
 
@@ -286,6 +288,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed(RenderParams P, const u
     const int py = global_row(P, ly);
     const bool inImage = valid && (py < P.H);
 
+    unsigned long long tl0 = 0;
+    int tlIters = 0;
+    if (MODE == kModeTimeline) tl0 = wall_clock64();
     bool hit = false;
     int steps = 0;
     int hx = 0, hy = 0, hz = 0, hs = 0;   // the solid leaf that was hit
@@ -308,12 +313,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed(RenderParams P, const u
     int sp = 0;                  // == its level
 
     while (alive) {
+        if (MODE == kModeTimeline) tlIters++;
         // ---- the node was popped and is internal: S/RT:313-318 pushes child[0..7], so they pop 7..0
         const uint2 d = desc[cur];
         const unsigned vis = (d.x >> 16) & 0xffu;
-        const unsigned imaskAll = d.x & 0xffu;          // every internal child owns a descriptor, visible or not
+        const unsigned imaskAll = (d.x >> 8) & 0xffu;   // every internal child owns a descriptor, visible or not
         const unsigned imask = imaskAll & vis;
-        const unsigned smask = (d.x >> 8) & vis & 0xffu;
+        const unsigned smask = d.x & vis;
         unsigned passMask;
         if (__builtin_amdgcn_ballot_w64(risky) != 0ull) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
         else passMask = child_pass_mask<false>(P, r, cx, cy, cz, half);
@@ -361,11 +367,243 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed(RenderParams P, const u
     }
     if (!hit && steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
 
-    if (MODE == kModeColor) {
+    if (MODE == kModeColor || MODE == kModeTimeline) {
         if (valid) {
             float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
             if (hit) color = shade_hit(P, r, hx, hy, hz, hs);
             out[(size_t)ly * P.W + px] = color;
+        }
+        if (MODE == kModeTimeline) {
+            // wave-max of the per-lane iteration counts = iterations the wave executed
+            int it = tlIters;
+            for (int off = 32; off > 0; off >>= 1) it = max(it, __shfl_down(it, off));
+            int act = __builtin_popcountll(__builtin_amdgcn_ballot_w64(tlIters > 0));
+            if (lane == 0 && ty < P.tilesY) {
+                const unsigned long long tl1 = wall_clock64();
+                unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+                unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));    // HW_REG_XCC_ID[3:0]
+                int* rec = stepsOut + (size_t)tile * 8;
+                rec[0] = (int)(tl0 & 0xffffffffu); rec[1] = (int)(tl0 >> 32);
+                rec[2] = (int)(tl1 & 0xffffffffu); rec[3] = (int)(tl1 >> 32);
+                rec[4] = it; rec[5] = (int)hwid; rec[6] = (int)xcc; rec[7] = act;
+            }
+        }
+    } else {
+        if (inImage) stepsOut[(size_t)py * P.W + px] = hit ? steps : -steps;
+        wave_accumulate(counters, steps, hit, inImage);
+    }
+}
+
+// ================================================================ packed kernel, low-latency form
+// Same traversal as k_trace_packed, restructured so that ONE loop iteration (= one internal node per
+// lane) is a short straight-line block -- the frame time of this path is set by the deepest rays
+// (~65 internal nodes) times the latency of one iteration, not by bandwidth:
+//   * O(1) ascent: `lvlPending` has a bit per tree level that still holds unpopped interesting
+//     children, so a finished subtree jumps straight to the deepest such level (one LDS read) instead
+//     of climbing level by level.  The step counts of the exhausted levels that are skipped over are
+//     pre-summed on the way down (`tailRun`; each stack entry remembers the sum above it).
+//   * the three slab conditions  tNear<=tFar, tFar>0, tNear<1e30  are folded into the per-axis
+//     half-plane terms:  max(tNear, FLT_TRUE_MIN) <= min(tFar, prev(1e30))  -- one compare per child.
+//   * v_max3/v_min3 per child, and the 8 pass bits are shifted into the mask through the carry chain
+//     (v_addc_co_u32), one VALU op per child.
+// Descriptor/stack word layout (bits): [7:0] solid | pending, [15:8] internal (unmasked), [23:16] visible,
+// [31:24] tail count above (stack entries only).
+
+__device__ __forceinline__ int unrank_centre_out(int k, int c, int n) {
+    // k-th element of 0..n-1 enumerated outwards from c: c, c+1, c-1, c+2, c-2, ... clipped to the range
+    const int lo = c, hi = n - 1 - c;
+    const int m = lo < hi ? lo : hi;
+    if (k <= 2 * m) return c + ((k & 1) ? ((k + 1) >> 1) : -(k >> 1));
+    return lo < hi ? k : n - 1 - k;
+}
+
+__device__ __forceinline__ void tile_of(const RenderParams& P, int t, int& tx, int& ty) {
+    const int rowRank = t / P.tilesX, colRank = t - rowRank * P.tilesX;
+    ty = unrank_centre_out(rowRank, P.orderCy, P.tilesY);
+    tx = unrank_centre_out(colRank, P.orderCx, P.tilesX);
+}
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Pass mask of the 8 children, fast form (no NaN can occur: see `risky`).
+__device__ __forceinline__ unsigned child_pass_mask_fast(const RenderParams& P, const Ray& r, int cx, int cy, int cz, int half) {
+    const float vs = P.voxelSize;
+    const float fh = (float)half;
+    const float sv = fh * vs;                                  // vec3(node.size) * voxelSize
+    const float kEps = __uint_as_float(1u);                   // smallest positive float: tFar > 0  <=>  tFar >= kEps
+    const float kBelow1e30 = __uint_as_float(0x7149f2c9u);    // largest float < 1e30f:  tNear < 1e30 <=> tNear <= this
+    float tmn[3][2], tmx[3][2];
+    const int c[3] = { cx, cy, cz };
+    const float o[3] = { r.ox, r.oy, r.oz };
+    const float inv[3] = { r.ix, r.iy, r.iz };
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float fc = (float)c[a];
+        const float flo = P.gridMin[a] + fc * vs;              // nodeMin of the low children
+        const float fhi = P.gridMin[a] + (fc + fh) * vs;       // fc + fh is exact: both are integers < 2^24
+        const float mlo = flo + sv, mhi = fhi + sv;            // their nodeMax
+        const float t1 = (flo - o[a]) * inv[a], t2 = (mlo - o[a]) * inv[a];
+        const float u1 = (fhi - o[a]) * inv[a], u2 = (mhi - o[a]) * inv[a];
+        tmn[a][0] = __builtin_fminf(t1, t2); tmx[a][0] = __builtin_fmaxf(t1, t2);
+        tmn[a][1] = __builtin_fminf(u1, u2); tmx[a][1] = __builtin_fmaxf(u1, u2);
+    }
+    // fold "tFar > 0" and "tNear < 1e30" into the x terms
+    tmn[0][0] = __builtin_fmaxf(tmn[0][0], kEps); tmn[0][1] = __builtin_fmaxf(tmn[0][1], kEps);
+    tmx[0][0] = __builtin_fminf(tmx[0][0], kBelow1e30); tmx[0][1] = __builtin_fminf(tmx[0][1], kBelow1e30);
+    unsigned pass = 0;
+#pragma unroll
+    for (int k = 7; k >= 0; k--) {
+        const float tn = max3f(tmn[0][k & 1], tmn[1][(k >> 1) & 1], tmn[2][k >> 2]);
+        const float tf = min3f(tmx[0][k & 1], tmx[1][(k >> 1) & 1], tmx[2][k >> 2]);
+        pass = pass + pass + ((tn <= tf) ? 1u : 0u);            // v_addc_co_u32: shift the verdict in through carry
+    }
+    return pass;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_trace_packed2(RenderParams P, const uint2* __restrict__ desc,
+                                                           float4* __restrict__ out, int* __restrict__ stepsOut,
+                                                           Counters* __restrict__ counters) {
+    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;   // entry(level) = stk[level * 64]
+
+    unsigned long long tl0 = 0;
+    int tlIters = 0;
+    if (MODE == kModeTimeline) tl0 = wall_clock64();
+
+    const int tile = blockIdx.x * (kBlock / kWave) + wave;
+    int tx = 0, ty = P.tilesY;
+    if (tile < P.tilesX * P.tilesY) tile_of(P, tile, tx, ty);
+    const int px = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    const bool inImage = valid && (py < P.H);
+
+    bool hit = false;
+    int steps = 0;
+    int hx = 0, hy = 0, hz = 0, hs = 0;
+    Ray r;
+    bool alive = false;
+    if (inImage && P.rootVisible) {
+        r = generate_ray(P, px, py);
+        float tNear, tFar, a0, a1, a2, a3, a4, a5;
+        steps = 1;   // the root's own pop
+        alive = slab_exact(P, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+    }
+    const bool risky = alive && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
+                                  __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
+
+    unsigned cur = 0;             // descriptor of the node being entered
+    int cx = 0, cy = 0, cz = 0;   // its integer position
+    int lvl = 0;                  // its level (root = 0); its children have edge rootSize >> (lvl + 1)
+    unsigned lvlPending = 0;      // bit l: stack level l still has interesting children to pop
+    unsigned tailRun = 0;         // steps owed by the exhausted levels directly above this node
+
+    int waveIter = 0;             // wave-uniform trip count (scalar): deep waves are the frame's critical path
+    while (alive) {
+        if (MODE == kModeTimeline) tlIters++;
+        // The frame ends when the deepest rays end (~65 nodes deep at 1080p/256^3) and a wave that shares its
+        // SIMD with 7 others advances slowly: raise the priority of waves as they get old so the long pole
+        // runs at near-solo speed while the many short waves fill the remaining issue slots.
+        waveIter++;
+        if (waveIter == 12) __builtin_amdgcn_s_setprio(1);
+        else if (waveIter == 24) __builtin_amdgcn_s_setprio(2);
+        else if (waveIter == 40) __builtin_amdgcn_s_setprio(3);
+        // ---------------- [A] enter node `cur`: which children matter?
+        const uint2 d = desc[cur];
+        const int half = P.rootSize >> (lvl + 1);
+        unsigned passMask;
+        if (__builtin_amdgcn_ballot_w64(risky) != 0ull) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
+        else passMask = child_pass_mask_fast(P, r, cx, cy, cz, half);
+        unsigned vm = (d.x >> 16) & 0xffu;
+        unsigned im = (d.x >> 8) & 0xffu;
+        const unsigned sm = d.x & vm;                                   // solid & visible (bits 0..7; higher bits cut by passMask)
+        unsigned hdr = d.x & 0x00ffff00u;                               // im | vm in stack-entry position
+        unsigned pending = ((im & vm) | sm) & passMask;
+        const unsigned solidHit = sm & passMask;
+        if (solidHit) pending &= ~((1u << (31 - __builtin_clz(solidHit))) - 1u);   // nothing below the first solid hit is reached
+        unsigned base = d.y;
+        unsigned tailAbove = tailRun;
+        int prev = 8;
+
+        // ---------------- [B] nothing to do here: count the children, jump to the deepest level with work
+        if (pending == 0) {
+            steps += __builtin_popcount(vm) + (int)tailRun;
+            if (lvlPending == 0 || steps >= kMaxTraversalSteps) {
+                alive = false;
+            } else {
+                const int L = 31 - __builtin_clz(lvlPending);
+                const uint2 e = stk[L * kWave];
+                pending = e.x & 0xffu; hdr = e.x & 0x00ffff00u; tailAbove = e.x >> 24; base = e.y;
+                im = (e.x >> 8) & 0xffu; vm = (e.x >> 16) & 0xffu;
+                const int bpos = P.depth - 1 - L;                        // log2 of level L's child edge
+                prev = ((cx >> bpos) & 1) | (((cy >> bpos) & 1) << 1) | (((cz >> bpos) & 1) << 2);
+                const int keep = (int)(0xffffffffu << (bpos + 1));
+                cx &= keep; cy &= keep; cz &= keep;
+                lvl = L;
+            }
+        }
+        // ---------------- [C] pop the next interesting child of level `lvl`
+        if (alive) {
+            const int j = 31 - __builtin_clz(pending);
+            const unsigned bitj = 1u << j;
+            const int skipped = __builtin_popcount(vm & ((1u << prev) - 1u) & ~((bitj << 1) - 1u));
+            if (steps + skipped >= kMaxTraversalSteps) {                 // S/RT:254: the cap ends the loop before this pop
+                steps = kMaxTraversalSteps;
+                alive = false;
+            } else {
+                steps += skipped + 1;
+                pending ^= bitj;
+                const int hl = P.rootSize >> (lvl + 1);
+                const int nx = cx | ((j & 1) ? hl : 0), ny = cy | ((j & 2) ? hl : 0), nz = cz | ((j & 4) ? hl : 0);
+                if (!(im & bitj)) {                                      // solid leaf: S/RT:278-288
+                    hit = true; hx = nx; hy = ny; hz = nz; hs = hl;
+                    alive = false;
+                } else {
+                    stk[lvl * kWave] = make_uint2(hdr | pending | (tailAbove << 24), base);
+                    const unsigned below = vm & (bitj - 1u);
+                    if (pending) { lvlPending |= (1u << lvl); tailRun = 0; }
+                    else { lvlPending &= ~(1u << lvl); tailRun = tailAbove + (unsigned)__builtin_popcount(below); }
+                    cur = base + (unsigned)__builtin_popcount(im & (bitj - 1u));
+                    cx = nx; cy = ny; cz = nz;
+                    lvl++;
+                }
+            }
+        }
+    }
+    if (!hit && steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
+
+    if (MODE == kModeColor || MODE == kModeTimeline) {
+        if (valid) {
+            float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+            if (hit) color = shade_hit(P, r, hx, hy, hz, hs);
+            out[(size_t)ly * P.W + px] = color;
+        }
+        if (MODE == kModeTimeline) {
+            int it = tlIters;
+            for (int off = 32; off > 0; off >>= 1) it = max(it, __shfl_down(it, off));
+            int act = __builtin_popcountll(__builtin_amdgcn_ballot_w64(tlIters > 0));
+            if (lane == 0 && ty < P.tilesY) {
+                const unsigned long long tl1 = wall_clock64();
+                unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+                unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+                int* rec = stepsOut + (size_t)tile * 8;
+                rec[0] = (int)(tl0 & 0xffffffffu); rec[1] = (int)(tl0 >> 32);
+                rec[2] = (int)(tl1 & 0xffffffffu); rec[3] = (int)(tl1 >> 32);
+                rec[4] = it; rec[5] = (int)hwid; rec[6] = (int)xcc; rec[7] = act;
+            }
         }
     } else {
         if (inImage) stepsOut[(size_t)py * P.W + px] = hit ? steps : -steps;

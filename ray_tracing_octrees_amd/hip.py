@@ -14,7 +14,7 @@ from . import _build
 
 RTO_OK = 0
 RTO_E_INVALID, RTO_E_NO_OCTREE, RTO_E_HIP, RTO_E_NO_DEVICE, RTO_E_UNSUPPORTED = -1, -2, -3, -4, -5
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED, KERNEL_PACKED_V1 = 0, 1, 2, 3
 
 # struct GPUNodes (453-skeleton/RayTracerBVH.h:21-26)
 NODE_DTYPE = np.dtype(
@@ -28,7 +28,7 @@ SYMBOLS = (
     "rto_upload_octree", "rto_octree_info_get", "rto_set_kernel",
     "rto_update_frustum", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
-    "rto_frame_stats", "rto_render_steps_host", "rto_last_kernel_ms", "rto_synchronize",
+    "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_last_kernel_ms", "rto_stream", "rto_synchronize",
 )
 
 
@@ -99,10 +99,10 @@ def load():
     L.rto_frame_stats.argtypes = [vp, C.POINTER(Frame), C.POINTER(Stats)]
     L.rto_render_steps_host.argtypes = [vp, C.POINTER(Frame), vp]
     L.rto_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.rto_debug_timeline.argtypes = [vp, C.POINTER(Frame), vp, C.c_int64, C.POINTER(C.c_int64)]
     L.rto_synchronize.argtypes = [vp]
-    for s in SYMBOLS:
-        if getattr(L, s).restype is C.c_int:   # default
-            getattr(L, s).restype = C.c_int
+    L.rto_stream.argtypes = [vp]
+    L.rto_stream.restype = vp
     _lib = L
     return L
 
@@ -211,10 +211,23 @@ class Context:
         self._check(self._L.rto_render_steps_host(self._h, C.byref(frame), out.ctypes.data))
         return out
 
+    def debug_timeline(self, frame: Frame) -> np.ndarray:
+        """(tiles, 8) int32 records, see rto_debug_timeline."""
+        n = C.c_int64()
+        self._check(self._L.rto_debug_timeline(self._h, C.byref(frame), None, 0, C.byref(n)))
+        out = np.zeros((n.value, 8), np.int32)
+        self._check(self._L.rto_debug_timeline(self._h, C.byref(frame), out.ctypes.data, n.value, C.byref(n)))
+        return out
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         self._check(self._L.rto_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    @property
+    def stream(self) -> int:
+        """The context's own hipStream_t as an integer handle."""
+        return self._L.rto_stream(self._h) or 0
 
     def synchronize(self):
         self._check(self._L.rto_synchronize(self._h))

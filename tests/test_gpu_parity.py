@@ -16,7 +16,7 @@ from conftest import assert_bit_exact
 pytestmark = pytest.mark.gpu
 TOL = 1e-4   # north-star tolerance; never reached: see assert_bit_exact
 
-KERNELS = [("packed", rto.KERNEL_PACKED), ("generic", rto.KERNEL_GENERIC)]
+KERNELS = [("packed", rto.KERNEL_PACKED), ("packed_v1", rto.KERNEL_PACKED_V1), ("generic", rto.KERNEL_GENERIC)]
 
 
 def oracle_frame(orc, s, view, pos, W, H, aspect=None, fov=45.0):
@@ -264,7 +264,7 @@ def test_partitions_assemble_to_the_full_frame(ctx, orc, scenes, camera):
             assert total == H
             frame = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
             ctx.assemble_device(f, hip.Partition(nparts, 0, band), gathered.data_ptr(), frame.data_ptr())
-            ctx.synchronize()
+            ctx.synchronize()      # everything above ran on the default stream (stream handle 0)
             assert_bit_exact(frame.cpu().numpy(), want, f"{W}x{H} parts={nparts} band={band}")
 
 
