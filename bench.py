@@ -169,6 +169,13 @@ def main():
         if world == 1:
             kms = sorted(a.elapsed_time(b) for a, b in ev)
             k_avg = sum(kms) / len(kms)
+            # cost of an event pair with nothing between (reported, not subtracted): rocprofv3's kernel
+            # duration is ~ k_avg minus this
+            cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+            for a, b in cal:
+                a.record(stream); b.record(stream)
+            torch.cuda.synchronize()
+            pair_overhead = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
             achieved = rays * bytes_per_ray / (k_avg * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -180,13 +187,25 @@ def main():
             roofline = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "k_trace_packed" if (info.canonical and args.kernel != "generic") else "k_trace_generic",
+                "kernel": ("k_trace_packed2" if args.kernel in ("auto", "packed") else "k_trace_packed") if (info.canonical and args.kernel != "generic") else "k_trace_generic",
                 "kernel_ms_avg": round(k_avg, 5), "kernel_ms_median": round(kms[len(kms) // 2], 5),
+                "event_pair_overhead_ms": round(pair_overhead, 5),
                 "algorithmic_bytes_per_ray": round(bytes_per_ray, 2), "pops_per_ray": round(pops_per_ray, 4),
                 "algorithmic_bytes_per_launch": int(round(rays * bytes_per_ray)),
                 "note": "algorithmic bytes = pops x 60 B reference node + 16 B pixel (SURVEY 8d); the packed kernel "
                         "reads 8-byte descriptors of internal nodes only, so frac may exceed 1: the real bound is VALU",
             }
+        pcie = None
+        if world == 1:
+            # the C ABI's host-buffer entry point (kernel + 33 MB D2H over PCIe): informational, never `value`
+            ts = []
+            for _ in range(5):
+                t = time.perf_counter()
+                ctx.render_host(frame)
+                ts.append(time.perf_counter() - t)
+            ts.sort()
+            pcie = {"ms_per_frame": round(ts[2] * 1e3, 4), "Mrays_per_s": round(rays / ts[2] / 1e6, 1),
+                    "what": "rto_render_host: kernel + device-to-host copy of the RGBA32F frame into pageable memory"}
         cpu = None
         if world == 1 and args.cpu_frames > 0:
             cpu, want = cpu_baseline(args, grid, nodes, view, pos, stats["pops"])
@@ -216,6 +235,8 @@ def main():
         }
         if roofline is not None:
             result["roofline"] = roofline
+        if pcie is not None:
+            result["pcie_inclusive"] = pcie
         if cpu is not None:
             result["cpu_baseline"] = cpu
             result["speedup_vs_cpu_all_cores"] = round(result["value"] / cpu["value"], 1)
