@@ -40,6 +40,9 @@ def parse_args():
     ap.add_argument("--band-rows", type=int, default=16)
     ap.add_argument("--kernel", choices=["auto", "packed", "generic"], default="auto")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="N=1 only: render consecutive frames on this many HIP streams (own framebuffers) so that the "
+                         "deep-ray tail of one frame overlaps the start of the next; 1 = strictly one frame at a time")
     return ap.parse_args()
 
 
@@ -143,9 +146,22 @@ def main():
 
     # ---- timed region: exactly K frames ------------------------------------------------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fif = max(1, args.frames_in_flight) if world == 1 else 1
+    if fif > 1:
+        streams = [torch.cuda.Stream() for _ in range(fif)]
+        bufs = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(fif)]
+        for i in range(fif):
+            ctx.render_device(frame, bufs[i].data_ptr(), None, streams[i].cuda_stream)
+        sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        if world == 1:
+        if fif > 1:
+            s_ = streams[k % fif]
+            ev[k][0].record(s_)
+            ctx.render_device(frame, bufs[k % fif].data_ptr(), None, s_.cuda_stream)
+            ev[k][1].record(s_)
+            img = bufs[k % fif]
+        elif world == 1:
             ev[k][0].record(stream)          # HIP events on the launch stream: the kernel's own duration
             img = renderer.render(frame)
             ev[k][1].record(stream)
@@ -187,7 +203,7 @@ def main():
             roofline = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": ("k_trace_packed2" if args.kernel in ("auto", "packed") else "k_trace_packed") if (info.canonical and args.kernel != "generic") else "k_trace_generic",
+                "kernel": ("k_trace_packed3" if args.kernel in ("auto", "packed") else "k_trace_packed") if (info.canonical and args.kernel != "generic") else "k_trace_generic",
                 "kernel_ms_avg": round(k_avg, 5), "kernel_ms_median": round(kms[len(kms) // 2], 5),
                 "event_pair_overhead_ms": round(pair_overhead, 5),
                 "algorithmic_bytes_per_ray": round(bytes_per_ray, 2), "pops_per_ray": round(pops_per_ray, 4),
@@ -226,7 +242,7 @@ def main():
             "config": {
                 "workload": f"{args.dim}^3 test-sphere voxel grid, octree to min-leaf 1 ({info.num_nodes} nodes), "
                             f"{W}x{H} primary rays, Camera(0.5,0.7,1.8), fov 45",
-                "parallelism": "1 GPU" if world == 1 else f"screen split over {world} GPUs, {args.band_rows}-row bands "
+                "parallelism": ("1 GPU" if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else f"screen split over {world} GPUs, {args.band_rows}-row bands "
                                                           f"round-robin, 1 RCCL gather per frame",
                 "kernel": args.kernel,
             },

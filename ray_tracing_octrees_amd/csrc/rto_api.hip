@@ -44,6 +44,12 @@ struct rto_context {
     rto_node* d_compact = nullptr;
     int64_t visibleNodes = 0;
 
+    // separable ray terms (per column / per row), cached by (W, H, aspect, tanHalfFov)
+    float* d_rayX = nullptr;
+    float* d_rayY = nullptr;
+    int rayW = 0, rayH = 0;
+    float rayAspect = 0.f, rayTan = 0.f;
+
     // outputs / instrumentation
     float4* d_frame = nullptr;
     size_t frameCap = 0;
@@ -123,6 +129,8 @@ void rto_destroy(rto_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_octree(c);
     (void)hipFree(c->d_frame);
+    (void)hipFree(c->d_rayX);
+    (void)hipFree(c->d_rayY);
     (void)hipFree(c->d_steps);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_visibleCount);
@@ -248,9 +256,9 @@ int rto_octree_info_get(const rto_context* c, rto_octree_info* out) {
 
 int rto_set_kernel(rto_context* c, int kernel) {
     if (!c) return RTO_E_INVALID;
-    if (kernel != RTO_KERNEL_AUTO && kernel != RTO_KERNEL_GENERIC && kernel != RTO_KERNEL_PACKED && kernel != RTO_KERNEL_PACKED_V1)
+    if (kernel < RTO_KERNEL_AUTO || kernel > RTO_KERNEL_PACKED_V2)
         return fail(c, RTO_E_INVALID, "rto_set_kernel: unknown kernel id");
-    if ((kernel == RTO_KERNEL_PACKED || kernel == RTO_KERNEL_PACKED_V1) && c->numNodes > 0 && !c->canonical)
+    if (kernel >= RTO_KERNEL_PACKED && c->numNodes > 0 && !c->canonical)
         return fail(c, RTO_E_UNSUPPORTED, "rto_set_kernel: packed kernel needs a canonical BFS octree");
     c->kernelMode = kernel;
     return RTO_OK;
@@ -358,6 +366,28 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     P.tilesX = (P.W + 7) / 8;
     P.tilesY = (P.localRows + 7) / 8;
     P.rootVisible = c->rootVisible;
+    // S/RT:341-346: nx depends on the column only, ny on the row only -> two small tables, same float ops
+    if (c->rayW != P.W || c->rayH != P.H || c->rayAspect != P.aspect || c->rayTan != P.tanHalfFov || !c->d_rayX) {
+        std::vector<float> tx((size_t)P.W), ty((size_t)P.H);
+        for (int px = 0; px < P.W; px++) {
+            float nx = ((float)px + 0.5f) / (float)P.W * 2.0f - 1.0f;
+            nx *= P.aspect;
+            nx *= P.tanHalfFov;
+            tx[(size_t)px] = nx;
+        }
+        for (int py = 0; py < P.H; py++) {
+            float ny = 1.0f - ((float)py + 0.5f) / (float)P.H * 2.0f;
+            ny *= P.tanHalfFov;
+            ty[(size_t)py] = ny;
+        }
+        if (c->rayW != P.W || !c->d_rayX) { (void)hipFree(c->d_rayX); c->d_rayX = nullptr; RTO_HIP(c, hipMalloc(&c->d_rayX, tx.size() * sizeof(float))); }
+        if (c->rayH != P.H || !c->d_rayY) { (void)hipFree(c->d_rayY); c->d_rayY = nullptr; RTO_HIP(c, hipMalloc(&c->d_rayY, ty.size() * sizeof(float))); }
+        RTO_HIP(c, hipDeviceSynchronize());   // nothing may still read the old tables
+        RTO_HIP(c, hipMemcpy(c->d_rayX, tx.data(), tx.size() * sizeof(float), hipMemcpyHostToDevice));
+        RTO_HIP(c, hipMemcpy(c->d_rayY, ty.data(), ty.size() * sizeof(float), hipMemcpyHostToDevice));
+        c->rayW = P.W; c->rayH = P.H; c->rayAspect = P.aspect; c->rayTan = P.tanHalfFov;
+    }
+    P.rayX = c->d_rayX; P.rayY = c->d_rayY;
     {   // project the centre of the solid geometry; any value is valid, it only orders the launch
         const rtmath::mat4 V = rtmath::mat4::from(f->view);
         const float wc[3] = { c->gridMin[0] + c->solidCentre[0] * c->voxelSize, c->gridMin[1] + c->solidCentre[1] * c->voxelSize,
@@ -384,16 +414,17 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     const int tiles = P.tilesX * P.tilesY;
     if (tiles <= 0) return RTO_OK;
     const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
-    const bool packed = c->kernelMode == RTO_KERNEL_PACKED || c->kernelMode == RTO_KERNEL_PACKED_V1 ||
-                        (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
+    const bool packed = c->kernelMode >= RTO_KERNEL_PACKED || (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
     if (packed && !c->canonical) return fail(c, RTO_E_UNSUPPORTED, "render: packed kernel needs a canonical BFS octree");
     RTO_HIP(c, hipEventRecord(c->ev0, s));
     if (packed) {
         const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint2);
         if (c->kernelMode == RTO_KERNEL_PACKED_V1)
             hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
-        else
+        else if (c->kernelMode == RTO_KERNEL_PACKED_V2)
             hipLaunchKernelGGL(k_trace_packed2<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
+        else
+            hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
     } else {
         const rto_node* nodes = c->culling ? c->d_compact : c->d_nodes;
         RenderParams Q = P;
@@ -509,7 +540,7 @@ int rto_debug_timeline(rto_context* c, const rto_frame* f, int32_t* host_records
     if ((rc = ensure_frame(c, pixels)) != RTO_OK) return rc;
     if ((rc = ensure_steps(c, (size_t)tiles * 8 > pixels ? (size_t)tiles * 8 : pixels)) != RTO_OK) return rc;
     const int saved = c->kernelMode;
-    if (saved != RTO_KERNEL_PACKED_V1) c->kernelMode = RTO_KERNEL_PACKED;
+    if (saved < RTO_KERNEL_PACKED) c->kernelMode = RTO_KERNEL_PACKED;
     rc = launch_trace<kModeTimeline>(c, P, c->d_frame, c->stream);
     c->kernelMode = saved;
     if (rc != RTO_OK) return rc;

@@ -59,6 +59,8 @@ struct RenderParams {
     int tilesX, tilesY;             // 8x8 tiles over W x localRows
     int rootVisible;                // 0 => frustum update culled the root: black frame
     int orderCx, orderCy;           // tile nearest the projected scene centre: tiles launch centre-out (heavy first)
+    const float* rayX;              // [W]  ((px+.5)/W*2-1)*aspect*tanHalfFov, the separable part of S/RT:341-346 (host-computed)
+    const float* rayY;              // [H]  (1-(py+.5)/H*2)*tanHalfFov
 };
 
 // ---------------------------------------------------------------- scalar helpers
@@ -109,6 +111,26 @@ __device__ __forceinline__ Ray generate_ray(const RenderParams& P, int px, int p
     float wy = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
     float wz = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
     // normalize(vec3): dot = x*x + y*y + z*z
+    float d3 = wx * wx + wy * wy + wz * wz;
+    float inv3 = inversesqrt(d3);
+    Ray r;
+    r.ox = P.camPos[0]; r.oy = P.camPos[1]; r.oz = P.camPos[2];
+    r.dx = wx * inv3; r.dy = wy * inv3; r.dz = wz * inv3;
+    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+    return r;
+}
+
+// Same, with the separable screen terms taken from the host tables (identical float operations, done once
+// per column / row instead of once per pixel).
+__device__ __forceinline__ Ray generate_ray_tab(const RenderParams& P, int px, int py) {
+    const float nx = P.rayX[px], ny = P.rayY[py];
+    float d4 = (nx * nx + ny * ny) + ((-1.0f) * (-1.0f) + 0.0f * 0.0f);
+    float inv4 = inversesqrt(d4);
+    float vx = nx * inv4, vy = ny * inv4, vz = (-1.0f) * inv4, vw = 0.0f * inv4;
+    const float* m = P.invView;
+    float wx = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * vw);
+    float wy = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * vw);
+    float wz = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * vw);
     float d3 = wx * wx + wy * wy + wz * wz;
     float inv3 = inversesqrt(d3);
     Ray r;
@@ -459,14 +481,15 @@ __device__ __forceinline__ unsigned child_pass_mask_fast(const RenderParams& P, 
     // fold "tFar > 0" and "tNear < 1e30" into the x terms
     tmn[0][0] = __builtin_fmaxf(tmn[0][0], kEps); tmn[0][1] = __builtin_fmaxf(tmn[0][1], kEps);
     tmx[0][0] = __builtin_fminf(tmx[0][0], kBelow1e30); tmx[0][1] = __builtin_fminf(tmx[0][1], kBelow1e30);
-    unsigned pass = 0;
+    // 8 independent verdicts, OR-ed as a tree: a lone deep wave is bound by dependency depth, not op count
+    unsigned b[8];
 #pragma unroll
-    for (int k = 7; k >= 0; k--) {
+    for (int k = 0; k < 8; k++) {
         const float tn = max3f(tmn[0][k & 1], tmn[1][(k >> 1) & 1], tmn[2][k >> 2]);
         const float tf = min3f(tmx[0][k & 1], tmx[1][(k >> 1) & 1], tmx[2][k >> 2]);
-        pass = pass + pass + ((tn <= tf) ? 1u : 0u);            // v_addc_co_u32: shift the verdict in through carry
+        b[k] = (tn <= tf) ? (1u << k) : 0u;
     }
-    return pass;
+    return (b[0] | b[1] | b[2]) | (b[3] | b[4] | b[5]) | (b[6] | b[7]);
 }
 
 template <int MODE>
@@ -589,6 +612,145 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed2(RenderParams P, const 
         if (valid) {
             float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
             if (hit) color = shade_hit(P, r, hx, hy, hz, hs);
+            out[(size_t)ly * P.W + px] = color;
+        }
+        if (MODE == kModeTimeline) {
+            int it = tlIters;
+            for (int off = 32; off > 0; off >>= 1) it = max(it, __shfl_down(it, off));
+            int act = __builtin_popcountll(__builtin_amdgcn_ballot_w64(tlIters > 0));
+            if (lane == 0 && ty < P.tilesY) {
+                const unsigned long long tl1 = wall_clock64();
+                unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+                unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+                int* rec = stepsOut + (size_t)tile * 8;
+                rec[0] = (int)(tl0 & 0xffffffffu); rec[1] = (int)(tl0 >> 32);
+                rec[2] = (int)(tl1 & 0xffffffffu); rec[3] = (int)(tl1 >> 32);
+                rec[4] = it; rec[5] = (int)hwid; rec[6] = (int)xcc; rec[7] = act;
+            }
+        }
+    } else {
+        if (inImage) stepsOut[(size_t)py * P.W + px] = hit ? steps : -steps;
+        wave_accumulate(counters, steps, hit, inImage);
+    }
+}
+
+// ================================================================ packed kernel, branch-free loop body
+// k_trace_packed2's algorithm with the loop body written as straight-line selects: the two lane classes of
+// an iteration ("entered a node with work" / "entered a node without work, resume at the deepest level
+// that has some") are merged through one packed state word W = pending | internal<<8 | visible<<16 |
+// tailAbove<<24 that comes either from the node's descriptor or from the LDS stack entry.  The LDS read is
+// unconditional (harmless when unused), the only predicated memory operation is the stack write.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_trace_packed3(RenderParams P, const uint2* __restrict__ desc,
+                                                           float4* __restrict__ out, int* __restrict__ stepsOut,
+                                                           Counters* __restrict__ counters) {
+    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;
+
+    unsigned long long tl0 = 0;
+    int tlIters = 0;
+    if (MODE == kModeTimeline) tl0 = wall_clock64();
+
+    const int tile = blockIdx.x * (kBlock / kWave) + wave;
+    int tx = 0, ty = P.tilesY;
+    if (tile < P.tilesX * P.tilesY) tile_of(P, tile, tx, ty);
+    const int px = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    const bool inImage = valid && (py < P.H);
+
+    bool hit = false;
+    int steps = 0;
+    Ray r;
+    bool alive = false;
+    if (inImage && P.rootVisible) {
+        r = generate_ray_tab(P, px, py);
+        float tNear, tFar, a0, a1, a2, a3, a4, a5;
+        steps = 1;   // the root's own pop
+        alive = slab_exact(P, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+    }
+    const bool risky = alive && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
+                                  __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
+
+    unsigned cur = 0;
+    int cx = 0, cy = 0, cz = 0;
+    int lvl = 0;
+    unsigned lvlPending = 0;
+    unsigned tailRun = 0;
+
+    while (alive) {
+        if (MODE == kModeTimeline) tlIters++;
+        // ---- [A] the node `cur` at (cx,cy,cz), level lvl
+        const uint2 d = desc[cur];
+        // the resume entry depends only on lvlPending: fetch it now, under the descriptor load and the slab math
+        const int L = 31 - __builtin_clz(lvlPending | 1u);
+#if defined(RTO_ABLATE_LDS)
+        const uint2 e = make_uint2(0x00ffff01u, cur + 1);   // timing experiment only
+#else
+        const uint2 e = stk[L * kWave];
+#endif
+        const int half = 1 << (P.depth - 1 - lvl);
+        unsigned passMask;
+#if defined(RTO_ABLATE_SLAB)
+        passMask = 0xa5u ^ (unsigned)(cx & 0xff);   // timing experiment only: no slab math
+        (void)half;
+#else
+        if (__builtin_amdgcn_ballot_w64(risky) != 0ull) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
+        else passMask = child_pass_mask_fast(P, r, cx, cy, cz, half);
+#endif
+        const unsigned vm0 = __builtin_amdgcn_ubfe(d.x, 16, 8);
+        const unsigned im0 = __builtin_amdgcn_ubfe(d.x, 8, 8);
+        const unsigned sm = d.x & vm0;                                  // solid & visible
+        unsigned cand = ((im0 & vm0) | sm) & passMask;
+        const unsigned solidHit = sm & passMask;
+        cand &= 0xffffffffu << (31 - __builtin_clz(solidHit | 1u));      // nothing below the first solid hit is reached
+        // ---- [B] merge with "resume at the deepest level that still has work"
+        const bool noWork = cand == 0;
+        const int stepsB = steps + __builtin_popcount(vm0) + (int)tailRun;
+        const bool dead = noWork && (lvlPending == 0 || stepsB >= kMaxTraversalSteps);
+        steps = noWork ? stepsB : steps;
+        const unsigned W = noWork ? e.x : ((d.x & 0x00ffff00u) | cand | (tailRun << 24));
+        const unsigned base = noWork ? e.y : d.y;
+        const int lvl2 = noWork ? L : lvl;
+        const int bpos = P.depth - 1 - lvl2;                             // log2 of the child edge at lvl2
+        const unsigned childIdx = ((cx >> bpos) & 1) | (((cy >> bpos) & 1) << 1) | (((cz >> bpos) & 1) << 2);
+        const unsigned belowPrev = noWork ? ((1u << childIdx) - 1u) : 0xffu;   // children not popped yet at lvl2
+        const int keep = (int)(0xffffffffu << (bpos + 1));
+        cx &= keep; cy &= keep; cz &= keep;                              // no-op for a freshly entered node
+        // ---- [C] pop the next interesting child of level lvl2
+        const unsigned pending = W & 0xffu;
+        const unsigned im = __builtin_amdgcn_ubfe(W, 8, 8);
+        const unsigned vm = __builtin_amdgcn_ubfe(W, 16, 8);
+        const unsigned tailAbove = W >> 24;
+        const int j = 31 - __builtin_clz(pending | 1u);
+        const unsigned bitj = 1u << j;
+        const int stepsC = steps + __builtin_popcount(vm & belowPrev & ~((bitj << 1) - 1u));
+        const bool capped = stepsC >= kMaxTraversalSteps;                // S/RT:254: the cap ends the loop before this pop
+        const bool go = !dead && !capped;
+        const bool solid = (im & bitj) == 0;
+        steps = dead ? steps : (capped ? kMaxTraversalSteps : stepsC + 1);
+        hit = go && solid;                                               // S/RT:278-288
+        const bool descend = go && !solid;
+        if (descend) stk[lvl2 * kWave] = make_uint2(W ^ bitj, base);
+        const unsigned pendingNew = pending ^ bitj;
+        const unsigned lb = 1u << lvl2;
+        tailRun = pendingNew ? 0u : tailAbove + (unsigned)__builtin_popcount(vm & (bitj - 1u));
+        lvlPending = pendingNew ? (lvlPending | lb) : (lvlPending & ~lb);
+        cur = base + (unsigned)__builtin_popcount(im & (bitj - 1u));
+        const int hl = 1 << bpos;
+        cx |= (j & 1) ? hl : 0; cy |= (j & 2) ? hl : 0; cz |= (j & 4) ? hl : 0;   // the popped child (kept on a hit)
+        lvl = lvl2 + 1;
+        alive = descend;
+    }
+    if (!hit && steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
+
+    if (MODE == kModeColor || MODE == kModeTimeline) {
+        if (valid) {
+            float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+            if (hit) color = shade_hit(P, r, cx, cy, cz, P.rootSize >> lvl);
             out[(size_t)ly * P.W + px] = color;
         }
         if (MODE == kModeTimeline) {

@@ -4,6 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import ray_tracing_octrees_amd as rto
+from ray_tracing_octrees_amd import _build
+if os.environ.get("RTO_LIB"):
+    _build.LIB_HIP = os.environ["RTO_LIB"]
 
 g = rto.VoxelGrid.test_sphere(256)
 root = rto.createOctreeFromVoxelGrid(g)

@@ -10,6 +10,8 @@ g = rto.VoxelGrid.test_sphere(dim)
 root = rto.createOctreeFromVoxelGrid(g)
 nodes = root.flatten()
 cam = rto.Camera(0.5, 0.7, 1.8)
+if "miss" in sys.argv:
+    cam.setTarget(np.array([5.0, 5.0, 9.0], np.float32))
 ctx = rto.Context(0)
 ctx.upload_octree(nodes, g.min, g.voxelSize)
 f = rto.make_frame(cam.getView(), cam.getPos(), W / H, 45.0, W, H)
