@@ -146,9 +146,9 @@ void RayTracerBVH::ensureComputeInitialized() {
 
 bool RayTracerBVH::render(const Camera& camera, int width, int height, float aspect, float fovDeg) {
     rto_frame f;
-    const rtmath::mat4 view = camera.getView();
-    std::memcpy(f.view, view.data(), sizeof f.view);
-    const rtmath::vec3 pos = camera.getPos();
+    const auto view = camera.getView();            // rtmath::mat4 or glm::mat4: both column-major, m[col][row]
+    std::memcpy(f.view, &view[0][0], sizeof f.view);
+    const auto pos = camera.getPos();
     f.cam_pos[0] = pos.x; f.cam_pos[1] = pos.y; f.cam_pos[2] = pos.z;
     f.aspect = aspect;
     f.fov_deg = fovDeg;
@@ -187,8 +187,8 @@ void RayTracerBVH::renderSceneComputeWithCulling(const Camera& camera, int width
     if (updateFrustum) {
         // the reference recomputes visibility on the CPU and re-uploads the compacted array
         // (RayTracerBVH.cpp:725-813); here the same test and compaction run on the GPU.
-        const rtmath::mat4 view = camera.getView();
-        if (api().update_frustum(m_ctx, view.data(), fovDeg, aspect, 1) != RTO_OK) {
+        const auto view = camera.getView();
+        if (api().update_frustum(m_ctx, &view[0][0], fovDeg, aspect, 1) != RTO_OK) {
             m_lastError = api().last_error(m_ctx);
             std::cerr << "[RayTracerBVH] frustum update failed: " << m_lastError << std::endl;
             return;

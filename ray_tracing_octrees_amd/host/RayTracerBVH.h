@@ -13,10 +13,23 @@
 #include <string>
 #include <vector>
 
+// "OctreeVoxel.h" / "Camera.h" resolve to this directory's headers by default.  Compiled with
+// -DRTO_REFERENCE_HEADERS and the reference's 453-skeleton/ + glm first on the include path, the very same
+// class builds against the reference's own OctreeNode / VoxelGrid / Camera (glm types): that is the
+// drop-in build INTEGRATION.md describes; the repo's test tree builds and runs exactly that configuration.
+#include "rto_hip.h"
+#ifdef RTO_REFERENCE_HEADERS
+#include <Camera.h>        // angle brackets: taken from the include path (the reference's 453-skeleton/), not from this directory
+#include <OctreeVoxel.h>
+#include <glm/glm.hpp>
+namespace rto_host { using vec3 = glm::vec3; }
+#else
 #include "Camera.h"
 #include "Frustum.h"
 #include "OctreeVoxel.h"
-#include "rto_hip.h"
+#include "rtmath.h"
+namespace rto_host { using vec3 = rtmath::vec3; }
+#endif
 
 // GPU-side node record, same name and layout as the reference's (RayTracerBVH.h:21-26)
 struct GPUNodes {
@@ -28,8 +41,8 @@ struct GPUNodes {
 static_assert(sizeof(GPUNodes) == sizeof(rto_node), "GPUNodes must stay 60 bytes");
 
 struct Ray {
-    rtmath::vec3 origin;
-    rtmath::vec3 direction;
+    rto_host::vec3 origin;
+    rto_host::vec3 direction;
 };
 
 class RayTracerBVH {

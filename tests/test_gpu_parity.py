@@ -346,3 +346,26 @@ def test_cpp_dropin_class_end_to_end(orc, scenes, camera):
     rt3.renderSceneCompute(cam, W, H, W / H, 45.0)
     assert rt3.framebuffer() is None
     rto.freeOctree(root)
+
+
+def test_reference_host_stack_drives_the_hip_path(orc, scenes, camera, tmp_path):
+    """oracle/_ref/dropin_test = the REFERENCE's compiled OctreeVoxel.cpp/Camera.cpp (+ its headers and glm) linked
+    with this repo's RayTracerBVH.cpp built with -DRTO_REFERENCE_HEADERS; it follows main.cpp's call sequence.
+    Built only where /root/reference exists (make -C oracle dropin); the binary travels to the GPU box."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "dropin_test")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/dropin_test not built (needs the reference checkout)")
+    W, H = 400, 240
+    out = tmp_path / "frame.raw"
+    env = dict(os.environ, RTO_HIP_LIB=hip.lib_path())
+    p = subprocess.run([exe, "64", str(W), str(H), str(out)], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "23561 nodes" in p.stdout
+    got = np.fromfile(out, dtype=np.float32).reshape(H, W, 4)
+    s = scenes("sphere64")
+    view, pos = camera("sphere")
+    want, _ = oracle_frame(orc, s, view, pos, W, H)
+    assert_bit_exact(got, want, "reference host stack + HIP path")
