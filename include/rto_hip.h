@@ -130,6 +130,15 @@ int  rto_partition_rows(const rto_frame* frame, const rto_partition* part);
 int  rto_assemble_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part,
                          const void* d_gathered, void* d_frame, void* hip_stream);
 
+/* ---- N1: octreeRaySkip --------------------------------------------------------
+ * replaces: the CPU recursion octreeRaySkip(root, ro, rd, tMin, tMax, grid, &visibility)
+ * (S/VolumeRaycastRenderer.cpp:50-155; called for a 7x7 probe grid per frame at :1602-1647).
+ * n rays share the origin ro; rd holds n directions (x,y,z).  out_t[i] = entry distance of the first solid
+ * leaf in the reference's child order, or 1e30.  use_visibility != 0 applies the flags of the last
+ * rto_update_frustum the way the reference applies its visibility map (:64-67).  Synchronous, host buffers. */
+int  rto_octree_ray_skip(rto_context* ctx, const float ro[3], const float* rd, int64_t n, float t_min, float t_max,
+                         int use_visibility, float* out_t);
+
 /* ---- instrumentation ------------------------------------------------------*/
 /* Renders the frame once with counting enabled (synchronous). */
 int  rto_frame_stats(rto_context* ctx, const rto_frame* frame, rto_stats* out);

@@ -549,6 +549,32 @@ int rto_debug_timeline(rto_context* c, const rto_frame* f, int32_t* host_records
     return RTO_OK;
 }
 
+int rto_octree_ray_skip(rto_context* c, const float ro[3], const float* rd, int64_t n, float t_min, float t_max,
+                        int use_visibility, float* out_t) {
+    if (!c) return RTO_E_INVALID;
+    if (!ro || !rd || !out_t || n < 0) return fail(c, RTO_E_INVALID, "rto_octree_ray_skip: NULL argument");
+    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_octree_ray_skip: no octree uploaded");
+    if (n == 0) return RTO_OK;
+    RTO_HIP(c, hipSetDevice(c->device));
+    float *d_rd = nullptr, *d_out = nullptr;
+    RTO_HIP(c, hipMalloc(&d_rd, (size_t)n * 3 * sizeof(float)));
+    if (hipMalloc(&d_out, (size_t)n * sizeof(float)) != hipSuccess) { (void)hipFree(d_rd); return fail(c, RTO_E_HIP, "rto_octree_ray_skip: hipMalloc"); }
+    hipError_t e = hipMemcpyAsync(d_rd, rd, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const uint8_t* vis = (use_visibility && c->culling) ? c->d_vis : nullptr;
+        const int blocks = (int)((n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_octree_ray_skip, dim3(blocks), dim3(kBlock), 0, c->stream, c->d_nodes, vis,
+                           c->gridMin[0], c->gridMin[1], c->gridMin[2], c->voxelSize, ro[0], ro[1], ro[2],
+                           d_rd, n, t_min, t_max, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_t, d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_rd); (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, RTO_E_HIP, std::string("rto_octree_ray_skip: ") + hipGetErrorString(e));
+    return RTO_OK;
+}
+
 int rto_last_kernel_ms(rto_context* c, float* ms) {
     if (!c || !ms) return RTO_E_INVALID;
     if (!c->timed) return fail(c, RTO_E_INVALID, "rto_last_kernel_ms: no kernel launched yet");

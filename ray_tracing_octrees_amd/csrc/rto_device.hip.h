@@ -891,6 +891,78 @@ __global__ __launch_bounds__(kBlock) void k_desc_visall(int64_t nInternal, uint2
     if (d < nInternal) desc[d].x |= 0xff0000u;
 }
 
+// ================================================================ N1: octreeRaySkip
+// Iterative form of the reference's recursive octreeRaySkip (453-skeleton/VolumeRaycastRenderer.cpp:50-155, "S/VR"):
+// children are tried in order of increasing Hamming distance from the octant of the ray's positive
+// direction bits (ties by octant index, S/VR:122-152); the first child whose subtree returns a finite
+// distance ends the search.  One thread per ray over the 60-byte node array; `vis` (optional) plays the
+// role of the reference's visibility map (S/VR:64-67): a node flagged 0 returns 1e30.
+struct SkipFrame { int idx; float enterT, exitT; int next; };
+
+__global__ __launch_bounds__(kBlock) void k_octree_ray_skip(const rto_node* __restrict__ nodes, const uint8_t* __restrict__ vis,
+                                                             float gx, float gy, float gz, float vx,
+                                                             float rox, float roy, float roz,
+                                                             const float* __restrict__ rd, int64_t n, float tMin0, float tMax0,
+                                                             float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float dx = rd[3 * i], dy = rd[3 * i + 1], dz = rd[3 * i + 2];
+    // S/VR:81-87
+    float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float smallValue = 1e-10f;
+    if (__builtin_fabsf(dx) < smallValue) ix = dx >= 0 ? 1e10f : -1e10f;
+    if (__builtin_fabsf(dy) < smallValue) iy = dy >= 0 ? 1e10f : -1e10f;
+    if (__builtin_fabsf(dz) < smallValue) iz = dz >= 0 ? 1e10f : -1e10f;
+    const int dirMask = ((dx > 0) ? 1 : 0) | ((dy > 0) ? 2 : 0) | ((dz > 0) ? 4 : 0);   // S/VR:114-116
+
+    SkipFrame st[kMaxDepth + 2];
+    int sp = 0;
+    st[0].idx = 0; st[0].enterT = tMin0; st[0].exitT = tMax0; st[0].next = -1;   // next == -1: node not examined yet
+    float result = 1e30f;
+    while (sp >= 0) {
+        SkipFrame& f = st[sp];
+        if (f.next < 0) {
+            // first visit of this node: S/VR:60-110
+            const rto_node nd = nodes[f.idx];
+            bool reject = (vis != nullptr) && (vis[f.idx] == 0);
+            const float wx0 = gx + (float)nd.x * vx, wy0 = gy + (float)nd.y * vx, wz0 = gz + (float)nd.z * vx;
+            const float wSize = (float)nd.size * vx;
+            const float t1x = (wx0 - rox) * ix, t1y = (wy0 - roy) * iy, t1z = (wz0 - roz) * iz;
+            const float t2x = ((wx0 + wSize) - rox) * ix, t2y = ((wy0 + wSize) - roy) * iy, t2z = ((wz0 + wSize) - roz) * iz;
+            const float tNx = gmin(t1x, t2x), tNy = gmin(t1y, t2y), tNz = gmin(t1z, t2z);
+            const float tFx = gmax(t1x, t2x), tFy = gmax(t1y, t2y), tFz = gmax(t1z, t2z);
+            const float enterT = gmax(gmax(tNx, tNy), gmax(tNz, f.enterT));
+            const float exitT = gmin(gmin(tFx, tFy), gmin(tFz, f.exitT));
+            if (!reject && enterT > exitT) reject = true;
+            if (reject) { sp--; continue; }                          // returns 1e30 to the parent
+            if (nd.isLeaf) {
+                if (nd.isSolid) { result = enterT; break; }          // finite: every ancestor returns it at once (S/VR:146-149)
+                sp--; continue;
+            }
+            f.enterT = enterT; f.exitT = exitT; f.next = 0;
+        }
+        // next child in (Hamming distance, octant) order
+        int child = -1;
+        while (f.next < 8) {
+            const int k = f.next++;
+            // k-th octant in the order: distance 0 (1), 1 (3), 2 (3), 3 (1); within a distance by octant index
+            int octant = -1, seen = 0;
+            for (int dist = 0; dist <= 3 && octant < 0; dist++)
+                for (int o = 0; o < 8; o++)
+                    if (__builtin_popcount(o ^ dirMask) == dist) { if (seen == k) { octant = o; break; } seen++; }
+            const rto_node* nd = nodes + f.idx;
+            child = nd->child[octant];
+            if (child >= 0) break;
+            child = -1;
+        }
+        if (child < 0) { sp--; continue; }                           // all children returned 1e30
+        const float eT = f.enterT, xT = f.exitT;
+        sp++;
+        st[sp].idx = child; st[sp].enterT = eT; st[sp].exitT = xT; st[sp].next = -1;
+    }
+    out[i] = result;
+}
+
 // ================================================================ multi-GPU reassembly
 // d_gathered: numParts compact buffers, each padded to partRows rows of W pixels.
 __global__ void k_assemble(const float4* __restrict__ gathered, float4* __restrict__ frame,

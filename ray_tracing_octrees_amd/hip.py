@@ -28,7 +28,7 @@ SYMBOLS = (
     "rto_upload_octree", "rto_octree_info_get", "rto_set_kernel",
     "rto_update_frustum", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
-    "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_last_kernel_ms", "rto_stream", "rto_synchronize",
+    "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_last_kernel_ms", "rto_stream", "rto_synchronize",
 )
 
 
@@ -97,6 +97,7 @@ def load():
     L.rto_partition_rows.argtypes = [C.POINTER(Frame), C.POINTER(Partition)]
     L.rto_assemble_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp, vp]
     L.rto_frame_stats.argtypes = [vp, C.POINTER(Frame), C.POINTER(Stats)]
+    L.rto_octree_ray_skip.argtypes = [vp, C.POINTER(C.c_float), vp, C.c_int64, C.c_float, C.c_float, C.c_int, vp]
     L.rto_render_steps_host.argtypes = [vp, C.POINTER(Frame), vp]
     L.rto_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.rto_debug_timeline.argtypes = [vp, C.POINTER(Frame), vp, C.c_int64, C.POINTER(C.c_int64)]
@@ -200,6 +201,15 @@ class Context:
 
     def partition_rows(self, frame: Frame, part: Partition | None) -> int:
         return self._L.rto_partition_rows(C.byref(frame), C.byref(part) if part else None)
+
+    def octree_ray_skip(self, ro, rd, t_min=0.0, t_max=1e30, use_visibility=False) -> np.ndarray:
+        """octreeRaySkip (VolumeRaycastRenderer.cpp:50-155) for n rays sharing the origin ro; rd: (n, 3)."""
+        rd = np.ascontiguousarray(rd, dtype=np.float32).reshape(-1, 3)
+        out = np.empty(len(rd), np.float32)
+        o = (C.c_float * 3)(*[_f(x) for x in ro])
+        self._check(self._L.rto_octree_ray_skip(self._h, o, rd.ctypes.data, len(rd), _f(t_min), _f(t_max),
+                                                1 if use_visibility else 0, out.ctypes.data))
+        return out
 
     def frame_stats(self, frame: Frame) -> dict:
         s = Stats()

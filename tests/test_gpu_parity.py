@@ -369,3 +369,53 @@ def test_reference_host_stack_drives_the_hip_path(orc, scenes, camera, tmp_path)
     view, pos = camera("sphere")
     want, _ = oracle_frame(orc, s, view, pos, W, H)
     assert_bit_exact(got, want, "reference host stack + HIP path")
+
+
+def test_octree_ray_skip_matches_oracle(ctx, orc, scenes, camera):
+    """N1: the GPU form of octreeRaySkip, bit-exact distances vs the oracle's restatement of the recursion,
+    on random rays, axis-aligned rays (the 1e-10 clamp, S/VR:83-87) and the reference's 7x7 probe pattern."""
+    rng = np.random.default_rng(11)
+    for name, ro in (("sphere32", (0.9, 0.7, 1.3)), ("calgary", (300.0, 900.0, 2500.0)), ("odd", (9.0, 6.0, 7.0))):
+        s = scenes(name)
+        upload(ctx, s)
+        ro = np.array(ro, np.float32)
+        centre = s.min + np.array(s.grid.dims, np.float32) * np.float32(0.5) * s.voxel
+        tg = centre[None, :] + (rng.random((400, 3)).astype(np.float32) - 0.5) * (np.array(s.grid.dims, np.float32) * s.voxel)[None, :]
+        rd = tg - ro[None, :]
+        rd = (rd / np.sqrt((rd * rd).sum(axis=1, keepdims=True))).astype(np.float32)
+        axis = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, -0.6, -0.8], [1e-12, -1, 0]], np.float32)
+        rd = np.concatenate([rd, axis])
+        want = np.array([orc.octree_ray_skip(s.nodes, s.min, s.voxel, ro, d) for d in rd], np.float32)
+        got = ctx.octree_ray_skip(ro, rd)
+        assert got.tobytes() == want.tobytes(), name
+        assert (want < 1e30).sum() > 20
+        # narrower [tMin, tMax] window
+        want2 = np.array([orc.octree_ray_skip(s.nodes, s.min, s.voxel, ro, d, 0.5, float(np.median(want[want < 1e30]))) for d in rd], np.float32)
+        got2 = ctx.octree_ray_skip(ro, rd, 0.5, float(np.median(want[want < 1e30])))
+        assert got2.tobytes() == want2.tobytes(), name
+    # the probe pattern of drawRaycast (S/VR:1602-1647): 7x7 NDC samples within +-0.2, unprojected with inverse(P), inverse(V)
+    s = scenes("calgary")
+    upload(ctx, s)
+    view, pos = camera("calgary_oblique")
+    P = orc.perspective(orc.radians(45.0), 16 / 9, 0.1, 5000.0)
+    invV, invP = orc.mat4_inverse(view).reshape(4, 4).T, orc.mat4_inverse(P).reshape(4, 4).T   # row-major views
+    dirs = []
+    for y in range(7):
+        for x in range(7):
+            ndc = np.array([(x / 6 - 0.5) * 2 * 0.2, (y / 6 - 0.5) * 2 * 0.2, 1.0, 1.0], np.float32)
+            v = invP @ ndc
+            v = v / v[3]
+            w = invV @ v
+            d = w[:3] - pos
+            dirs.append(d / np.sqrt((d * d).sum()))
+    dirs = np.array(dirs, np.float32)
+    want = np.array([orc.octree_ray_skip(s.nodes, s.min, s.voxel, pos, d) for d in dirs], np.float32)
+    assert ctx.octree_ray_skip(pos, dirs).tobytes() == want.tobytes()
+    assert (want < 1e30).any()
+    # visibility map: nodes culled by the last frustum update return 1e30
+    ctx.update_frustum(view, 45.0, 16 / 9, enable=True)
+    _, vis = orc.cull_compact(s.nodes, s.min, s.voxel, view, 45.0, 16 / 9)
+    assert ctx.octree_ray_skip(pos, dirs, use_visibility=False).tobytes() == want.tobytes()
+    got_v = ctx.octree_ray_skip(pos, dirs, use_visibility=True)
+    assert (got_v >= want).all()
+    ctx.update_frustum(view, 45.0, 16 / 9, enable=False)
