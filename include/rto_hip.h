@@ -97,6 +97,16 @@ int  rto_device_name(const rto_context* ctx, char* buf, size_t buflen);
  * library additionally repacks canonical arrays into child descriptors. */
 int  rto_upload_octree(rto_context* ctx, const rto_node* nodes, int64_t num_nodes,
                        const float grid_min[3], float voxel_size);
+/* N4 -- replaces createOctreeFromVoxelGrid + the BFS of setOctree + the upload (S/OctreeVoxel.cpp:704-778,
+ * S/RayTracerBVH.cpp:443-504) in one call: the voxel grid (VoxelGrid.data layout: 1 byte per voxel, 0 EMPTY /
+ * 1 FILLED, x fastest) is copied to the GPU and the flat GPUNodes array + child descriptors are built there
+ * (occupancy pyramid, level-order emission).  The resident array is byte-identical to what the reference's two
+ * functions produce; rto_download_nodes returns it. */
+int  rto_build_octree(rto_context* ctx, const uint8_t* voxels, int dim_x, int dim_y, int dim_z,
+                      const float grid_min[3], float voxel_size);
+int  rto_download_nodes(rto_context* ctx, rto_node* out, int64_t capacity, int64_t* count);   /* out may be NULL */
+/* Device time of the last rto_build_octree: kernels (pyramid + emission) and the host-to-device voxel copy. */
+int  rto_last_build_ms(const rto_context* ctx, float* kernels_ms, float* upload_ms);
 int  rto_octree_info_get(const rto_context* ctx, rto_octree_info* out);
 int  rto_set_kernel(rto_context* ctx, int kernel /* RTO_KERNEL_* */);
 

@@ -58,6 +58,8 @@ struct rto_context {
     Counters* d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    float buildMs = -1.f;      // device time of the last rto_build_octree (pyramid + emission kernels)
+    float buildUploadMs = -1.f;
 };
 
 static thread_local std::string g_createError;
@@ -239,6 +241,168 @@ int rto_upload_octree(rto_context* c, const rto_node* nodes, int64_t n, const fl
         c->numInternal = internal;
         c->rootSize = nodes[0].size;
     }
+    return RTO_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- N4: build on the GPU
+namespace {
+struct LevelBuf {
+    int4* coords = nullptr;
+    uint8_t* state = nullptr;
+    uint8_t* flag = nullptr;
+    int* rank = nullptr;
+    int64_t m = 0;       // nodes at this level
+    int64_t k = 0;       // internal nodes at this level
+};
+struct BuildScratch {
+    std::vector<void*> allocs;
+    ~BuildScratch() { for (void* p : allocs) (void)hipFree(p); }
+    template <class T> hipError_t alloc(T** p, size_t count) {
+        hipError_t e = hipMalloc(p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) allocs.push_back(*p);
+        return e;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, int dimZ, const float grid_min[3], float voxel_size) {
+    if (!c) return RTO_E_INVALID;
+    if (!voxels || !grid_min || dimX <= 0 || dimY <= 0 || dimZ <= 0)
+        return fail(c, RTO_E_INVALID, "rto_build_octree: empty voxel grid (createOctreeFromVoxelGrid returns no root for it)");
+    int maxDim = dimX > dimY ? dimX : dimY;
+    if (dimZ > maxDim) maxDim = dimZ;
+    int R = 0;
+    while ((1 << R) < maxDim) R++;
+    if (R > kMaxDepth) return fail(c, RTO_E_UNSUPPORTED, "rto_build_octree: grid too large");
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    free_octree(c);
+    std::memcpy(c->gridMin, grid_min, sizeof c->gridMin);
+    c->voxelSize = voxel_size;
+    hipStream_t s = c->stream;
+    BuildScratch scratch;
+    hipEvent_t e0, e1, e2;
+    RTO_HIP(c, hipEventCreate(&e0)); RTO_HIP(c, hipEventCreate(&e1)); RTO_HIP(c, hipEventCreate(&e2));
+    struct EvGuard { hipEvent_t a, b, d; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(d); } } evg{ e0, e1, e2 };
+
+    // ---- voxels -> HBM
+    const size_t nvox = (size_t)dimX * dimY * dimZ;
+    uint8_t* d_vox = nullptr;
+    RTO_HIP(c, scratch.alloc(&d_vox, nvox));
+    RTO_HIP(c, hipEventRecord(e0, s));
+    RTO_HIP(c, hipMemcpyAsync(d_vox, voxels, nvox, hipMemcpyHostToDevice, s));
+    RTO_HIP(c, hipEventRecord(e1, s));
+
+    // ---- occupancy pyramid, bottom-up
+    PyramidView V;
+    std::memset(&V, 0, sizeof V);
+    V.level[0] = d_vox; V.nx[0] = dimX; V.ny[0] = dimY; V.nz[0] = dimZ;
+    for (int l = 1; l <= R; l++) {
+        V.nx[l] = (V.nx[l - 1] + 1) / 2; V.ny[l] = (V.ny[l - 1] + 1) / 2; V.nz[l] = (V.nz[l - 1] + 1) / 2;
+        const size_t cells = (size_t)V.nx[l] * V.ny[l] * V.nz[l];
+        uint8_t* d = nullptr;
+        RTO_HIP(c, scratch.alloc(&d, cells));
+        V.level[l] = d;
+        hipLaunchKernelGGL(k_pyramid_level, dim3((unsigned)((cells + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                           V.level[l - 1], V.nx[l - 1], V.ny[l - 1], V.nz[l - 1], d, V.nx[l], V.ny[l], V.nz[l], 1 << l, dimX, dimY, dimZ);
+    }
+    RTO_HIP(c, hipGetLastError());
+
+    // ---- pass 1: level-order node lists, internal flags and ranks
+    std::vector<LevelBuf> levels;
+    {
+        LevelBuf L0; L0.m = 1;
+        RTO_HIP(c, scratch.alloc(&L0.coords, 1));
+        const int4 rootc = make_int4(0, 0, 0, 0);
+        RTO_HIP(c, hipMemcpyAsync(L0.coords, &rootc, sizeof rootc, hipMemcpyHostToDevice, s));
+        levels.push_back(L0);
+    }
+    for (int L = 0; L <= R; L++) {
+        LevelBuf& lb = levels[(size_t)L];
+        const int lv = R - L;
+        const int nb = (int)((lb.m + kBlock - 1) / kBlock);
+        int *d_bc = nullptr, *d_bb = nullptr;
+        RTO_HIP(c, scratch.alloc(&lb.state, (size_t)lb.m)); RTO_HIP(c, scratch.alloc(&lb.flag, (size_t)lb.m));
+        RTO_HIP(c, scratch.alloc(&lb.rank, (size_t)lb.m));
+        RTO_HIP(c, scratch.alloc(&d_bc, (size_t)nb)); RTO_HIP(c, scratch.alloc(&d_bb, (size_t)nb));
+        hipLaunchKernelGGL(k_build_classify, dim3(nb), dim3(kBlock), 0, s, V, lb.coords, lb.m, lv, lb.state, lb.flag, d_bc);
+        hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, s, d_bc, nb, d_bb, c->d_visibleCount);
+        hipLaunchKernelGGL(k_cull_remap, dim3(nb), dim3(kBlock), 0, s, lb.flag, lb.m, d_bb, lb.rank);
+        RTO_HIP(c, hipGetLastError());
+        int64_t k = 0;
+        RTO_HIP(c, hipMemcpyAsync(&k, c->d_visibleCount, sizeof k, hipMemcpyDeviceToHost, s));
+        RTO_HIP(c, hipStreamSynchronize(s));
+        lb.k = k;
+        if (k == 0) break;
+        LevelBuf next; next.m = k * 8;
+        if (next.m > 0x7fffffff) return fail(c, RTO_E_UNSUPPORTED, "rto_build_octree: more than 2^31 nodes on one level");
+        RTO_HIP(c, scratch.alloc(&next.coords, (size_t)next.m));
+        hipLaunchKernelGGL(k_build_children, dim3(nb), dim3(kBlock), 0, s, lb.coords, lb.rank, lb.m, (1 << lv) / 2, next.coords);
+        RTO_HIP(c, hipGetLastError());
+        levels.push_back(next);
+    }
+    int64_t total = 0, internal = 0;
+    for (const LevelBuf& lb : levels) { total += lb.m; internal += lb.k; }
+    if (total > 0x7fffffff) return fail(c, RTO_E_UNSUPPORTED, "rto_build_octree: node indices are int32 (GPUNodes.child)");
+
+    // ---- pass 2: node records + descriptors
+    RTO_HIP(c, hipMalloc(&c->d_nodes, (size_t)total * sizeof(rto_node)));
+    if (internal > 0) {
+        RTO_HIP(c, hipMalloc(&c->d_desc, (size_t)internal * sizeof(uint2)));
+        RTO_HIP(c, hipMalloc(&c->d_descFirstChild, (size_t)internal * sizeof(int)));
+    }
+    int64_t levelBase = 0, internalBase = 0;
+    for (size_t L = 0; L < levels.size(); L++) {
+        const LevelBuf& lb = levels[L];
+        const bool hasNext = L + 1 < levels.size();
+        const int nb = (int)((lb.m + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(kBlock), 0, s, lb.coords, lb.state, lb.rank, lb.m, 1 << (R - (int)L),
+                           levelBase, internalBase, hasNext ? levels[L + 1].state : nullptr, hasNext ? levels[L + 1].rank : nullptr,
+                           internalBase + lb.k, c->d_nodes, c->d_desc, c->d_descFirstChild);
+        levelBase += lb.m; internalBase += lb.k;
+    }
+    RTO_HIP(c, hipGetLastError());
+    // ---- where the solid geometry is (launch-order heuristic)
+    int* d_bbox = nullptr;
+    RTO_HIP(c, scratch.alloc(&d_bbox, 6));
+    const int initBox[6] = { 0x7fffffff, 0x7fffffff, 0x7fffffff, -0x7fffffff, -0x7fffffff, -0x7fffffff };
+    RTO_HIP(c, hipMemcpyAsync(d_bbox, initBox, sizeof initBox, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_solid_bbox, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, c->d_nodes, total, d_bbox);
+    RTO_HIP(c, hipGetLastError());
+    RTO_HIP(c, hipEventRecord(e2, s));
+    int box[6];
+    RTO_HIP(c, hipMemcpyAsync(box, d_bbox, sizeof box, hipMemcpyDeviceToHost, s));
+    RTO_HIP(c, hipStreamSynchronize(s));
+    for (int a = 0; a < 3; a++) c->solidCentre[a] = box[a] <= box[3 + a] ? 0.5f * (float)(box[a] + box[3 + a]) : 0.5f * (float)(1 << R);
+    RTO_HIP(c, hipEventElapsedTime(&c->buildUploadMs, e0, e1));
+    RTO_HIP(c, hipEventElapsedTime(&c->buildMs, e1, e2));
+
+    c->numNodes = total; c->visibleNodes = total; c->numInternal = internal;
+    c->rootSize = 1 << R; c->depth = R;
+    c->canonical = internal > 0;                 // a one-node tree is rendered by the generic kernel
+    return RTO_OK;
+}
+
+int rto_last_build_ms(const rto_context* c, float* kernels_ms, float* upload_ms) {
+    if (!c || c->buildMs < 0.f) return RTO_E_INVALID;
+    if (kernels_ms) *kernels_ms = c->buildMs;
+    if (upload_ms) *upload_ms = c->buildUploadMs;
+    return RTO_OK;
+}
+
+int rto_download_nodes(rto_context* c, rto_node* out, int64_t capacity, int64_t* count) {
+    if (!c || !count) return RTO_E_INVALID;
+    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_download_nodes: no octree resident");
+    *count = c->numNodes;
+    if (!out) return RTO_OK;
+    if (capacity < c->numNodes) return fail(c, RTO_E_INVALID, "rto_download_nodes: capacity too small");
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    RTO_HIP(c, hipMemcpy(out, c->d_nodes, (size_t)c->numNodes * sizeof(rto_node), hipMemcpyDeviceToHost));
     return RTO_OK;
 }
 

@@ -963,6 +963,137 @@ __global__ __launch_bounds__(kBlock) void k_octree_ray_skip(const rto_node* __re
     out[i] = result;
 }
 
+// ================================================================ N4: octree construction on the GPU
+// createOctreeFromVoxelGrid + setOctree (453-skeleton/OctreeVoxel.cpp:704-778, RayTracerBVH.cpp:443-490) without
+// a pointer tree: (1) bottom-up occupancy pyramid over the voxel grid (state 0 = all EMPTY incl. the
+// out-of-grid part, 1 = all FILLED, 2 = mixed); (2) level-order emission -- the BFS numbering of setOctree IS
+// level order with the children of a level's internal nodes appended in node order -- using one flag scan
+// per level; (3) node records and child descriptors written straight into HBM.
+struct PyramidView {
+    const uint8_t* level[kMaxDepth + 1];   // level[0] = the voxels
+    int nx[kMaxDepth + 1], ny[kMaxDepth + 1], nz[kMaxDepth + 1];
+};
+
+__device__ __forceinline__ int pyr_state(const PyramidView& V, int lv, int x, int y, int z) {
+    const int i = x >> lv, j = y >> lv, k = z >> lv;
+    if (i >= V.nx[lv] || j >= V.ny[lv] || k >= V.nz[lv]) return 0;   // wholly outside the grid: EMPTY (getVoxelSafe)
+    return V.level[lv][(size_t)i + (size_t)j * V.nx[lv] + (size_t)k * V.nx[lv] * V.ny[lv]];
+}
+
+// one thread per cell of level lv >= 1; children at level lv-1 (voxels for lv == 1)
+__global__ __launch_bounds__(kBlock) void k_pyramid_level(const uint8_t* __restrict__ child, int cnx, int cny, int cnz,
+                                                           uint8_t* __restrict__ out, int nx, int ny, int nz,
+                                                           int ext, int dimX, int dimY, int dimZ) {
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t total = (size_t)nx * ny * nz;
+    if (t >= total) return;
+    const int i = (int)(t % nx), j = (int)((t / nx) % ny), k = (int)(t / ((size_t)nx * ny));
+    // the cell sticks out of the grid (its out-of-grid voxels are EMPTY) iff its extent passes a grid dimension
+    bool any0 = (i + 1) * (long)ext > dimX || (j + 1) * (long)ext > dimY || (k + 1) * (long)ext > dimZ;
+    bool any1 = false, mixed = false;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int ci = 2 * i + (c & 1), cj = 2 * j + ((c >> 1) & 1), ck = 2 * k + (c >> 2);
+        if (ci >= cnx || cj >= cny || ck >= cnz) continue;
+        const uint8_t s = child[(size_t)ci + (size_t)cj * cnx + (size_t)ck * cnx * cny];
+        mixed |= (s == 2); any1 |= (s == 1); any0 |= (s == 0);
+    }
+    out[t] = (mixed || (any0 && any1)) ? 2 : (any1 ? 1 : 0);
+}
+
+// classify the nodes of one tree level: internal flag + per-block internal count
+__global__ __launch_bounds__(kBlock) void k_build_classify(PyramidView V, const int4* __restrict__ coords, int64_t m, int lv,
+                                                            uint8_t* __restrict__ state, uint8_t* __restrict__ flag,
+                                                            int* __restrict__ blockCount) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool internal = false;
+    if (i < m) {
+        const int4 c = coords[i];
+        const int s = pyr_state(V, lv, c.x, c.y, c.z);
+        internal = (lv > 0) && (s == 2);
+        state[i] = (uint8_t)s;
+        flag[i] = internal ? 1 : 0;
+    }
+    const int cnt = __syncthreads_count(internal ? 1 : 0);
+    if (threadIdx.x == 0) blockCount[blockIdx.x] = cnt;
+}
+
+// children of the internal nodes of a level, in (node order, child slot) order = the next level's node list
+__global__ __launch_bounds__(kBlock) void k_build_children(const int4* __restrict__ coords, const int* __restrict__ rank, int64_t m,
+                                                            int half, int4* __restrict__ next) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const int r = rank[i];
+    if (r < 0) return;
+    const int4 c = coords[i];
+#pragma unroll
+    for (int k = 0; k < 8; k++)   // S/OctreeVoxel.cpp:751-754: bit0 -> +x, bit1 -> +y, bit2 -> +z
+        next[(size_t)r * 8 + k] = make_int4(c.x + ((k & 1) ? half : 0), c.y + ((k & 2) ? half : 0), c.z + ((k & 4) ? half : 0), 0);
+}
+
+// node records (GPUNodes) and child descriptors of one level
+__global__ __launch_bounds__(kBlock) void k_build_emit(const int4* __restrict__ coords, const uint8_t* __restrict__ state,
+                                                        const int* __restrict__ rank, int64_t m, int size,
+                                                        int64_t levelBase,          // flat index of this level's first node
+                                                        int64_t internalBase,       // descriptor index of this level's first internal node
+                                                        const uint8_t* __restrict__ childState,   // next level (8 per internal node), may be null
+                                                        const int* __restrict__ childRank,        // next level's internal ranks (-1 = leaf)
+                                                        int64_t nextInternalBase,
+                                                        rto_node* __restrict__ nodes, uint2* __restrict__ desc, int* __restrict__ descFirstChild) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const int4 c = coords[i];
+    const int r = rank[i];
+    rto_node nd;
+    nd.x = c.x; nd.y = c.y; nd.z = c.z; nd.size = size;
+    const bool internal = r >= 0;
+    nd.isLeaf = internal ? 0 : 1;
+    nd.isUniform = nd.isLeaf;                                  // S/OctreeVoxel.cpp:716-745: leaf <=> uniform
+    nd.isSolid = (!internal && state[i] == 1) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) nd.child[k] = -1;
+    if (internal) {
+        const int64_t c0 = levelBase + m + (int64_t)r * 8;     // the next level starts right after this one
+        unsigned imask = 0, smask = 0;
+        int firstInternal = -1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            nd.child[k] = (int)(c0 + k);
+            const int cr = childRank[(size_t)r * 8 + k];
+            if (cr >= 0) { imask |= 1u << k; if (firstInternal < 0) firstInternal = cr; }
+            else if (childState[(size_t)r * 8 + k] == 1) smask |= 1u << k;
+        }
+        const int64_t d = internalBase + r;
+        desc[d] = make_uint2(smask | (imask << 8) | 0xff0000u, firstInternal >= 0 ? (unsigned)(nextInternalBase + firstInternal) : 0u);
+        descFirstChild[d] = (int)c0;
+    }
+    nodes[levelBase + i] = nd;
+}
+
+// bounding box of the solid leaves (voxel units) for the launch-order heuristic: 6 atomics per wave
+__global__ __launch_bounds__(kBlock) void k_solid_bbox(const rto_node* __restrict__ nodes, int64_t n, int* __restrict__ bbox /* lo[3], hi[3] */) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
+    if (i < n) {
+        const rto_node* nd = nodes + i;
+        if ((nd->isLeaf == 1 || nd->isUniform == 1) && nd->isSolid == 1) {
+            lo[0] = nd->x; lo[1] = nd->y; lo[2] = nd->z;
+            hi[0] = nd->x + nd->size; hi[1] = nd->y + nd->size; hi[2] = nd->z + nd->size;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = min(lo[a], __shfl_down(lo[a], off));
+            hi[a] = max(hi[a], __shfl_down(hi[a], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { atomicMin(&bbox[a], lo[a]); atomicMax(&bbox[3 + a], hi[a]); }
+    }
+}
+
 // ================================================================ multi-GPU reassembly
 // d_gathered: numParts compact buffers, each padded to partRows rows of W pixels.
 __global__ void k_assemble(const float4* __restrict__ gathered, float4* __restrict__ frame,

@@ -25,7 +25,7 @@ NODE_DTYPE = np.dtype(
 # every symbol include/rto_hip.h declares
 SYMBOLS = (
     "rto_create", "rto_destroy", "rto_last_error", "rto_device_name",
-    "rto_upload_octree", "rto_octree_info_get", "rto_set_kernel",
+    "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel",
     "rto_update_frustum", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_last_kernel_ms", "rto_stream", "rto_synchronize",
@@ -89,6 +89,9 @@ def load():
     L.rto_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.rto_upload_octree.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_float), C.c_float]
     L.rto_octree_info_get.argtypes = [vp, C.POINTER(OctreeInfo)]
+    L.rto_build_octree.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float]
+    L.rto_download_nodes.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.rto_last_build_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rto_set_kernel.argtypes = [vp, C.c_int]
     L.rto_update_frustum.argtypes = [vp, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int]
     L.rto_download_visible_nodes.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
@@ -162,6 +165,25 @@ class Context:
             raise RtoError(RTO_E_INVALID, "nodes must be an array of 60-byte GPUNodes records")
         gm = (C.c_float * 3)(*[_f(x) for x in grid_min])
         self._check(self._L.rto_upload_octree(self._h, nodes.ctypes.data, len(nodes), gm, _f(voxel_size)))
+
+    def build_octree(self, voxels: np.ndarray, grid_min, voxel_size):
+        """N4: createOctreeFromVoxelGrid + setOctree on the GPU. voxels: uint8 (dimZ, dimY, dimX), 0 EMPTY / 1 FILLED."""
+        v = np.ascontiguousarray(voxels, dtype=np.uint8)
+        dz, dy, dx = v.shape
+        gm = (C.c_float * 3)(*[_f(x) for x in grid_min])
+        self._check(self._L.rto_build_octree(self._h, v.ctypes.data, dx, dy, dz, gm, _f(voxel_size)))
+
+    def download_nodes(self) -> np.ndarray:
+        cnt = C.c_int64()
+        self._check(self._L.rto_download_nodes(self._h, None, 0, C.byref(cnt)))
+        out = np.zeros(cnt.value, NODE_DTYPE)
+        self._check(self._L.rto_download_nodes(self._h, out.ctypes.data, cnt.value, C.byref(cnt)))
+        return out
+
+    def last_build_ms(self):
+        k, u = C.c_float(), C.c_float()
+        self._check(self._L.rto_last_build_ms(self._h, C.byref(k), C.byref(u)))
+        return k.value, u.value
 
     def info(self) -> OctreeInfo:
         o = OctreeInfo()

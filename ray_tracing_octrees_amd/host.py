@@ -85,6 +85,8 @@ def load():
     L.rtoh_rt_ensure_compute_initialized.restype = None
     L.rtoh_rt_set_octree.argtypes = [_vp, _vp, _vp]
     L.rtoh_rt_set_octree.restype = None
+    L.rtoh_rt_set_octree_from_grid.argtypes = [_vp, _vp]
+    L.rtoh_rt_set_octree_from_grid.restype = None
     L.rtoh_rt_set_frustum_culling_enabled.argtypes = [_vp, C.c_int]
     L.rtoh_rt_set_frustum_culling_enabled.restype = None
     L.rtoh_rt_render_scene_compute.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float]
@@ -277,6 +279,11 @@ class RayTracerBVH:
     def setOctree(self, root: OctreeNode | None, grid: VoxelGrid):
         self._keep = (root, grid)
         load().rtoh_rt_set_octree(self._h, root._h if root is not None else None, grid._h)
+
+    def setOctreeFromGrid(self, grid: VoxelGrid):
+        """Addition: build the octree on the GPU straight from the voxel grid (rto_build_octree)."""
+        self._keep = (None, grid)
+        load().rtoh_rt_set_octree_from_grid(self._h, grid._h)
 
     def setFrustumCullingEnabled(self, enabled: bool):
         load().rtoh_rt_set_frustum_culling_enabled(self._h, 1 if enabled else 0)

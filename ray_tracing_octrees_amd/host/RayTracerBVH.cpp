@@ -19,6 +19,8 @@ struct HipApi {
     decltype(&rto_destroy) destroy = nullptr;
     decltype(&rto_last_error) last_error = nullptr;
     decltype(&rto_upload_octree) upload_octree = nullptr;
+    decltype(&rto_build_octree) build_octree = nullptr;
+    decltype(&rto_octree_info_get) octree_info = nullptr;
     decltype(&rto_update_frustum) update_frustum = nullptr;
     decltype(&rto_render_host) render_host = nullptr;
     std::string error;
@@ -51,6 +53,8 @@ struct HipApi {
         destroy = reinterpret_cast<decltype(destroy)>(sym("rto_destroy"));
         last_error = reinterpret_cast<decltype(last_error)>(sym("rto_last_error"));
         upload_octree = reinterpret_cast<decltype(upload_octree)>(sym("rto_upload_octree"));
+        build_octree = reinterpret_cast<decltype(build_octree)>(sym("rto_build_octree"));
+        octree_info = reinterpret_cast<decltype(octree_info)>(sym("rto_octree_info_get"));
         update_frustum = reinterpret_cast<decltype(update_frustum)>(sym("rto_update_frustum"));
         render_host = reinterpret_cast<decltype(render_host)>(sym("rto_render_host"));
         if (!ok) { dlclose(handle); handle = nullptr; }
@@ -118,6 +122,25 @@ void RayTracerBVH::setOctree(OctreeNode* root, const VoxelGrid& grid) {
     }
 }
 
+void RayTracerBVH::setOctreeFromGrid(const VoxelGrid& grid) {
+    m_octreeRoot = nullptr;
+    m_grid = grid;
+    m_flatNodes.clear();
+    m_numNodes = 0;
+    if (!m_computeInited) ensureComputeInitialized();
+    if (!m_computeOk || grid.dimX <= 0 || grid.dimY <= 0 || grid.dimZ <= 0) return;
+    const float gridMin[3] = { grid.minX, grid.minY, grid.minZ };
+    static_assert(sizeof(VoxelState) == 1, "VoxelGrid.data is one byte per voxel");
+    if (api().build_octree(m_ctx, reinterpret_cast<const uint8_t*>(grid.data.data()), grid.dimX, grid.dimY, grid.dimZ, gridMin,
+                           grid.voxelSize) != RTO_OK) {
+        m_lastError = api().last_error(m_ctx);
+        std::cerr << "[RayTracerBVH] GPU octree build failed: " << m_lastError << std::endl;
+        return;
+    }
+    rto_octree_info info;
+    if (api().octree_info(m_ctx, &info) == RTO_OK) m_numNodes = static_cast<int>(info.num_nodes);
+}
+
 void RayTracerBVH::ensureComputeInitialized() {
     if (m_computeInited) return;
     m_computeInited = true;
@@ -133,7 +156,7 @@ void RayTracerBVH::ensureComputeInitialized() {
         return;
     }
     m_computeOk = true;
-    if (m_numNodes > 0) {               // setOctree() came first
+    if (m_numNodes > 0 && !m_flatNodes.empty()) {   // setOctree() came first
         const float gridMin[3] = { m_grid.minX, m_grid.minY, m_grid.minZ };
         if (api().upload_octree(m_ctx, reinterpret_cast<const rto_node*>(m_flatNodes.data()), m_numNodes, gridMin,
                                 m_grid.voxelSize) != RTO_OK) {

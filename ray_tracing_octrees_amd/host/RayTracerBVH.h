@@ -60,9 +60,13 @@ public:
                                        bool updateFrustum);
 
     // ---- additions (not in the reference) ----
+    // createOctreeFromVoxelGrid + setOctree in one step ON THE GPU (rto_build_octree): no pointer tree, no host
+    // flatten.  The resident array equals what setOctree(createOctreeFromVoxelGrid(grid), grid) uploads.
+    void setOctreeFromGrid(const VoxelGrid& grid);
     // BFS numbering of setOctree (RayTracerBVH.cpp:443-490) without touching the GPU.
     static std::vector<GPUNodes> flatten(const OctreeNode* root);
-    const std::vector<GPUNodes>& flatNodes() const { return m_flatNodes; }
+    const std::vector<GPUNodes>& flatNodes() const { return m_flatNodes; }   // empty after setOctreeFromGrid
+    int numNodes() const { return m_numNodes; }
     const std::vector<float>& framebuffer() const { return m_frame; }   // width*height*4 floats of the last render
     int frameWidth() const { return m_frameW; }
     int frameHeight() const { return m_frameH; }

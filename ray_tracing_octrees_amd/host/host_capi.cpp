@@ -113,6 +113,7 @@ RayTracerBVH* rtoh_rt_new(int device) {
 void rtoh_rt_free(RayTracerBVH* rt) { delete rt; }
 void rtoh_rt_ensure_compute_initialized(RayTracerBVH* rt) { rt->ensureComputeInitialized(); }
 void rtoh_rt_set_octree(RayTracerBVH* rt, OctreeNode* root, const VoxelGrid* g) { rt->setOctree(root, *g); }
+void rtoh_rt_set_octree_from_grid(RayTracerBVH* rt, const VoxelGrid* g) { rt->setOctreeFromGrid(*g); }
 void rtoh_rt_set_frustum_culling_enabled(RayTracerBVH* rt, int enabled) { rt->setFrustumCullingEnabled(enabled != 0); }
 void rtoh_rt_render_scene_compute(RayTracerBVH* rt, const Camera* cam, int w, int h, float aspect, float fovDeg) {
     rt->renderSceneCompute(*cam, w, h, aspect, fovDeg);
@@ -121,7 +122,7 @@ void rtoh_rt_render_scene_compute_with_culling(RayTracerBVH* rt, const Camera* c
                                                float fovDeg, int updateFrustum) {
     rt->renderSceneComputeWithCulling(*cam, w, h, aspect, fovDeg, updateFrustum != 0);
 }
-int64_t rtoh_rt_num_nodes(const RayTracerBVH* rt) { return (int64_t)rt->flatNodes().size(); }
+int64_t rtoh_rt_num_nodes(const RayTracerBVH* rt) { return (int64_t)rt->numNodes(); }
 int rtoh_rt_framebuffer(const RayTracerBVH* rt, float* out, int64_t capacityFloats, int* w, int* h) {
     *w = rt->frameWidth(); *h = rt->frameHeight();
     const std::vector<float>& fb = rt->framebuffer();

@@ -339,6 +339,12 @@ def test_cpp_dropin_class_end_to_end(orc, scenes, camera):
     rt2.ensureComputeInitialized()
     rt2.renderSceneCompute(cam, W, H, W / H, 45.0)
     assert_bit_exact(rt2.framebuffer(), want, "C++ drop-in, deferred upload")
+    # addition: octree built on the GPU from the grid, no pointer tree at all
+    rt4 = rto.RayTracerBVH()
+    rt4.setOctreeFromGrid(g)
+    assert rt4.numNodes == 23561
+    rt4.renderSceneCompute(cam, W, H, W / H, 45.0)
+    assert_bit_exact(rt4.framebuffer(), want, "C++ drop-in, GPU-built octree")
     # null root: silently nothing (S/RT:439, :625)
     rt3 = rto.RayTracerBVH()
     rt3.ensureComputeInitialized()
@@ -419,3 +425,64 @@ def test_octree_ray_skip_matches_oracle(ctx, orc, scenes, camera):
     got_v = ctx.octree_ray_skip(pos, dirs, use_visibility=True)
     assert (got_v >= want).all()
     ctx.update_frustum(view, 45.0, 16 / 9, enable=False)
+
+
+@pytest.mark.parametrize("name", ["sphere16", "sphere64", "sphere256", "calgary", "odd"])
+def test_gpu_octree_build_equals_reference_arrays(ctx, orc, scenes, camera, golden_meta, name):
+    """N4: the flat array built on the GPU from the voxel grid is byte-identical to createOctreeFromVoxelGrid +
+    setOctree (oracle == reference goldens), and renders identically through the packed kernel."""
+    import hashlib
+
+    s = scenes(name)
+    ctx.set_kernel(rto.KERNEL_AUTO)
+    ctx.build_octree(s.grid.data, s.min, s.voxel)
+    got = ctx.download_nodes()
+    assert len(got) == len(s.nodes)
+    assert got.tobytes() == s.nodes.tobytes()
+    if name in golden_meta["octrees"]:
+        assert hashlib.sha256(got.tobytes()).hexdigest() == golden_meta["octrees"][name]["sha256"]
+    info = ctx.info()
+    assert info.canonical == 1 and info.num_internal == int((s.nodes["isLeaf"] == 0).sum())
+    if name == "odd":
+        cam = orc.Camera(0.4, 0.9, 9.0)
+        view, pos = cam.get_view(), cam.get_pos()
+    else:
+        view, pos = camera("calgary_oblique" if name == "calgary" else "sphere")
+    W, H = 320, 200
+    want, _ = oracle_frame(orc, s, view, pos, W, H)
+    for kname, kernel in KERNELS:
+        ctx.set_kernel(kernel)
+        assert_bit_exact(ctx.render_host(rto.make_frame(view, pos, W / H, 45.0, W, H)), want, f"gpu-built {name} {kname}")
+    # culling works on the GPU-built tree too
+    if name == "calgary":
+        ctx.set_kernel(rto.KERNEL_AUTO)
+        ctx.update_frustum(view, 45.0, W / H, enable=True)
+        cn, _ = orc.cull_compact(s.nodes, s.min, s.voxel, view, 45.0, W / H)
+        assert ctx.download_visible_nodes().tobytes() == cn.tobytes()
+        wantc, _ = orc.render(cn, s.min, s.voxel, view, pos, W / H, 45.0, W, H)
+        assert_bit_exact(ctx.render_host(rto.make_frame(view, pos, W / H, 45.0, W, H)), wantc, "gpu-built culled")
+        ctx.update_frustum(view, 45.0, W / H, enable=False)
+
+
+def test_gpu_octree_build_degenerate_and_random_grids(ctx, orc):
+    rng = np.random.default_rng(3)
+    cases = [((1, 1, 1), 1.0), ((1, 1, 1), 0.0), ((4, 4, 4), 1.0), ((4, 4, 4), 0.0), ((3, 3, 3), 1.0), ((7, 5, 3), 0.5),
+             ((33, 9, 20), 0.9), ((64, 1, 1), 0.5), ((2, 3, 1), 0.0), ((17, 17, 17), 0.02)]
+    for dims, p in cases:
+        data = (rng.random((dims[2], dims[1], dims[0])) < p).astype(np.uint8)
+        mn = np.array([0.5, -2.0, 3.0], np.float32)
+        want = orc.build_flat_octree(orc.Grid(dims, mn, np.float32(0.3), data))
+        ctx.build_octree(data, mn, 0.3)
+        assert ctx.download_nodes().tobytes() == want.tobytes(), (dims, p)
+        assert ctx.info().canonical == (1 if len(want) > 1 else 0)
+    with pytest.raises(rto.RtoError) as e:
+        ctx.build_octree(np.zeros((0, 4, 4), np.uint8), [0, 0, 0], 1.0)
+    assert e.value.code == hip.RTO_E_INVALID
+
+
+def test_gpu_octree_build_512(ctx, orc, scenes):
+    s = scenes("sphere512")
+    ctx.build_octree(s.grid.data, s.min, s.voxel)
+    assert ctx.download_nodes().tobytes() == s.nodes.tobytes()
+    k_ms, up_ms = ctx.last_build_ms()
+    assert 0 < k_ms < 1000
