@@ -58,6 +58,10 @@ def load():
     L.rtoh_octree_flatten.argtypes = [_vp, _vp, C.c_int64]
     L.rtoh_octree_flatten.restype = C.c_int64
     L.rtoh_octree_neighbors.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.rtoh_local_mc.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64]
+    L.rtoh_local_mc.restype = C.c_int64
+    L.rtoh_mc_renderer.argtypes = [_vp, _vp, _vp, C.c_int64]
+    L.rtoh_mc_renderer.restype = C.c_int64
     L.rtoh_camera_new.argtypes = [C.c_float, C.c_float, C.c_float]
     L.rtoh_camera_new.restype = _vp
     L.rtoh_camera_free.argtypes = [_vp]
@@ -192,6 +196,26 @@ class OctreeNode:
 def createOctreeFromVoxelGrid(grid: VoxelGrid) -> OctreeNode | None:
     h = load().rtoh_octree_build(grid._h)
     return OctreeNode(h) if h else None
+
+
+def localMC(grid: VoxelGrid, x0: int, y0: int, z0: int, size: int) -> np.ndarray:
+    """453-skeleton/OctreeVoxel.cpp:780-879.  Returns (n, 18) float32: v0,v1,v2 then the three (equal) normals."""
+    n = load().rtoh_local_mc(grid._h, x0, y0, z0, size, None, 0)
+    out = np.zeros((n, 18), np.float32)
+    if n:
+        load().rtoh_local_mc(grid._h, x0, y0, z0, size, out.ctypes.data, n)
+    return out
+
+
+class MarchingCubesRenderer:
+    """453-skeleton/Renderer.h:18-24: localMC over every leaf of the tree, in child order."""
+
+    def render(self, root: OctreeNode, grid: VoxelGrid) -> np.ndarray:
+        n = load().rtoh_mc_renderer(root._h, grid._h, None, 0)
+        out = np.zeros((n, 18), np.float32)
+        if n:
+            load().rtoh_mc_renderer(root._h, grid._h, out.ctypes.data, n)
+        return out
 
 
 def freeOctree(root: OctreeNode | None):

@@ -64,8 +64,9 @@ OctreeNode* getParentCube(OctreeNode* node);
 int getSubcubeIndex(int x, int y, int z, int halfSize, int x0, int y0, int z0);
 std::vector<OctreeNode*> getNeighbors(OctreeNode* node, const std::unordered_map<long long, OctreeNode*>& nodeMap);
 
-// localMC (per-leaf Marching Cubes, OctreeVoxel.cpp:780-879) belongs to row N2 of the scope table
-// (leaf triangles for config 5) and is declared in MarchingCubes.h once that row is built.
+// Marching Cubes over the cells [x0,x0+size) x [y0,..) x [z0,..) of the grid (cell = 8 neighbouring voxels;
+// FILLED -> -1, EMPTY / out of grid -> +1, iso 0), same output order as upstream (OctreeVoxel.cpp:780-879).
+std::vector<MCTriangle> localMC(const VoxelGrid& grid, int x0, int y0, int z0, int size);
 
 // Test scene of the reference app (453-skeleton/main.cpp:337-372, 1052-1070, 376-422); these are
 // file-static helpers of main.cpp upstream, exposed here because every benchmark config uses them.

@@ -11,6 +11,7 @@
 #include "Frustum.h"
 #include "OctreeVoxel.h"
 #include "RayTracerBVH.h"
+#include "Renderer.h"
 
 extern "C" {
 
@@ -69,6 +70,25 @@ int rtoh_octree_neighbors(const VoxelGrid* g, int x, int y, int z, int size, int
         outXYZS[i * 4 + 0] = nb[i]->x; outXYZS[i * 4 + 1] = nb[i]->y; outXYZS[i * 4 + 2] = nb[i]->z; outXYZS[i * 4 + 3] = nb[i]->size;
     }
     return (int)nb.size();
+}
+
+// localMC / MarchingCubesRenderer: 18 floats per triangle (v0,v1,v2, n0,n1,n2); call with out == NULL to size
+static int64_t copy_tris(const std::vector<MCTriangle>& tris, float* out, int64_t capacityTris) {
+    if (out && capacityTris >= (int64_t)tris.size())
+        for (size_t i = 0; i < tris.size(); i++)
+            for (int v = 0; v < 3; v++)
+                for (int a = 0; a < 3; a++) {
+                    out[i * 18 + v * 3 + a] = tris[i].v[v][a];
+                    out[i * 18 + 9 + v * 3 + a] = tris[i].normal[v][a];
+                }
+    return (int64_t)tris.size();
+}
+int64_t rtoh_local_mc(const VoxelGrid* g, int x0, int y0, int z0, int size, float* out, int64_t capacityTris) {
+    return copy_tris(localMC(*g, x0, y0, z0, size), out, capacityTris);
+}
+int64_t rtoh_mc_renderer(const OctreeNode* root, const VoxelGrid* g, float* out, int64_t capacityTris) {
+    MarchingCubesRenderer r;
+    return copy_tris(r.render(root, *g, root ? root->x : 0, root ? root->y : 0, root ? root->z : 0, root ? root->size : 0), out, capacityTris);
 }
 
 // ---------------------------------------------------------------- Camera

@@ -192,3 +192,36 @@ def test_host_test_scene_matches_oracle(orc):
         og = orc.test_sphere_grid(dim)
         assert (g.data == og.data).all()
         np.testing.assert_array_equal(g.min, og.min)
+
+
+def test_host_local_mc_matches_reference_triangles(golden):
+    """N2 input: localMC (OctreeVoxel.cpp:780-879) against triangles the reference itself produced."""
+    z = golden("ref_localmc_sphere16.npz")
+    g = rto.VoxelGrid.test_sphere(16)
+    whole = rto.localMC(g, 0, 0, 0, 16)
+    assert whole.shape == z["whole"].shape and whole.shape[0] > 1000
+    assert whole.tobytes() == z["whole"].tobytes()
+    cell = rto.localMC(g, 4, 4, 4, 4)
+    assert cell.tobytes() == z["cell_4_4_4_s4"].tobytes()
+    # the case table itself: every one of the 256 corner configurations of a single cell
+    cases = golden("ref_mc_cases.npz")
+    corners = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+    for case in range(256):
+        data = np.zeros((2, 2, 2), np.uint8)
+        for i, (x, y, zc) in enumerate(corners):
+            if case >> i & 1:
+                data[zc, y, x] = 1
+        got = rto.localMC(rto.VoxelGrid.from_array(data, [0, 0, 0], 1.0), 0, 0, 0, 1)
+        assert got.tobytes() == cases[f"case{case}"].tobytes(), case
+
+
+def test_host_marching_cubes_renderer_covers_every_leaf():
+    g = rto.VoxelGrid.test_sphere(16)
+    root = rto.createOctreeFromVoxelGrid(g)
+    tris = rto.MarchingCubesRenderer().render(root, g)
+    whole = rto.localMC(g, 0, 0, 0, 16)
+    # leaves tile the grid, so the per-leaf extraction yields the same triangle multiset as one whole-grid pass
+    assert len(tris) == len(whole)
+    key = lambda a: a[np.lexsort(a.T[::-1])]
+    assert key(tris).tobytes() == key(whole).tobytes()
+    rto.freeOctree(root)
