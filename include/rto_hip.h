@@ -140,6 +140,19 @@ int  rto_partition_rows(const rto_frame* frame, const rto_partition* part);
 int  rto_assemble_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part,
                          const void* d_gathered, void* d_frame, void* hip_stream);
 
+/* ---- N2: leaf triangles + shadow ray (BASELINE config 5) -------------------------
+ * No upstream counterpart: the reference has no ray/triangle code (its MC triangles are rasterised).  The
+ * triangles are those MarchingCubesRenderer emits per leaf (localMC, S/OctreeVoxel.cpp:780-879;
+ * host/OctreeVoxel.h buildLeafTriangles): 12 floats each (v0, v1, v2, face normal), ordered by node;
+ * tri_offset[i]..tri_offset[i+1] (numNodes+1 entries) is node i's range.  Rendering follows the reference's
+ * traversal order and 512-pop cap; a leaf is hit when one of its triangles is (Moeller-Trumbore, nearest
+ * t > 0 in the leaf); shading = the reference's Lambert term on the ray-facing face normal; shadow != 0 adds one
+ * ray towards the light (any hit => ambient only).  stats may be NULL (pops counts both traversals). */
+int  rto_upload_leaf_triangles(rto_context* ctx, const float* tris, int64_t num_tris, const int32_t* tri_offset);
+int  rto_render_triangles_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part, int shadow,
+                                 void* d_out, void* hip_stream);
+int  rto_render_triangles_host(rto_context* ctx, const rto_frame* frame, int shadow, float* host_rgba, rto_stats* stats);
+
 /* ---- N1: octreeRaySkip --------------------------------------------------------
  * replaces: the CPU recursion octreeRaySkip(root, ro, rd, tMin, tMax, grid, &visibility)
  * (S/VolumeRaycastRenderer.cpp:50-155; called for a 7x7 probe grid per frame at :1602-1647).

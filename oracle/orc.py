@@ -106,6 +106,12 @@ def lib():
                                    C.c_int, C.c_int, C.c_void_p]
     L.orc_octree_ray_skip.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float]
     L.orc_octree_ray_skip.restype = C.c_float
+    L.orc_local_mc.argtypes = [C.POINTER(_Grid), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.orc_local_mc.restype = C.c_int64
+    L.orc_build_leaf_triangles.argtypes = [C.POINTER(_Grid), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.orc_build_leaf_triangles.restype = C.c_int64
+    L.orc_render_triangles.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _f32p, C.c_float, _f32p, _f32p, C.c_float,
+                                       C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_Stats), C.c_int]
     L.orc_max_threads.restype = C.c_int
     _lib = L
     return L
@@ -248,6 +254,38 @@ def octree_ray_skip(nodes, grid_min, voxel_size, ro, rd, tmin=0.0, tmax=1e30):
     nodes = np.ascontiguousarray(nodes)
     return lib().orc_octree_ray_skip(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size),
                                      _f32(ro), _f32(rd), tmin, tmax)
+
+
+def local_mc(g: Grid, x0, y0, z0, size) -> np.ndarray:
+    out = C.c_void_p()
+    cg = g.c()
+    n = lib().orc_local_mc(C.byref(cg), x0, y0, z0, size, C.byref(out))
+    arr = np.frombuffer(C.string_at(out.value, max(n, 0) * 72), dtype=np.float32).copy().reshape(-1, 18)
+    lib().orc_free(out)
+    return arr
+
+
+def build_leaf_triangles(g: Grid, nodes):
+    """(tris (n,12) float32, triOffset (numNodes+1,) int32): localMC per leaf in flat-array order."""
+    nodes = np.ascontiguousarray(nodes)
+    t, o = C.c_void_p(), C.c_void_p()
+    cg = g.c()
+    n = lib().orc_build_leaf_triangles(C.byref(cg), nodes.ctypes.data, len(nodes), C.byref(t), C.byref(o))
+    tris = np.frombuffer(C.string_at(t.value, max(n, 0) * 48), dtype=np.float32).copy().reshape(-1, 12)
+    off = np.frombuffer(C.string_at(o.value, (len(nodes) + 1) * 4), dtype=np.int32).copy()
+    lib().orc_free(t); lib().orc_free(o)
+    return tris, off
+
+
+def render_triangles(nodes, tris, tri_offset, grid_min, voxel_size, view, cam_pos, aspect, fov_deg, W, H, shadow=True, nthreads=1):
+    nodes = np.ascontiguousarray(nodes); tris = np.ascontiguousarray(tris, dtype=np.float32)
+    tri_offset = np.ascontiguousarray(tri_offset, dtype=np.int32)
+    out = np.zeros((H, W, 4), np.float32)
+    st = _Stats()
+    lib().orc_render_triangles(nodes.ctypes.data, len(nodes), tris.ctypes.data, tri_offset.ctypes.data, _f32(grid_min),
+                               float(voxel_size), _f32(view), _f32(cam_pos), float(aspect), float(fov_deg), W, H,
+                               1 if shadow else 0, out.ctypes.data, C.byref(st), nthreads)
+    return out, {k: getattr(st, k) for k in ("rays", "pops", "hits", "capped")}
 
 
 def max_threads() -> int:

@@ -707,3 +707,185 @@ float orc_octree_ray_skip(const orc_node* nodes, int64_t n, const float gridMin[
     if (n <= 0) return 1e30f;
     return ray_skip_rec(nodes, 0, gridMin, voxelSize, v3_(ro[0], ro[1], ro[2]), v3_(rd[0], rd[1], rd[2]), tMin, tMax);
 }
+
+/* ------------------------------------------------------------------ */
+/* N2: localMC (S/OctreeVoxel.cpp:633-640, 780-879), leaf triangles, triangle renderer */
+/* ------------------------------------------------------------------ */
+#include "mc_cases.inc"   /* derived by probing the compiled reference: tools/gen_mc_tables.py */
+
+static const int kMcCorner[8][3] = { {0,0,0},{1,0,0},{1,1,0},{0,1,0},{0,0,1},{1,0,1},{1,1,1},{0,1,1} };
+static const int kMcEdge[12][2] = { {0,1},{1,2},{2,3},{3,0},{4,5},{5,6},{6,7},{7,4},{0,4},{1,5},{2,6},{3,7} };   /* S/OctreeVoxel.h:16-20 */
+
+static inline v3 vertex_interp(float iso, v3 p1, v3 p2, float v1, float v2) {
+    /* S/OctreeVoxel.cpp:633-640 */
+    if (fabsf(iso - v1) < 0.00001f) return p1;
+    if (fabsf(iso - v2) < 0.00001f) return p2;
+    if (fabsf(v1 - v2) < 0.00001f) return p1;
+    float mu = (iso - v1) / (v2 - v1);
+    v3 d = v3_sub(p2, p1);
+    return v3_add(p1, v3_(mu * d.x, mu * d.y, mu * d.z));
+}
+
+static inline int hexval(char c) { return c <= '9' ? c - '0' : c - 'a' + 10; }
+
+typedef struct { float* p; size_t n, cap; } fvec;
+static void fvec_push(fvec* v, const float* src, size_t k) {
+    if (v->n + k > v->cap) { v->cap = (v->cap ? v->cap * 2 : 4096) + k; v->p = (float*)realloc(v->p, v->cap * sizeof(float)); }
+    memcpy(v->p + v->n, src, k * sizeof(float)); v->n += k;
+}
+
+/* appends triangles of the cells [x0,x0+size)^3; stride 18 (reference MCTriangle) or 12 (v0,v1,v2,n) */
+static void local_mc_append(const orc_grid* g, int x0, int y0, int z0, int size, fvec* out, int stride) {
+    const float vx = g->voxelSize;
+    for (int z = z0; z < z0 + size && z < g->dimZ - 1; z++)
+        for (int y = y0; y < y0 + size && y < g->dimY - 1; y++)
+            for (int x = x0; x < x0 + size && x < g->dimX - 1; x++) {
+                v3 pos[8]; float val[8]; int cube = 0;
+                for (int i = 0; i < 8; i++) {
+                    int cx = x + kMcCorner[i][0], cy = y + kMcCorner[i][1], cz = z + kMcCorner[i][2];
+                    pos[i] = v3_(g->minX + cx * vx, g->minY + cy * vx, g->minZ + cz * vx);
+                    int oob = cx < 0 || cy < 0 || cz < 0 || cx >= g->dimX || cy >= g->dimY || cz >= g->dimZ;
+                    val[i] = (!oob && g->data[(size_t)cx + (size_t)cy * g->dimX + (size_t)cz * ((size_t)g->dimX * g->dimY)] == 1) ? -1.0f : 1.0f;
+                    if (val[i] < 0) cube |= 1 << i;
+                }
+                const char* edges = kMcCaseEdges[cube];
+                if (edges[0] == 'f') continue;
+                v3 vert[12];
+                for (const char* e = edges; *e != 'f'; e++) {
+                    int id = hexval(*e), a = kMcEdge[id][0], b = kMcEdge[id][1];
+                    vert[id] = vertex_interp(0.0f, pos[a], pos[b], val[a], val[b]);
+                }
+                for (const char* e = edges; *e != 'f'; e += 3) {
+                    v3 a = vert[hexval(e[0])], b = vert[hexval(e[1])], c = vert[hexval(e[2])];
+                    v3 nrm = v3_normalize(v3_cross(v3_sub(b, a), v3_sub(c, a)));
+                    float t[18] = { a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, nrm.x, nrm.y, nrm.z, nrm.x, nrm.y, nrm.z, nrm.x, nrm.y, nrm.z };
+                    fvec_push(out, t, (size_t)stride);
+                }
+            }
+}
+
+int64_t orc_local_mc(const orc_grid* g, int x0, int y0, int z0, int size, float** out18) {
+    fvec v = { NULL, 0, 0 };
+    local_mc_append(g, x0, y0, z0, size, &v, 18);
+    if (!v.p) v.p = (float*)malloc(4);
+    *out18 = v.p;
+    return (int64_t)(v.n / 18);
+}
+
+int64_t orc_build_leaf_triangles(const orc_grid* g, const orc_node* nodes, int64_t n, float** tris, int32_t** triOffset) {
+    fvec v = { NULL, 0, 0 };
+    int32_t* off = (int32_t*)malloc((size_t)(n + 1) * sizeof(int32_t));
+    for (int64_t i = 0; i < n; i++) {
+        off[i] = (int32_t)(v.n / 12);
+        if (nodes[i].isLeaf == 1) local_mc_append(g, nodes[i].x, nodes[i].y, nodes[i].z, nodes[i].size, &v, 12);
+    }
+    off[n] = (int32_t)(v.n / 12);
+    if (!v.p) v.p = (float*)malloc(4);
+    *tris = v.p; *triOffset = off;
+    return (int64_t)(v.n / 12);
+}
+
+/* Moeller-Trumbore, fixed operation order (the HIP kernel mirrors it) */
+static inline int ray_triangle(v3 ro, v3 rd, const float* T, float* tOut) {
+    v3 v0 = v3_(T[0], T[1], T[2]), v1 = v3_(T[3], T[4], T[5]), v2 = v3_(T[6], T[7], T[8]);
+    v3 e1 = v3_sub(v1, v0), e2 = v3_sub(v2, v0);
+    v3 p = v3_cross(rd, e2);
+    float det = v3_dot(e1, p);
+    if (fabsf(det) < 1e-12f) return 0;
+    float invDet = 1.0f / det;
+    v3 tv = v3_sub(ro, v0);
+    float u = v3_dot(tv, p) * invDet;
+    if (u < 0.0f || u > 1.0f) return 0;
+    v3 q = v3_cross(tv, e1);
+    float v = v3_dot(rd, q) * invDet;
+    if (v < 0.0f || u + v > 1.0f) return 0;
+    float t = v3_dot(e2, q) * invDet;
+    if (!(t > 0.0f)) return 0;
+    *tOut = t;
+    return 1;
+}
+
+typedef struct { int hit; int steps; float t; v3 normal; } tri_result;
+
+static inline tri_result trace_triangles(const orc_node* nodes, const float* tris, const int32_t* triOffset,
+                                         const frame_consts* fc, v3 ro, v3 rd) {
+    tri_result r; r.hit = 0; r.steps = 0; r.t = 1e30f; r.normal = v3_(0, 0, 0);
+    float closestT = 1e30f;
+    int stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    int traversalSteps = 0;
+    v3 gmn = v3_(fc->gridMin[0], fc->gridMin[1], fc->gridMin[2]);
+    float vs = fc->voxelSize;
+    while (sp > 0 && traversalSteps < MAX_TRAVERSAL_STEPS) {
+        sp--;
+        int nodeIdx = stack[sp];
+        if (nodeIdx < 0) continue;
+        traversalSteps++;
+        const orc_node* node = &nodes[nodeIdx];
+        v3 nodeMin = v3_(gmn.x + (float)node->x * vs, gmn.y + (float)node->y * vs, gmn.z + (float)node->z * vs);
+        float ext = (float)node->size * vs;
+        v3 nodeMax = v3_(nodeMin.x + ext, nodeMin.y + ext, nodeMin.z + ext);
+        float tNear, tFar;
+        if (!intersect_aabb(ro, rd, nodeMin, nodeMax, &tNear, &tFar)) continue;
+        if (tNear >= closestT) continue;
+        if (node->isUniform == 1 || node->isLeaf == 1) {
+            float bestT = closestT; int best = -1;
+            for (int k = triOffset[nodeIdx]; k < triOffset[nodeIdx + 1]; k++) {
+                float t;
+                if (ray_triangle(ro, rd, tris + (size_t)k * 12, &t) && t < bestT) { bestT = t; best = k; }
+            }
+            if (best >= 0) {
+                r.hit = 1; r.t = bestT;
+                r.normal = v3_(tris[(size_t)best * 12 + 9], tris[(size_t)best * 12 + 10], tris[(size_t)best * 12 + 11]);
+                break;
+            }
+            continue;
+        }
+        for (int i = 0; i < 8; i++) {
+            int childIdx = node->child[i];
+            if (childIdx >= 0) stack[sp++] = childIdx;
+        }
+    }
+    r.steps = traversalSteps;
+    return r;
+}
+
+void orc_render_triangles(const orc_node* nodes, int64_t n, const float* tris, const int32_t* triOffset,
+                          const float gridMin[3], float voxelSize, const float view[16], const float camPos[3],
+                          float aspect, float fovDeg, int W, int H, int shadow, float* out, orc_stats* stats, int nthreads) {
+    (void)n;
+    frame_consts fc;
+    frame_setup(&fc, gridMin, voxelSize, view, camPos, aspect, fovDeg, W, H);
+    v3 ro = v3_(camPos[0], camPos[1], camPos[2]);
+    v3 l = v3_normalize(v3_(-1.0f, -1.0f, -1.0f));
+    v3 nl = v3_(-l.x, -l.y, -l.z);
+    float bias = voxelSize * 1e-3f;
+    uint64_t pops = 0, hits = 0, capped = 0;
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+:pops,hits,capped)
+#endif
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            v3 rd;
+            generate_ray(&fc, px, py, &rd);
+            tri_result tr = trace_triangles(nodes, tris, triOffset, &fc, ro, rd);
+            float* o = out + ((size_t)py * W + px) * 4;
+            pops += (uint64_t)tr.steps;
+            if (!tr.hit) { o[0] = o[1] = o[2] = 0.0f; o[3] = 1.0f; capped += (uint64_t)(tr.steps >= MAX_TRAVERSAL_STEPS); continue; }
+            hits++;
+            v3 nrm = tr.normal;
+            if (v3_dot(nrm, rd) > 0.0f) nrm = v3_(-nrm.x, -nrm.y, -nrm.z);
+            float ndotl = gmax(0.0f, v3_dot(nrm, nl));
+            if (shadow) {
+                v3 p = v3_(ro.x + rd.x * tr.t, ro.y + rd.y * tr.t, ro.z + rd.z * tr.t);
+                v3 so = v3_(p.x + nrm.x * bias, p.y + nrm.y * bias, p.z + nrm.z * bias);
+                tri_result sh = trace_triangles(nodes, tris, triOffset, &fc, so, nl);
+                pops += (uint64_t)sh.steps;
+                if (sh.hit) ndotl = 0.0f;
+            }
+            o[0] = 1.0f * ndotl + 0.1f; o[1] = 0.8f * ndotl + 0.1f; o[2] = 0.6f * ndotl + 0.1f; o[3] = 1.0f;
+        }
+    if (stats) { stats->rays = (uint64_t)W * H; stats->pops = pops; stats->hits = hits; stats->capped = capped; stats->internal = 0; stats->max_stack = 0; stats->pad = 0; }
+}

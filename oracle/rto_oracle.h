@@ -110,6 +110,27 @@ void orc_render_steps(const orc_node* nodes, int64_t n, const float gridMin[3], 
 float orc_octree_ray_skip(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
                           const float ro[3], const float rd[3], float tMin, float tMax);
 
+/* ---- N2: leaf triangles + shadow ray (BASELINE config 5) -------------------------------------------
+ * localMC is a restatement of S/OctreeVoxel.cpp:780-879 and IS pinned by the reference's own triangles
+ * (tests/golden/ref_localmc_sphere16.npz, ref_mc_cases.npz).  The renderer below has NO reference counterpart
+ * (no ray/triangle code exists upstream): it is this project's definition of config 5 --
+ * "parity unpinned".  Semantics:
+ *   - triangle buffer: for every node i in flat (BFS) order that is a leaf, the triangles
+ *     localMC(grid, x, y, z, size) (what MarchingCubesRenderer::render emits per leaf, S/Renderer.cpp:14-36);
+ *     12 floats per triangle (v0, v1, v2, face normal); triOffset[i]..triOffset[i+1] is node i's range.
+ *   - traversal: exactly intersectOctreeIterative (same LIFO order, 512-pop cap), except that a popped leaf
+ *     (solid or not) that passes the slab test is tested against its triangles (Moeller-Trumbore, t > 0, nearest
+ *     within the leaf); the first leaf in pop order with a triangle hit ends the traversal.
+ *   - shading: n = face normal, flipped to face the ray; c = (1,.8,.6)*max(0, dot(n, -L)) + 0.1 with the
+ *     reference's light L = normalize(-1,-1,-1); if `shadow`, one ray from p + n*1e-3*voxelSize towards -L
+ *     through the same traversal: any triangle hit drops the diffuse term (c = 0.1). Miss: (0,0,0,1). */
+int64_t orc_local_mc(const orc_grid* g, int x0, int y0, int z0, int size, float** out18);   /* 18 floats/tri as the reference's MCTriangle */
+/* Returns the triangle count; *tris (12 floats each) and *triOffset (n+1 ints) are malloc'd. */
+int64_t orc_build_leaf_triangles(const orc_grid* g, const orc_node* nodes, int64_t n, float** tris, int32_t** triOffset);
+void orc_render_triangles(const orc_node* nodes, int64_t n, const float* tris, const int32_t* triOffset,
+                          const float gridMin[3], float voxelSize, const float view[16], const float camPos[3],
+                          float aspect, float fovDeg, int W, int H, int shadow, float* out, orc_stats* stats, int nthreads);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

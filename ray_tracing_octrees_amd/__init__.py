@@ -18,12 +18,13 @@ from __future__ import annotations
 from . import hip, host
 from .hip import (KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED, KERNEL_PACKED_V1, KERNEL_PACKED_V2, NODE_DTYPE, Context, Frame, Partition,
                   RtoError, make_frame)
-from .host import (Camera, MarchingCubesRenderer, OctreeNode, RayTracerBVH, VoxelGrid, createOctreeFromVoxelGrid,
+from .host import (Camera, MarchingCubesRenderer, OctreeNode, RayTracerBVH, VoxelGrid, buildLeafTriangles,
+                   createOctreeFromVoxelGrid,
                    freeOctree, getVoxelSafe, loadVoxelGrid, loadVoxelGridPartial, localMC, saveVoxelGrid)
 
 __all__ = [
     "RayTracerBVH", "VoxelGrid", "OctreeNode", "Camera", "createOctreeFromVoxelGrid", "freeOctree",
-    "getVoxelSafe", "loadVoxelGrid", "loadVoxelGridPartial", "saveVoxelGrid", "localMC", "MarchingCubesRenderer",
+    "getVoxelSafe", "loadVoxelGrid", "loadVoxelGridPartial", "saveVoxelGrid", "localMC", "MarchingCubesRenderer", "buildLeafTriangles",
     "Context", "Frame", "Partition", "RtoError", "make_frame", "NODE_DTYPE",
     "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_PACKED", "KERNEL_PACKED_V1", "KERNEL_PACKED_V2", "hip", "host",
 ]

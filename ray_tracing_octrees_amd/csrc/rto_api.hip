@@ -44,6 +44,11 @@ struct rto_context {
     rto_node* d_compact = nullptr;
     int64_t visibleNodes = 0;
 
+    // leaf triangles (config 5 extension)
+    float* d_tris = nullptr;
+    int* d_triOffset = nullptr;
+    int64_t numTris = 0;
+
     // separable ray terms (per column / per row), cached by (W, H, aspect, tanHalfFov)
     float* d_rayX = nullptr;
     float* d_rayY = nullptr;
@@ -85,6 +90,9 @@ static void free_octree(rto_context* c) {
     (void)hipFree(c->d_blockCount); c->d_blockCount = nullptr;
     (void)hipFree(c->d_blockBase); c->d_blockBase = nullptr;
     (void)hipFree(c->d_compact); c->d_compact = nullptr;
+    (void)hipFree(c->d_tris); c->d_tris = nullptr;
+    (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
+    c->numTris = 0;
     c->numNodes = c->numInternal = 0;
     c->canonical = false; c->culling = false; c->rootVisible = 1; c->visibleNodes = 0;
 }
@@ -710,6 +718,70 @@ int rto_debug_timeline(rto_context* c, const rto_frame* f, int32_t* host_records
     if (rc != RTO_OK) return rc;
     RTO_HIP(c, hipMemcpyAsync(host_records, c->d_steps, (size_t)tiles * 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     RTO_HIP(c, hipStreamSynchronize(c->stream));
+    return RTO_OK;
+}
+
+int rto_upload_leaf_triangles(rto_context* c, const float* tris, int64_t num_tris, const int32_t* tri_offset) {
+    if (!c) return RTO_E_INVALID;
+    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_upload_leaf_triangles: upload the octree first");
+    if (!tri_offset || num_tris < 0 || (num_tris > 0 && !tris)) return fail(c, RTO_E_INVALID, "rto_upload_leaf_triangles: NULL argument");
+    if (tri_offset[0] != 0 || tri_offset[c->numNodes] != num_tris)
+        return fail(c, RTO_E_INVALID, "rto_upload_leaf_triangles: tri_offset must hold numNodes+1 entries running from 0 to num_tris");
+    for (int64_t i = 0; i < c->numNodes; i++)
+        if (tri_offset[i + 1] < tri_offset[i]) return fail(c, RTO_E_INVALID, "rto_upload_leaf_triangles: tri_offset must be non-decreasing");
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_tris); c->d_tris = nullptr;
+    (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
+    RTO_HIP(c, hipMalloc(&c->d_tris, (size_t)(num_tris ? num_tris : 1) * 12 * sizeof(float)));
+    RTO_HIP(c, hipMalloc(&c->d_triOffset, (size_t)(c->numNodes + 1) * sizeof(int)));
+    if (num_tris) RTO_HIP(c, hipMemcpy(c->d_tris, tris, (size_t)num_tris * 12 * sizeof(float), hipMemcpyHostToDevice));
+    RTO_HIP(c, hipMemcpy(c->d_triOffset, tri_offset, (size_t)(c->numNodes + 1) * sizeof(int), hipMemcpyHostToDevice));
+    c->numTris = num_tris;
+    return RTO_OK;
+}
+
+static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partition* p, int shadow, float4* d_out, hipStream_t s,
+                            bool count) {
+    if (!c->d_triOffset) return fail(c, RTO_E_NO_OCTREE, "render_triangles: no leaf triangles uploaded");
+    if (c->culling) return fail(c, RTO_E_UNSUPPORTED, "render_triangles: not available while frustum culling is active");
+    RenderParams P;
+    int rc = fill_params(c, f, p, P);
+    if (rc != RTO_OK) return rc;
+    const int tiles = P.tilesX * P.tilesY;
+    if (tiles <= 0) return RTO_OK;
+    const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
+    TriScene S{ c->d_nodes, c->d_tris, c->d_triOffset };
+    RTO_HIP(c, hipEventRecord(c->ev0, s));
+    if (count) hipLaunchKernelGGL(k_trace_triangles<kModeSteps>, dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
+    else hipLaunchKernelGGL(k_trace_triangles<kModeColor>, dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
+    RTO_HIP(c, hipGetLastError());
+    RTO_HIP(c, hipEventRecord(c->ev1, s));
+    c->timed = true;
+    return RTO_OK;
+}
+
+int rto_render_triangles_device(rto_context* c, const rto_frame* f, const rto_partition* p, int shadow, void* d_out, void* hip_stream) {
+    if (!c) return RTO_E_INVALID;
+    if (!d_out) return fail(c, RTO_E_INVALID, "rto_render_triangles_device: d_out is NULL");
+    RTO_HIP(c, hipSetDevice(c->device));
+    return launch_triangles(c, f, p, shadow, (float4*)d_out, (hipStream_t)hip_stream, false);
+}
+
+int rto_render_triangles_host(rto_context* c, const rto_frame* f, int shadow, float* host_rgba, rto_stats* stats) {
+    if (!c) return RTO_E_INVALID;
+    if (!host_rgba || !f) return fail(c, RTO_E_INVALID, "rto_render_triangles_host: NULL argument");
+    RTO_HIP(c, hipSetDevice(c->device));
+    const size_t pixels = (size_t)f->width * f->height;
+    int rc = ensure_frame(c, pixels);
+    if (rc != RTO_OK) return rc;
+    if (stats) RTO_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));
+    if ((rc = launch_triangles(c, f, nullptr, shadow, c->d_frame, c->stream, stats != nullptr)) != RTO_OK) return rc;
+    Counters h{ 0, 0, 0 };
+    if (stats) RTO_HIP(c, hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipMemcpyAsync(host_rgba, c->d_frame, pixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    if (stats) { stats->rays = pixels; stats->pops = h.pops; stats->hits = h.hits; stats->capped = 0; }
     return RTO_OK;
 }
 

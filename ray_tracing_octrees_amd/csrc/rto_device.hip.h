@@ -891,6 +891,127 @@ __global__ __launch_bounds__(kBlock) void k_desc_visall(int64_t nInternal, uint2
     if (d < nInternal) desc[d].x |= 0xff0000u;
 }
 
+// ================================================================ N2: leaf triangles + shadow ray (config 5)
+// No upstream counterpart (the reference has no ray/triangle code): semantics are this project's, fixed in
+// include/rto_hip.h and DESIGN.md ("parity unpinned").  Traversal = S/RT:239-327 unchanged (LIFO order, 512-pop cap), but a
+// popped leaf that passes the slab test is tested against its Marching-Cubes triangles (Moeller-Trumbore, nearest
+// t > 0 within the leaf); the first leaf in pop order with a triangle hit ends the traversal.  Shading: face
+// normal turned towards the ray, the reference's Lambert term, one shadow ray towards the light.
+struct TriScene {
+    const rto_node* nodes;
+    const float* tris;          // 12 floats per triangle: v0, v1, v2, face normal
+    const int* triOffset;       // numNodes + 1
+};
+
+__device__ __forceinline__ bool ray_triangle(float ox, float oy, float oz, float dx, float dy, float dz,
+                                             const float* __restrict__ T, float& tOut) {
+    const float v0x = T[0], v0y = T[1], v0z = T[2];
+    const float e1x = T[3] - v0x, e1y = T[4] - v0y, e1z = T[5] - v0z;
+    const float e2x = T[6] - v0x, e2y = T[7] - v0y, e2z = T[8] - v0z;
+    // p = cross(rd, e2)  (glm cross: x.y*y.z - y.y*x.z, ...)
+    const float px = dy * e2z - e2y * dz, py = dz * e2x - e2z * dx, pz = dx * e2y - e2x * dy;
+    const float det = e1x * px + e1y * py + e1z * pz;
+    if (__builtin_fabsf(det) < 1e-12f) return false;
+    const float invDet = 1.0f / det;
+    const float tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+    const float u = (tx * px + ty * py + tz * pz) * invDet;
+    if (u < 0.0f || u > 1.0f) return false;
+    const float qx = ty * e1z - e1y * tz, qy = tz * e1x - e1z * tx, qz = tx * e1y - e1x * ty;
+    const float v = (dx * qx + dy * qy + dz * qz) * invDet;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float t = (e2x * qx + e2y * qy + e2z * qz) * invDet;
+    if (!(t > 0.0f)) return false;
+    tOut = t;
+    return true;
+}
+
+struct TriHit { bool hit; int steps; float t; float nx, ny, nz; };
+
+__device__ __forceinline__ TriHit trace_triangles(const RenderParams& P, const TriScene& S, const Ray& r) {
+    TriHit h; h.hit = false; h.steps = 0; h.t = 1e30f; h.nx = h.ny = h.nz = 0.f;
+    int stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    const float closestT = 1e30f;
+    while (sp > 0 && h.steps < kMaxTraversalSteps) {
+        sp--;
+        const int nodeIdx = stack[sp];
+        if (nodeIdx < 0) continue;
+        h.steps++;
+        const rto_node nd = S.nodes[nodeIdx];
+        float tNear, tFar, a0, a1, a2, a3, a4, a5;
+        if (!slab_exact(P, r, nd.x, nd.y, nd.z, nd.size, tNear, tFar, a0, a1, a2, a3, a4, a5)) continue;
+        if (tNear >= closestT) continue;
+        if (nd.isUniform == 1 || nd.isLeaf == 1) {
+            float bestT = closestT;
+            int best = -1;
+            const int k1 = S.triOffset[nodeIdx + 1];
+            for (int k = S.triOffset[nodeIdx]; k < k1; k++) {
+                float t;
+                if (ray_triangle(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, S.tris + (size_t)k * 12, t) && t < bestT) { bestT = t; best = k; }
+            }
+            if (best >= 0) {
+                h.hit = true; h.t = bestT;
+                h.nx = S.tris[(size_t)best * 12 + 9]; h.ny = S.tris[(size_t)best * 12 + 10]; h.nz = S.tris[(size_t)best * 12 + 11];
+                break;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int c = nd.child[i];
+            if (c >= 0) stack[sp++] = c;
+        }
+    }
+    return h;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_trace_triangles(RenderParams P, TriScene S, int shadow, float4* __restrict__ out,
+                                                             Counters* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+    const int px = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    const bool inImage = valid && (py < P.H);
+    float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+    int steps = 0;
+    bool hit = false;
+    if (inImage) {
+        const Ray r = generate_ray_tab(P, px, py);
+        const TriHit h = trace_triangles(P, S, r);
+        steps = h.steps;
+        hit = h.hit;
+        if (h.hit) {
+            float nx = h.nx, ny = h.ny, nz = h.nz;
+            if (nx * r.dx + ny * r.dy + nz * r.dz > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+            float ndotl = gmax(0.0f, nx * P.lightNeg[0] + ny * P.lightNeg[1] + nz * P.lightNeg[2]);
+            if (shadow) {
+                const float bias = P.voxelSize * 1e-3f;
+                const float hx = r.ox + r.dx * h.t, hy = r.oy + r.dy * h.t, hz = r.oz + r.dz * h.t;
+                Ray s;
+                s.ox = hx + nx * bias; s.oy = hy + ny * bias; s.oz = hz + nz * bias;
+                s.dx = P.lightNeg[0]; s.dy = P.lightNeg[1]; s.dz = P.lightNeg[2];
+                s.ix = 1.0f / s.dx; s.iy = 1.0f / s.dy; s.iz = 1.0f / s.dz;
+                const TriHit sh = trace_triangles(P, S, s);
+                steps += sh.steps;
+                if (sh.hit) ndotl = 0.0f;
+            }
+            color = make_float4(1.0f * ndotl + 0.1f, 0.8f * ndotl + 0.1f, 0.6f * ndotl + 0.1f, 1.0f);
+        }
+    }
+    if (valid) out[(size_t)ly * P.W + px] = color;
+    if (MODE == kModeSteps) {
+        // counters: pops = steps of the primary + shadow traversals; capped = primary misses that ran into the cap
+        unsigned long long pops = inImage ? (unsigned long long)steps : 0ull, hits = (inImage && hit) ? 1ull : 0ull;
+        for (int off = 32; off > 0; off >>= 1) { pops += __shfl_down(pops, off); hits += __shfl_down(hits, off); }
+        if (lane == 0) { atomicAdd(&counters->pops, pops); atomicAdd(&counters->hits, hits); }
+    }
+}
+
 // ================================================================ N1: octreeRaySkip
 // Iterative form of the reference's recursive octreeRaySkip (453-skeleton/VolumeRaycastRenderer.cpp:50-155, "S/VR"):
 // children are tried in order of increasing Hamming distance from the octant of the ray's positive

@@ -28,6 +28,7 @@ SYMBOLS = (
     "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel",
     "rto_update_frustum", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
+    "rto_upload_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_last_kernel_ms", "rto_stream", "rto_synchronize",
 )
 
@@ -100,6 +101,9 @@ def load():
     L.rto_partition_rows.argtypes = [C.POINTER(Frame), C.POINTER(Partition)]
     L.rto_assemble_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp, vp]
     L.rto_frame_stats.argtypes = [vp, C.POINTER(Frame), C.POINTER(Stats)]
+    L.rto_upload_leaf_triangles.argtypes = [vp, vp, C.c_int64, vp]
+    L.rto_render_triangles_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), C.c_int, vp, vp]
+    L.rto_render_triangles_host.argtypes = [vp, C.POINTER(Frame), C.c_int, vp, C.POINTER(Stats)]
     L.rto_octree_ray_skip.argtypes = [vp, C.POINTER(C.c_float), vp, C.c_int64, C.c_float, C.c_float, C.c_int, vp]
     L.rto_render_steps_host.argtypes = [vp, C.POINTER(Frame), vp]
     L.rto_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -223,6 +227,24 @@ class Context:
 
     def partition_rows(self, frame: Frame, part: Partition | None) -> int:
         return self._L.rto_partition_rows(C.byref(frame), C.byref(part) if part else None)
+
+    def upload_leaf_triangles(self, tris: np.ndarray, tri_offset: np.ndarray):
+        """Config 5: tris (n, 12) float32 = v0, v1, v2, face normal; tri_offset (numNodes+1,) int32."""
+        tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 12)
+        off = np.ascontiguousarray(tri_offset, dtype=np.int32)
+        self._keep_tris = (tris, off)
+        self._check(self._L.rto_upload_leaf_triangles(self._h, tris.ctypes.data if len(tris) else None, len(tris), off.ctypes.data))
+
+    def render_triangles_host(self, frame: Frame, shadow: bool = True, stats: bool = False):
+        out = np.empty((frame.height, frame.width, 4), np.float32)
+        s = Stats()
+        self._check(self._L.rto_render_triangles_host(self._h, C.byref(frame), 1 if shadow else 0, out.ctypes.data,
+                                                      C.byref(s) if stats else None))
+        return (out, {"rays": s.rays, "pops": s.pops, "hits": s.hits}) if stats else out
+
+    def render_triangles_device(self, frame: Frame, d_out: int, shadow: bool = True, part: Partition | None = None, stream: int = 0):
+        self._check(self._L.rto_render_triangles_device(self._h, C.byref(frame), C.byref(part) if part else None,
+                                                        1 if shadow else 0, C.c_void_p(d_out), C.c_void_p(stream) if stream else None))
 
     def octree_ray_skip(self, ro, rd, t_min=0.0, t_max=1e30, use_visibility=False) -> np.ndarray:
         """octreeRaySkip (VolumeRaycastRenderer.cpp:50-155) for n rays sharing the origin ro; rd: (n, 3)."""

@@ -62,6 +62,8 @@ def load():
     L.rtoh_local_mc.restype = C.c_int64
     L.rtoh_mc_renderer.argtypes = [_vp, _vp, _vp, C.c_int64]
     L.rtoh_mc_renderer.restype = C.c_int64
+    L.rtoh_build_leaf_triangles.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp]
+    L.rtoh_build_leaf_triangles.restype = C.c_int64
     L.rtoh_camera_new.argtypes = [C.c_float, C.c_float, C.c_float]
     L.rtoh_camera_new.restype = _vp
     L.rtoh_camera_free.argtypes = [_vp]
@@ -97,6 +99,10 @@ def load():
     L.rtoh_rt_render_scene_compute.restype = None
     L.rtoh_rt_render_scene_compute_with_culling.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
     L.rtoh_rt_render_scene_compute_with_culling.restype = None
+    L.rtoh_rt_build_leaf_triangles.argtypes = [_vp]
+    L.rtoh_rt_build_leaf_triangles.restype = None
+    L.rtoh_rt_render_scene_triangles.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
+    L.rtoh_rt_render_scene_triangles.restype = None
     L.rtoh_rt_num_nodes.argtypes = [_vp]
     L.rtoh_rt_num_nodes.restype = C.c_int64
     L.rtoh_rt_framebuffer.argtypes = [_vp, _vp, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -205,6 +211,16 @@ def localMC(grid: VoxelGrid, x0: int, y0: int, z0: int, size: int) -> np.ndarray
     if n:
         load().rtoh_local_mc(grid._h, x0, y0, z0, size, out.ctypes.data, n)
     return out
+
+
+def buildLeafTriangles(grid: VoxelGrid, nodes: np.ndarray):
+    """Triangle buffer of the config-5 ray path: (tris (n, 12) float32, triOffset (numNodes+1,) int32)."""
+    nodes = np.ascontiguousarray(nodes)
+    n = load().rtoh_build_leaf_triangles(grid._h, nodes.ctypes.data, len(nodes), None, 0, None)
+    tris = np.zeros((n, 12), np.float32)
+    off = np.zeros(len(nodes) + 1, np.int32)
+    load().rtoh_build_leaf_triangles(grid._h, nodes.ctypes.data, len(nodes), tris.ctypes.data, n, off.ctypes.data)
+    return tris, off
 
 
 class MarchingCubesRenderer:
@@ -321,6 +337,13 @@ class RayTracerBVH:
                                                          1 if updateFrustum else 0)
 
     # -- additions ---------------------------------------------------------
+    def buildLeafTriangles(self):
+        """Config 5: per-leaf Marching-Cubes triangles of the grid given to setOctree(), uploaded to the GPU."""
+        load().rtoh_rt_build_leaf_triangles(self._h)
+
+    def renderSceneTriangles(self, camera: Camera, width: int, height: int, aspect: float, fovDeg: float, shadow: bool = True):
+        load().rtoh_rt_render_scene_triangles(self._h, camera._h, width, height, _f(aspect), _f(fovDeg), 1 if shadow else 0)
+
     def framebuffer(self) -> np.ndarray | None:
         w, h = C.c_int(), C.c_int()
         if not load().rtoh_rt_framebuffer(self._h, None, 0, C.byref(w), C.byref(h)):

@@ -25,8 +25,35 @@ inline int hexval(char c) { return c <= '9' ? c - '0' : c - 'a' + 10; }
 
 }  // namespace
 
+namespace {
+template <class Emit>
+void forEachLocalMCTriangle(const VoxelGrid& grid, int x0, int y0, int z0, int size, Emit emit);
+}
+
 std::vector<MCTriangle> localMC(const VoxelGrid& grid, int x0, int y0, int z0, int size) {
     std::vector<MCTriangle> out;
+    forEachLocalMCTriangle(grid, x0, y0, z0, size, [&](const MCTriangle& t) { out.push_back(t); });
+    return out;
+}
+
+void buildLeafTriangles(const VoxelGrid& grid, const GPUNodesView& nodes, std::vector<float>& tris, std::vector<int32_t>& triOffset) {
+    tris.clear();
+    triOffset.assign((size_t)nodes.count + 1, 0);
+    for (int64_t i = 0; i < nodes.count; i++) {
+        triOffset[(size_t)i] = (int32_t)(tris.size() / 12);
+        const int32_t* nd = nodes.data + i * 15;                  // x, y, z, size, isLeaf, ...
+        if (nd[4] != 1) continue;
+        forEachLocalMCTriangle(grid, nd[0], nd[1], nd[2], nd[3], [&](const MCTriangle& t) {
+            for (int v = 0; v < 3; v++) { tris.push_back(t.v[v].x); tris.push_back(t.v[v].y); tris.push_back(t.v[v].z); }
+            tris.push_back(t.normal[0].x); tris.push_back(t.normal[0].y); tris.push_back(t.normal[0].z);
+        });
+    }
+    triOffset[(size_t)nodes.count] = (int32_t)(tris.size() / 12);
+}
+
+namespace {
+template <class Emit>
+void forEachLocalMCTriangle(const VoxelGrid& grid, int x0, int y0, int z0, int size, Emit emit) {
     const float vx = grid.voxelSize;
     auto scalar = [&](int x, int y, int z) -> float {
         if (x < 0 || y < 0 || z < 0 || x >= grid.dimX || y >= grid.dimY || z >= grid.dimZ) return 1.0f;
@@ -62,8 +89,8 @@ std::vector<MCTriangle> localMC(const VoxelGrid& grid, int x0, int y0, int z0, i
                     tri.v[2] = vert[hexval(e[2])];
                     const vec3 n = rtmath::normalize(rtmath::cross(tri.v[1] - tri.v[0], tri.v[2] - tri.v[0]));
                     tri.normal[0] = tri.normal[1] = tri.normal[2] = n;
-                    out.push_back(tri);
+                    emit(tri);
                 }
             }
-    return out;
 }
+}  // namespace

@@ -68,6 +68,12 @@ std::vector<OctreeNode*> getNeighbors(OctreeNode* node, const std::unordered_map
 // FILLED -> -1, EMPTY / out of grid -> +1, iso 0), same output order as upstream (OctreeVoxel.cpp:780-879).
 std::vector<MCTriangle> localMC(const VoxelGrid& grid, int x0, int y0, int z0, int size);
 
+// Leaf-triangle buffer of the triangle ray path (config 5; no upstream counterpart): for every node of a flat
+// GPUNodes array (15 int32 each) that is a leaf, its localMC triangles, 12 floats each (v0, v1, v2, face normal),
+// in node order; triOffset[i]..triOffset[i+1] is node i's range (what MarchingCubesRenderer emits per leaf).
+struct GPUNodesView { const int32_t* data; int64_t count; };
+void buildLeafTriangles(const VoxelGrid& grid, const GPUNodesView& nodes, std::vector<float>& tris, std::vector<int32_t>& triOffset);
+
 // Test scene of the reference app (453-skeleton/main.cpp:337-372, 1052-1070, 376-422); these are
 // file-static helpers of main.cpp upstream, exposed here because every benchmark config uses them.
 std::vector<float> generateTestVolume(int dimX, int dimY, int dimZ);

@@ -23,6 +23,8 @@ struct HipApi {
     decltype(&rto_octree_info_get) octree_info = nullptr;
     decltype(&rto_update_frustum) update_frustum = nullptr;
     decltype(&rto_render_host) render_host = nullptr;
+    decltype(&rto_upload_leaf_triangles) upload_leaf_triangles = nullptr;
+    decltype(&rto_render_triangles_host) render_triangles_host = nullptr;
     std::string error;
 
     bool load() {
@@ -57,6 +59,8 @@ struct HipApi {
         octree_info = reinterpret_cast<decltype(octree_info)>(sym("rto_octree_info_get"));
         update_frustum = reinterpret_cast<decltype(update_frustum)>(sym("rto_update_frustum"));
         render_host = reinterpret_cast<decltype(render_host)>(sym("rto_render_host"));
+        upload_leaf_triangles = reinterpret_cast<decltype(upload_leaf_triangles)>(sym("rto_upload_leaf_triangles"));
+        render_triangles_host = reinterpret_cast<decltype(render_triangles_host)>(sym("rto_render_triangles_host"));
         if (!ok) { dlclose(handle); handle = nullptr; }
         return ok;
     }
@@ -187,6 +191,44 @@ bool RayTracerBVH::render(const Camera& camera, int width, int height, float asp
     }
     return true;
 }
+
+#ifndef RTO_REFERENCE_HEADERS
+void RayTracerBVH::buildLeafTriangles() {
+    if (!m_computeInited || !m_computeOk) {
+        std::cerr << "[RayTracerBVH] Compute pipeline not initialized or failed.\n";
+        return;
+    }
+    if (m_flatNodes.empty()) return;
+    std::vector<float> tris;
+    std::vector<int32_t> off;
+    ::buildLeafTriangles(m_grid, GPUNodesView{ reinterpret_cast<const int32_t*>(m_flatNodes.data()), (int64_t)m_flatNodes.size() }, tris, off);
+    if (api().upload_leaf_triangles(m_ctx, tris.data(), (int64_t)(tris.size() / 12), off.data()) != RTO_OK) {
+        m_lastError = api().last_error(m_ctx);
+        std::cerr << "[RayTracerBVH] triangle upload failed: " << m_lastError << std::endl;
+    }
+}
+
+void RayTracerBVH::renderSceneTriangles(const Camera& camera, int width, int height, float aspect, float fovDeg, bool shadow) {
+    if (!m_computeInited || !m_computeOk) {
+        std::cerr << "[RayTracerBVH] Compute pipeline not initialized or failed.\n";
+        return;
+    }
+    if (m_numNodes <= 0 || width <= 0 || height <= 0) return;
+    rto_frame f;
+    const auto view = camera.getView();
+    std::memcpy(f.view, &view[0][0], sizeof f.view);
+    const auto pos = camera.getPos();
+    f.cam_pos[0] = pos.x; f.cam_pos[1] = pos.y; f.cam_pos[2] = pos.z;
+    f.aspect = aspect; f.fov_deg = fovDeg; f.width = width; f.height = height;
+    m_frame.resize(static_cast<size_t>(width) * height * 4);
+    m_frameW = width; m_frameH = height;
+    if (api().render_triangles_host(m_ctx, &f, shadow ? 1 : 0, m_frame.data(), nullptr) != RTO_OK) {
+        m_lastError = api().last_error(m_ctx);
+        std::cerr << "[RayTracerBVH] render failed: " << m_lastError << std::endl;
+        m_frame.clear(); m_frameW = m_frameH = 0;
+    }
+}
+#endif
 
 void RayTracerBVH::renderSceneCompute(const Camera& camera, int width, int height, float aspect, float fovDeg) {
     if (!m_computeInited || !m_computeOk) {

@@ -91,6 +91,19 @@ int64_t rtoh_mc_renderer(const OctreeNode* root, const VoxelGrid* g, float* out,
     return copy_tris(r.render(root, *g, root ? root->x : 0, root ? root->y : 0, root ? root->z : 0, root ? root->size : 0), out, capacityTris);
 }
 
+// leaf-triangle buffer for the triangle ray path: returns the triangle count; call with tris == NULL to size
+int64_t rtoh_build_leaf_triangles(const VoxelGrid* g, const GPUNodes* nodes, int64_t n, float* tris, int64_t capacityTris, int32_t* triOffset) {
+    std::vector<float> t;
+    std::vector<int32_t> off;
+    buildLeafTriangles(*g, GPUNodesView{ reinterpret_cast<const int32_t*>(nodes), n }, t, off);
+    const int64_t count = (int64_t)(t.size() / 12);
+    if (tris && capacityTris >= count && triOffset) {
+        std::memcpy(tris, t.data(), t.size() * sizeof(float));
+        std::memcpy(triOffset, off.data(), off.size() * sizeof(int32_t));
+    }
+    return count;
+}
+
 // ---------------------------------------------------------------- Camera
 Camera* rtoh_camera_new(float theta, float phi, float radius) { return new Camera(theta, phi, radius); }
 void rtoh_camera_free(Camera* c) { delete c; }
@@ -141,6 +154,10 @@ void rtoh_rt_render_scene_compute(RayTracerBVH* rt, const Camera* cam, int w, in
 void rtoh_rt_render_scene_compute_with_culling(RayTracerBVH* rt, const Camera* cam, int w, int h, float aspect,
                                                float fovDeg, int updateFrustum) {
     rt->renderSceneComputeWithCulling(*cam, w, h, aspect, fovDeg, updateFrustum != 0);
+}
+void rtoh_rt_build_leaf_triangles(RayTracerBVH* rt) { rt->buildLeafTriangles(); }
+void rtoh_rt_render_scene_triangles(RayTracerBVH* rt, const Camera* cam, int w, int h, float aspect, float fovDeg, int shadow) {
+    rt->renderSceneTriangles(*cam, w, h, aspect, fovDeg, shadow != 0);
 }
 int64_t rtoh_rt_num_nodes(const RayTracerBVH* rt) { return (int64_t)rt->numNodes(); }
 int rtoh_rt_framebuffer(const RayTracerBVH* rt, float* out, int64_t capacityFloats, int* w, int* h) {

@@ -225,3 +225,14 @@ def test_host_marching_cubes_renderer_covers_every_leaf():
     key = lambda a: a[np.lexsort(a.T[::-1])]
     assert key(tris).tobytes() == key(whole).tobytes()
     rto.freeOctree(root)
+
+
+def test_host_leaf_triangle_buffer_matches_oracle(orc, scenes):
+    for name in ("sphere16", "sphere32", "odd"):
+        s = scenes(name)
+        g = rto.VoxelGrid.from_array(s.grid.data, s.min, s.voxel)
+        tris, off = rto.buildLeafTriangles(g, s.nodes)
+        wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
+        assert off.tobytes() == wo.tobytes() and tris.tobytes() == wt.tobytes(), name
+        assert len(tris) > 0 and off[-1] == len(tris)
+        assert (np.diff(off)[s.nodes["isLeaf"] == 0] == 0).all()      # only leaves own triangles

@@ -486,3 +486,102 @@ def test_gpu_octree_build_512(ctx, orc, scenes):
     assert ctx.download_nodes().tobytes() == s.nodes.tobytes()
     k_ms, up_ms = ctx.last_build_ms()
     assert 0 < k_ms < 1000
+
+
+@pytest.mark.parametrize("scene,W,H,cam", [("sphere32", 160, 120, (0.5, 0.7, 1.8)), ("sphere64", 320, 200, (0.5, 0.7, 1.8)),
+                                           ("sphere64", 200, 200, (-0.6, 3.9, 1.4)), ("odd", 200, 120, (0.4, 0.9, 9.0)),
+                                           ("calgary", 320, 180, (0.6, 0.5, 3500.0))])
+def test_config5_leaf_triangles_and_shadow_ray(ctx, orc, scenes, scene, W, H, cam):
+    """N2 / BASELINE config 5 (extension, own oracle -- the reference has no ray/triangle code): Marching-Cubes
+    leaf triangles (pinned by the reference's localMC) + Moeller-Trumbore + one shadow ray, bit-exact vs the oracle."""
+    s = scenes(scene)
+    upload(ctx, s)
+    g = rto.VoxelGrid.from_array(s.grid.data, s.min, s.voxel)
+    tris, off = rto.buildLeafTriangles(g, s.nodes)          # product builder (C++), equal to the oracle's (CPU test)
+    ctx.upload_leaf_triangles(tris, off)
+    c = orc.Camera(*cam)
+    view, pos = c.get_view(), c.get_pos()
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
+    for shadow in (False, True):
+        want, st = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, view, pos, W / H, 45.0, W, H, shadow=shadow,
+                                        nthreads=min(16, orc.max_threads()))
+        got, gs = ctx.render_triangles_host(f, shadow=shadow, stats=True)
+        assert_bit_exact(got, want, f"{scene} triangles shadow={shadow}")
+        assert (gs["pops"], gs["hits"]) == (st["pops"], st["hits"])
+        assert st["hits"] > 0
+
+
+def test_config5_shadows_exist_and_partitions_agree(ctx, orc, scenes):
+    torch = pytest.importorskip("torch")
+    s = scenes("calgary")
+    upload(ctx, s)
+    g = rto.VoxelGrid.from_array(s.grid.data, s.min, s.voxel)
+    ctx.upload_leaf_triangles(*rto.buildLeafTriangles(g, s.nodes))
+    c = orc.Camera(0.9, 2.4, 2600.0)
+    W, H = 384, 216
+    f = rto.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H)
+    lit = ctx.render_triangles_host(f, shadow=False)
+    shd = ctx.render_triangles_host(f, shadow=True)
+    changed = (lit != shd).any(axis=-1)
+    assert changed.sum() > 50                                   # buildings do cast shadows
+    assert (shd[changed][:, 0] == np.float32(0.1)).all()        # shadowed pixels keep the ambient term only
+    # band partition of the triangle path == whole frame
+    nparts, band = 3, 16
+    rows0 = ctx.partition_rows(f, hip.Partition(nparts, 0, band))
+    gathered = torch.zeros((nparts, rows0, W, 4), dtype=torch.float32, device="cuda")
+    for p in range(nparts):
+        ctx.render_triangles_device(f, gathered[p].data_ptr(), True, hip.Partition(nparts, p, band))
+    frame = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    ctx.assemble_device(f, hip.Partition(nparts, 0, band), gathered.data_ptr(), frame.data_ptr())
+    ctx.synchronize()
+    assert_bit_exact(frame.cpu().numpy(), shd, "triangle path, 3 parts")
+    # error paths
+    fresh = rto.Context(0)
+    fresh.upload_octree(scenes("sphere16").nodes, scenes("sphere16").min, scenes("sphere16").voxel)
+    with pytest.raises(rto.RtoError) as e:
+        fresh.render_triangles_host(rto.make_frame(c.get_view(), c.get_pos(), 1.0, 45.0, 16, 16))
+    assert e.value.code == hip.RTO_E_NO_OCTREE
+    with pytest.raises(rto.RtoError) as e:
+        fresh.upload_leaf_triangles(np.zeros((3, 12), np.float32), np.zeros(5, np.int32))
+    assert e.value.code == hip.RTO_E_INVALID
+    fresh.close()
+
+
+def test_config5_full_size_512_4k_triangles_shadow(ctx, orc, scenes, camera):
+    """BASELINE config 5 at full size on one GPU: 512^3 sphere, 3840x2160, MC leaf triangles + 1 shadow ray per hit."""
+    import time
+
+    s = scenes("sphere512")
+    view, pos = camera("sphere")
+    W, H = 3840, 2160
+    upload(ctx, s)
+    wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
+    assert len(wt) > 1_000_000
+    ctx.upload_leaf_triangles(wt, wo)
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, st = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, view, pos, W / H, 45.0, W, H, shadow=True,
+                                    nthreads=min(16, orc.max_threads()))
+    t = time.perf_counter()
+    got, gs = ctx.render_triangles_host(f, shadow=True, stats=True)
+    assert_bit_exact(got, want, "config 5 full size")
+    assert (gs["pops"], gs["hits"]) == (st["pops"], st["hits"])
+    print(f"config5 4K triangles+shadow: {st['hits']} hits, {len(wt)} triangles, kernel {ctx.last_kernel_ms():.3f} ms")
+
+
+def test_cpp_dropin_class_triangle_path(orc, scenes):
+    W, H = 256, 160
+    g = rto.VoxelGrid.test_sphere(32)
+    root = rto.createOctreeFromVoxelGrid(g)
+    rt = rto.RayTracerBVH()
+    rt.ensureComputeInitialized()
+    rt.setOctree(root, g)
+    rt.buildLeafTriangles()
+    cam = rto.Camera(0.5, 0.7, 1.8)
+    rt.renderSceneTriangles(cam, W, H, W / H, 45.0, True)
+    s = scenes("sphere32")
+    oc = orc.Camera(0.5, 0.7, 1.8)
+    wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
+    want, _ = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, oc.get_view(), oc.get_pos(), W / H, 45.0, W, H, shadow=True)
+    assert_bit_exact(rt.framebuffer(), want, "C++ class, triangle path")
+    rto.freeOctree(root)
