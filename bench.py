@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--band-rows", type=int, default=16)
     ap.add_argument("--kernel", choices=["auto", "packed", "generic"], default="auto")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--order", choices=["temporal", "centre-out"], default="temporal",
+                    help="tile launch order of the packed kernel (scheduling only; pixels are identical)")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="N=1 only: render consecutive frames on this many HIP streams (own framebuffers) so that the "
                          "deep-ray tail of one frame overlaps the start of the next; 1 = strictly one frame at a time")
@@ -128,6 +130,7 @@ def main():
     ctx = rto.Context(local_rank)
     ctx.upload_octree(nodes, grid.min, grid.voxelSize)
     ctx.set_kernel({"auto": rto.KERNEL_AUTO, "packed": rto.KERNEL_PACKED, "generic": rto.KERNEL_GENERIC}[args.kernel])
+    ctx.set_launch_order(1 if args.order == "temporal" else 0)
     info = ctx.info()
     renderer = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows)
 
@@ -145,7 +148,6 @@ def main():
     sync_all()
 
     # ---- timed region: exactly K frames ------------------------------------------------------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fif = max(1, args.frames_in_flight) if world == 1 else 1
     if fif > 1:
         streams = [torch.cuda.Stream() for _ in range(fif)]
@@ -153,18 +155,14 @@ def main():
         for i in range(fif):
             ctx.render_device(frame, bufs[i].data_ptr(), None, streams[i].cuda_stream)
         sync_all()
+    ctx.timing_begin(args.steps)      # HIP event pair around every traversal kernel, on its launch stream, no syncs
+    sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
         if fif > 1:
             s_ = streams[k % fif]
-            ev[k][0].record(s_)
             ctx.render_device(frame, bufs[k % fif].data_ptr(), None, s_.cuda_stream)
-            ev[k][1].record(s_)
             img = bufs[k % fif]
-        elif world == 1:
-            ev[k][0].record(stream)          # HIP events on the launch stream: the kernel's own duration
-            img = renderer.render(frame)
-            ev[k][1].record(stream)
         else:
             img = renderer.render(frame)
     sync_all()
@@ -183,7 +181,8 @@ def main():
         bytes_per_ray = pops_per_ray * NODE_BYTES + PIXEL_BYTES
         roofline = None
         if world == 1:
-            kms = sorted(a.elapsed_time(b) for a, b in ev)
+            kms = sorted(float(x) for x in ctx.timing_read())
+            assert len(kms) == args.steps
             k_avg = sum(kms) / len(kms)
             # cost of an event pair with nothing between (reported, not subtracted): rocprofv3's kernel
             # duration is ~ k_avg minus this
@@ -204,6 +203,7 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": ("k_trace_packed3" if args.kernel in ("auto", "packed") else "k_trace_packed") if (info.canonical and args.kernel != "generic") else "k_trace_generic",
+                "launch_order": "temporal (tiles sorted by the previous frame's trip counts; k_sort_scatter follows each frame)" if args.order == "temporal" else "centre-out",
                 "kernel_ms_avg": round(k_avg, 5), "kernel_ms_median": round(kms[len(kms) // 2], 5),
                 "event_pair_overhead_ms": round(pair_overhead, 5),
                 "algorithmic_bytes_per_ray": round(bytes_per_ray, 2), "pops_per_ray": round(pops_per_ray, 4),

@@ -109,6 +109,13 @@ int  rto_download_nodes(rto_context* ctx, rto_node* out, int64_t capacity, int64
 int  rto_last_build_ms(const rto_context* ctx, float* kernels_ms, float* upload_ms);
 int  rto_octree_info_get(const rto_context* ctx, rto_octree_info* out);
 int  rto_set_kernel(rto_context* ctx, int kernel /* RTO_KERNEL_* */);
+/* Launch order of the 8x8-pixel tiles in the packed kernel (a scheduling hint; pixels never depend on it).
+ * The frame ends when its deepest rays end, so the waves that will run longest should start first.
+ * CENTRE_OUT: outwards from the projection of the solid geometry's centre.  TEMPORAL (default): by the per-tile
+ * trip counts the previous frame of the same size recorded (falls back to CENTRE_OUT for the first frame). */
+#define RTO_ORDER_CENTRE_OUT 0
+#define RTO_ORDER_TEMPORAL   1
+int  rto_set_launch_order(rto_context* ctx, int policy);
 
 /* ---- frustum culling ------------------------------------------------------
  * replaces: the CPU loop + compaction + SSBO re-upload of
@@ -172,9 +179,19 @@ int  rto_render_steps_host(rto_context* ctx, const rto_frame* frame, int32_t* ho
  * the tree.  host_records may be NULL to query *num_tiles. */
 int  rto_debug_timeline(rto_context* ctx, const rto_frame* frame, int32_t* host_records, int64_t capacity_tiles,
                         int64_t* num_tiles);
+/* Developer aids for the launch-order study: per-tile trip counts of the last frame, and a caller-supplied
+ * slot -> tile table (NULL restores the automatic one). */
+int  rto_debug_tile_cost(rto_context* ctx, int32_t* host_cost, int64_t capacity, int64_t* count);
+int  rto_debug_set_tile_order(rto_context* ctx, const int32_t* host_order, int64_t n);
 /* Device time in ms of the most recent traversal kernel launched by this context
  * (hipEvent pair on the launch stream; synchronises on that event). */
 int  rto_last_kernel_ms(rto_context* ctx, float* ms);
+/* Per-launch timing without synchronising inside a timed loop: after rto_timing_begin(ctx, n) the next n
+ * traversal-kernel launches are bracketed by their own hipEvent pair on the launch stream (just that kernel: the
+ * launch-order kernel that may follow is outside the pair); rto_timing_read synchronises the device and returns the
+ * durations in ms.  rto_timing_begin(ctx, 0) switches it off. */
+int  rto_timing_begin(rto_context* ctx, int capacity);
+int  rto_timing_read(rto_context* ctx, float* ms, int capacity, int* count);   /* ms may be NULL to query count */
 /* The context's own hipStream_t (used by the synchronous entry points). */
 void* rto_stream(rto_context* ctx);
 /* Waits for all work on the context's device (hipDeviceSynchronize). */

@@ -6,8 +6,10 @@
 
 #include "../host/rtmath.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -44,6 +46,17 @@ struct rto_context {
     rto_node* d_compact = nullptr;
     int64_t visibleNodes = 0;
 
+    // temporal launch order (packed kernel): previous frame's per-tile cost -> this frame's slot->tile table
+    int orderPolicy = 1;            // 0 = centre-out only, 1 = temporal (falls back to centre-out without history)
+    int* d_tileCost = nullptr;
+    int* d_tileOrder = nullptr;
+    int* d_sortHist = nullptr;      // 2 x [sort blocks][64], ping-pong
+    int histPing = 0;
+    int orderTiles = 0;             // tile count the buffers are sized for
+    long orderKey[6] = { 0, 0, 0, 0, 0, 0 };   // W, H, numParts, part, bandRows, tiles of the frame the history belongs to
+    bool orderValid = false;
+    bool orderFixed = false;        // debug: the caller supplied the table, do not rebuild it
+
     // leaf triangles (config 5 extension)
     float* d_tris = nullptr;
     int* d_triOffset = nullptr;
@@ -63,6 +76,10 @@ struct rto_context {
     Counters* d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // optional ring of event pairs, one per traversal-kernel launch (rto_timing_begin / rto_timing_read)
+    std::vector<hipEvent_t> ringStart, ringStop;
+    size_t ringUsed = 0;
+    hipEvent_t lastA = nullptr, lastB = nullptr;
     float buildMs = -1.f;      // device time of the last rto_build_octree (pyramid + emission kernels)
     float buildUploadMs = -1.f;
 };
@@ -93,6 +110,7 @@ static void free_octree(rto_context* c) {
     (void)hipFree(c->d_tris); c->d_tris = nullptr;
     (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
     c->numTris = 0;
+    c->orderValid = false;
     c->numNodes = c->numInternal = 0;
     c->canonical = false; c->culling = false; c->rootVisible = 1; c->visibleNodes = 0;
 }
@@ -141,9 +159,14 @@ void rto_destroy(rto_context* c) {
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_rayX);
     (void)hipFree(c->d_rayY);
+    (void)hipFree(c->d_tileCost);
+    (void)hipFree(c->d_tileOrder);
+    (void)hipFree(c->d_sortHist);
     (void)hipFree(c->d_steps);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_visibleCount);
+    for (hipEvent_t e : c->ringStart) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ringStop) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -414,6 +437,41 @@ int rto_download_nodes(rto_context* c, rto_node* out, int64_t capacity, int64_t*
     return RTO_OK;
 }
 
+int rto_debug_tile_cost(rto_context* c, int32_t* host_cost, int64_t capacity, int64_t* count) {
+    if (!c || !count) return RTO_E_INVALID;
+    *count = c->orderTiles;
+    if (!host_cost) return RTO_OK;
+    if (capacity < c->orderTiles || !c->d_tileCost) return fail(c, RTO_E_INVALID, "rto_debug_tile_cost: nothing recorded / capacity");
+    RTO_HIP(c, hipDeviceSynchronize());
+    RTO_HIP(c, hipMemcpy(host_cost, c->d_tileCost, (size_t)c->orderTiles * sizeof(int), hipMemcpyDeviceToHost));
+    return RTO_OK;
+}
+
+int rto_debug_set_tile_order(rto_context* c, const int32_t* host_order, int64_t n) {
+    if (!c) return RTO_E_INVALID;
+    if (!host_order) {
+        c->orderFixed = false; c->orderValid = false;
+        if (c->d_sortHist) {
+            RTO_HIP(c, hipDeviceSynchronize());
+            RTO_HIP(c, hipMemset(c->d_sortHist, 0, (size_t)((c->orderTiles + kSortBlock - 1) / kSortBlock) * 64 * 2 * sizeof(int)));
+        }
+        return RTO_OK;
+    }
+    if (n != c->orderTiles || !c->d_tileOrder) return fail(c, RTO_E_INVALID, "rto_debug_set_tile_order: render one frame first; n must equal the tile count");
+    RTO_HIP(c, hipDeviceSynchronize());
+    RTO_HIP(c, hipMemcpy(c->d_tileOrder, host_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    c->orderFixed = true; c->orderValid = true;
+    return RTO_OK;
+}
+
+int rto_set_launch_order(rto_context* c, int policy) {
+    if (!c) return RTO_E_INVALID;
+    if (policy != RTO_ORDER_CENTRE_OUT && policy != RTO_ORDER_TEMPORAL) return fail(c, RTO_E_INVALID, "rto_set_launch_order: unknown policy");
+    c->orderPolicy = policy;
+    c->orderValid = false;
+    return RTO_OK;
+}
+
 int rto_octree_info_get(const rto_context* c, rto_octree_info* out) {
     if (!c || !out) return RTO_E_INVALID;
     out->num_nodes = c->numNodes;
@@ -560,6 +618,35 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
         c->rayW = P.W; c->rayH = P.H; c->rayAspect = P.aspect; c->rayTan = P.tanHalfFov;
     }
     P.rayX = c->d_rayX; P.rayY = c->d_rayY;
+    P.tileOrder = nullptr; P.tileCost = nullptr; P.tileHist = nullptr;
+    {   // Conservative pixel rectangle of the root box: rays through pixels outside it miss the root for certain.
+        // Valid only when all 8 corners are strictly in front of the eye (then the box projects onto the convex hull
+        // of its projected corners); computed in double with a 2-pixel margin, far above any float error of the
+        // per-pixel ray directions.  Otherwise: the whole image.
+        P.rootX0 = 0; P.rootY0 = 0; P.rootX1 = P.W - 1; P.rootY1 = P.H - 1;
+        const double ext = (double)c->rootSize * (double)c->voxelSize;
+        const double tanH = (double)P.tanHalfFov, asp = (double)P.aspect;
+        double lox = 1e300, loy = 1e300, hix = -1e300, hiy = -1e300;
+        bool allInFront = tanH > 0.0 && asp > 0.0 && std::isfinite(ext);
+        for (int k = 0; k < 8 && allInFront; k++) {
+            const double wx = (double)c->gridMin[0] + ((k & 1) ? ext : 0.0), wy = (double)c->gridMin[1] + ((k & 2) ? ext : 0.0),
+                         wz = (double)c->gridMin[2] + ((k & 4) ? ext : 0.0);
+            const float* v = f->view;
+            const double vx = v[0] * wx + v[4] * wy + v[8] * wz + v[12], vy = v[1] * wx + v[5] * wy + v[9] * wz + v[13],
+                         vz = v[2] * wx + v[6] * wy + v[10] * wz + v[14];
+            if (!(vz < -1e-6 * (1.0 + std::fabs(vx) + std::fabs(vy)))) { allInFront = false; break; }
+            const double sx = ((vx / -vz) / (asp * tanH) * 0.5 + 0.5) * P.W, sy = (0.5 - (vy / -vz) / tanH * 0.5) * P.H;
+            if (!std::isfinite(sx) || !std::isfinite(sy)) { allInFront = false; break; }
+            lox = std::min(lox, sx); hix = std::max(hix, sx); loy = std::min(loy, sy); hiy = std::max(hiy, sy);
+        }
+        if (allInFront) {
+            const double x0 = std::floor(lox) - 2.0, x1 = std::ceil(hix) + 2.0, y0 = std::floor(loy) - 2.0, y1 = std::ceil(hiy) + 2.0;
+            P.rootX0 = (int)std::max(0.0, std::min(x0, (double)P.W));        // may exceed W-1: then nothing can hit
+            P.rootX1 = (int)std::max(-1.0, std::min(x1, (double)P.W - 1.0));
+            P.rootY0 = (int)std::max(0.0, std::min(y0, (double)P.H));
+            P.rootY1 = (int)std::max(-1.0, std::min(y1, (double)P.H - 1.0));
+        }
+    }
     {   // project the centre of the solid geometry; any value is valid, it only orders the launch
         const rtmath::mat4 V = rtmath::mat4::from(f->view);
         const float wc[3] = { c->gridMin[0] + c->solidCentre[0] * c->voxelSize, c->gridMin[1] + c->solidCentre[1] * c->voxelSize,
@@ -588,15 +675,53 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
     const bool packed = c->kernelMode >= RTO_KERNEL_PACKED || (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
     if (packed && !c->canonical) return fail(c, RTO_E_UNSUPPORTED, "render: packed kernel needs a canonical BFS octree");
-    RTO_HIP(c, hipEventRecord(c->ev0, s));
+    bool stopRecorded = false;
+    hipEvent_t evA = c->ev0, evB = c->ev1;
+    if (c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
+    RTO_HIP(c, hipEventRecord(evA, s));
     if (packed) {
-        const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint2);
+        size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint2);
+        if (const char* pad = std::getenv("RTO_LDS_PAD")) lds += (size_t)std::atoi(pad);   // tuning aid: caps workgroups per CU
         if (c->kernelMode == RTO_KERNEL_PACKED_V1)
             hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
         else if (c->kernelMode == RTO_KERNEL_PACKED_V2)
             hipLaunchKernelGGL(k_trace_packed2<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
-        else
-            hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
+        else {
+            // temporal launch order: this frame consumes the table built from the previous frame of the same geometry
+            RenderParams Q = P;
+            Q.tileOrder = nullptr; Q.tileCost = nullptr; Q.tileHist = nullptr;
+            const long key[6] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles };
+            const bool useOrder = c->orderPolicy == RTO_ORDER_TEMPORAL && MODE == kModeColor &&
+                                  (size_t)((tiles + kSortBlock - 1) / kSortBlock) * 64 * sizeof(int) <= 96 * 1024;   // table must fit LDS
+            if (useOrder) {
+                if (c->orderTiles != tiles) {
+                    (void)hipFree(c->d_tileCost); (void)hipFree(c->d_tileOrder); c->d_tileCost = c->d_tileOrder = nullptr; c->orderTiles = 0;
+                    RTO_HIP(c, hipMalloc(&c->d_tileCost, (size_t)tiles * sizeof(int)));
+                    RTO_HIP(c, hipMalloc(&c->d_tileOrder, (size_t)tiles * sizeof(int)));
+                    (void)hipFree(c->d_sortHist); c->d_sortHist = nullptr;
+                    const size_t histInts = (size_t)((tiles + kSortBlock - 1) / kSortBlock) * 64 * 2;   // ping-pong
+                    RTO_HIP(c, hipMalloc(&c->d_sortHist, histInts * sizeof(int)));
+                    RTO_HIP(c, hipMemsetAsync(c->d_sortHist, 0, histInts * sizeof(int), s));
+                    c->histPing = 0;
+                    c->orderTiles = tiles; c->orderValid = false; c->orderFixed = false;
+                }
+                if (std::memcmp(key, c->orderKey, sizeof key) != 0) { c->orderValid = false; c->orderFixed = false; std::memcpy(c->orderKey, key, sizeof key); }
+                Q.tileOrder = c->orderValid ? c->d_tileOrder : nullptr;
+                Q.tileCost = c->d_tileCost;
+                Q.tileHist = c->d_sortHist + (size_t)c->histPing * ((tiles + kSortBlock - 1) / kSortBlock) * 64;
+            }
+            hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+            RTO_HIP(c, hipEventRecord(evB, s));       // the traversal kernel alone; the order kernel follows
+            stopRecorded = true;
+            if (useOrder && !c->orderFixed) {
+                const int nsb = (tiles + kSortBlock - 1) / kSortBlock;
+                int* cur = c->d_sortHist + (size_t)c->histPing * nsb * 64;
+                int* nxt = c->d_sortHist + (size_t)(1 - c->histPing) * nsb * 64;
+                hipLaunchKernelGGL(k_sort_scatter, dim3(nsb), dim3(kSortBlock), (size_t)nsb * 64 * sizeof(int), s, c->d_tileCost, tiles, cur, nsb, c->d_tileOrder, nxt);
+                c->histPing = 1 - c->histPing;
+                c->orderValid = true;
+            }
+        }
     } else {
         const rto_node* nodes = c->culling ? c->d_compact : c->d_nodes;
         RenderParams Q = P;
@@ -605,7 +730,8 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
         hipLaunchKernelGGL(k_trace_generic<MODE>, dim3(blocks), dim3(kBlock), 0, s, Q, nodes, d_out, c->d_steps, c->d_counters);
     }
     RTO_HIP(c, hipGetLastError());
-    RTO_HIP(c, hipEventRecord(c->ev1, s));
+    if (!stopRecorded) RTO_HIP(c, hipEventRecord(evB, s));
+    if (evA != c->ev0) { c->lastA = evA; c->lastB = evB; } else { c->lastA = c->ev0; c->lastB = c->ev1; }
     c->timed = true;
     return RTO_OK;
 }
@@ -815,8 +941,35 @@ int rto_last_kernel_ms(rto_context* c, float* ms) {
     if (!c || !ms) return RTO_E_INVALID;
     if (!c->timed) return fail(c, RTO_E_INVALID, "rto_last_kernel_ms: no kernel launched yet");
     RTO_HIP(c, hipSetDevice(c->device));
-    RTO_HIP(c, hipEventSynchronize(c->ev1));
-    RTO_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    hipEvent_t a = c->lastA ? c->lastA : c->ev0, b = c->lastB ? c->lastB : c->ev1;
+    RTO_HIP(c, hipEventSynchronize(b));
+    RTO_HIP(c, hipEventElapsedTime(ms, a, b));
+    return RTO_OK;
+}
+
+int rto_timing_begin(rto_context* c, int capacity) {
+    if (!c || capacity < 0) return RTO_E_INVALID;
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipDeviceSynchronize());
+    for (hipEvent_t e : c->ringStart) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ringStop) (void)hipEventDestroy(e);
+    c->ringStart.clear(); c->ringStop.clear(); c->ringUsed = 0; c->lastA = c->lastB = nullptr;
+    for (int i = 0; i < capacity; i++) {
+        hipEvent_t a, b;
+        RTO_HIP(c, hipEventCreate(&a)); c->ringStart.push_back(a);
+        RTO_HIP(c, hipEventCreate(&b)); c->ringStop.push_back(b);
+    }
+    return RTO_OK;
+}
+
+int rto_timing_read(rto_context* c, float* ms, int capacity, int* count) {
+    if (!c || !count) return RTO_E_INVALID;
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipDeviceSynchronize());
+    *count = (int)c->ringUsed;
+    if (!ms) return RTO_OK;
+    if (capacity < (int)c->ringUsed) return fail(c, RTO_E_INVALID, "rto_timing_read: capacity too small");
+    for (size_t i = 0; i < c->ringUsed; i++) RTO_HIP(c, hipEventElapsedTime(&ms[i], c->ringStart[i], c->ringStop[i]));
     return RTO_OK;
 }
 

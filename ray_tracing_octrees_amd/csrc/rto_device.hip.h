@@ -59,6 +59,10 @@ struct RenderParams {
     int tilesX, tilesY;             // 8x8 tiles over W x localRows
     int rootVisible;                // 0 => frustum update culled the root: black frame
     int orderCx, orderCy;           // tile nearest the projected scene centre: tiles launch centre-out (heavy first)
+    int rootX0, rootY0, rootX1, rootY1;   // pixel rectangle (inclusive, GLOBAL rows) outside of which no ray can meet the root box
+    const int* tileOrder;           // launch slot -> tile, costliest tiles of the PREVIOUS frame first (null: centre-out)
+    int* tileCost;                  // tile -> loop trip count of its wave in THIS frame (null: not recorded)
+    int* tileHist;                  // [tile / 1024][64] histogram of min(cost, 63) of THIS frame (zeroed beforehand)
     const float* rayX;              // [W]  ((px+.5)/W*2-1)*aspect*tanHalfFov, the separable part of S/RT:341-346 (host-computed)
     const float* rayY;              // [H]  (1-(py+.5)/H*2)*tanHalfFov
 };
@@ -445,6 +449,8 @@ __device__ __forceinline__ void tile_of(const RenderParams& P, int t, int& tx, i
     tx = unrank_centre_out(colRank, P.orderCx, P.tilesX);
 }
 
+// hipcc does not fold fmax(fmax(a,b),c) into v_max3_f32 when a, b, c are themselves min/max results (it cannot
+// prove them canonical), so the 3-input forms are spelled out; the assembler pads them with a few s_nop.
 __device__ __forceinline__ float max3f(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -457,6 +463,12 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
 }
 
 // Pass mask of the 8 children, fast form (no NaN can occur: see `risky`).
+// The lo/hi child halves of every axis go through the same operations, so they are computed as 2-vectors:
+// hipcc lowers these to v_pk_mul_f32 / v_pk_add_f32, which are IEEE-identical per element (no fusion) and cost a
+// lone wave about as much as a scalar-float VALU op -- the critical path of the frame is exactly such lone deep
+// waves, so halving the instruction count of this block shortens the frame, not just the wave.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ unsigned child_pass_mask_fast(const RenderParams& P, const Ray& r, int cx, int cy, int cz, int half) {
     const float vs = P.voxelSize;
     const float fh = (float)half;
@@ -467,29 +479,28 @@ __device__ __forceinline__ unsigned child_pass_mask_fast(const RenderParams& P, 
     const int c[3] = { cx, cy, cz };
     const float o[3] = { r.ox, r.oy, r.oz };
     const float inv[3] = { r.ix, r.iy, r.iz };
+    const f32x2 addHalf = { 0.0f, fh };
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const float fc = (float)c[a];
-        const float flo = P.gridMin[a] + fc * vs;              // nodeMin of the low children
-        const float fhi = P.gridMin[a] + (fc + fh) * vs;       // fc + fh is exact: both are integers < 2^24
-        const float mlo = flo + sv, mhi = fhi + sv;            // their nodeMax
-        const float t1 = (flo - o[a]) * inv[a], t2 = (mlo - o[a]) * inv[a];
-        const float u1 = (fhi - o[a]) * inv[a], u2 = (mhi - o[a]) * inv[a];
-        tmn[a][0] = __builtin_fminf(t1, t2); tmx[a][0] = __builtin_fmaxf(t1, t2);
-        tmn[a][1] = __builtin_fminf(u1, u2); tmx[a][1] = __builtin_fmaxf(u1, u2);
+        const f32x2 fcc = (f32x2){ fc, fc } + addHalf;        // (fc, fc + fh): both exact (integers < 2^24; fc + 0 == fc)
+        const f32x2 lo = (f32x2){ P.gridMin[a], P.gridMin[a] } + fcc * vs;     // nodeMin of the low / high children
+        const f32x2 hi = lo + sv;                              // their nodeMax
+        const f32x2 t1 = (lo - o[a]) * inv[a];
+        const f32x2 t2 = (hi - o[a]) * inv[a];
+        tmn[a][0] = __builtin_fminf(t1.x, t2.x); tmx[a][0] = __builtin_fmaxf(t1.x, t2.x);
+        tmn[a][1] = __builtin_fminf(t1.y, t2.y); tmx[a][1] = __builtin_fmaxf(t1.y, t2.y);
     }
     // fold "tFar > 0" and "tNear < 1e30" into the x terms
     tmn[0][0] = __builtin_fmaxf(tmn[0][0], kEps); tmn[0][1] = __builtin_fmaxf(tmn[0][1], kEps);
     tmx[0][0] = __builtin_fminf(tmx[0][0], kBelow1e30); tmx[0][1] = __builtin_fminf(tmx[0][1], kBelow1e30);
     // 8 independent verdicts, OR-ed as a tree: a lone deep wave is bound by dependency depth, not op count
-    unsigned b[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const float tn = max3f(tmn[0][k & 1], tmn[1][(k >> 1) & 1], tmn[2][k >> 2]);
-        const float tf = min3f(tmx[0][k & 1], tmx[1][(k >> 1) & 1], tmx[2][k >> 2]);
-        b[k] = (tn <= tf) ? (1u << k) : 0u;
-    }
-    return (b[0] | b[1] | b[2]) | (b[3] | b[4] | b[5]) | (b[6] | b[7]);
+#define RTO_CHILD(k) ((max3f(tmn[0][(k) & 1], tmn[1][((k) >> 1) & 1], tmn[2][(k) >> 2]) <= \
+                       min3f(tmx[0][(k) & 1], tmx[1][((k) >> 1) & 1], tmx[2][(k) >> 2])) ? (1u << (k)) : 0u)
+    const unsigned b0 = RTO_CHILD(0), b1 = RTO_CHILD(1), b2 = RTO_CHILD(2), b3 = RTO_CHILD(3);
+    const unsigned b4 = RTO_CHILD(4), b5 = RTO_CHILD(5), b6 = RTO_CHILD(6), b7 = RTO_CHILD(7);
+#undef RTO_CHILD
+    return (b0 | b1 | b2) | (b3 | b4 | b5) | (b6 | b7);
 }
 
 template <int MODE>
@@ -653,9 +664,16 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed3(RenderParams P, const 
     int tlIters = 0;
     if (MODE == kModeTimeline) tl0 = wall_clock64();
 
-    const int tile = blockIdx.x * (kBlock / kWave) + wave;
+    // Launch order.  The frame ends when its deepest waves end, so they must start first.  With temporal order the
+    // slot -> tile table lists the tiles by their trip count in the previous frame (a scheduling hint only: every
+    // tile is rendered exactly once either way); without history, tiles go centre-out from the projected geometry.
+    const int slot = blockIdx.x * (kBlock / kWave) + wave;
+    int tile = slot;
     int tx = 0, ty = P.tilesY;
-    if (tile < P.tilesX * P.tilesY) tile_of(P, tile, tx, ty);
+    if (slot < P.tilesX * P.tilesY) {
+        if (P.tileOrder) { tile = P.tileOrder[slot]; ty = tile / P.tilesX; tx = tile - ty * P.tilesX; }
+        else { tile_of(P, slot, tx, ty); tile = ty * P.tilesX + tx; }
+    }
     const int px = tx * 8 + (lane & 7);
     const int ly = ty * 8 + (lane >> 3);
     const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
@@ -666,14 +684,21 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed3(RenderParams P, const 
     int steps = 0;
     Ray r;
     bool alive = false;
+    // A pixel outside the (conservative, host-computed) screen rectangle of the root box cannot hit it: the root's
+    // slab test fails for it, the pixel is black after one pop (S/RT:254-270).  Whole tiles out there skip ray setup.
+    const bool outsideRoot = px < P.rootX0 || px > P.rootX1 || py < P.rootY0 || py > P.rootY1;
     if (inImage && P.rootVisible) {
-        r = generate_ray_tab(P, px, py);
-        float tNear, tFar, a0, a1, a2, a3, a4, a5;
         steps = 1;   // the root's own pop
-        alive = slab_exact(P, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+        if (!outsideRoot) {
+            r = generate_ray_tab(P, px, py);
+            float tNear, tFar, a0, a1, a2, a3, a4, a5;
+            alive = slab_exact(P, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+        }
     }
     const bool risky = alive && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
                                   __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
+
+    const bool anyRisky = __builtin_amdgcn_ballot_w64(risky) != 0ull;   // wave-uniform and fixed for the whole traversal
 
     unsigned cur = 0;
     int cx = 0, cy = 0, cz = 0;
@@ -681,8 +706,19 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed3(RenderParams P, const 
     unsigned lvlPending = 0;
     unsigned tailRun = 0;
 
+#if defined(RTO_STAMP)
+    unsigned long long stampSum[5] = { 0, 0, 0, 0, 0 };
+#define RTO_T(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); stampSum[i] += t_ - stampLast; stampLast = t_; } while (0)
+    unsigned long long stampLast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stampLast) :: "memory");
+#else
+#define RTO_T(i) do { } while (0)
+#endif
+    int trips = 0;                                 // wave-uniform (scalar) trip count = this tile's cost
     while (alive) {
+        trips++;
         if (MODE == kModeTimeline) tlIters++;
+        RTO_T(4);                                   // loop overhead / back edge
         // ---- [A] the node `cur` at (cx,cy,cz), level lvl
         const uint2 d = desc[cur];
         // the resume entry depends only on lvlPending: fetch it now, under the descriptor load and the slab math
@@ -698,13 +734,18 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed3(RenderParams P, const 
         passMask = 0xa5u ^ (unsigned)(cx & 0xff);   // timing experiment only: no slab math
         (void)half;
 #else
-        if (__builtin_amdgcn_ballot_w64(risky) != 0ull) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
+        if (anyRisky) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
         else passMask = child_pass_mask_fast(P, r, cx, cy, cz, half);
 #endif
+        RTO_T(0);                                   // slab math (descriptor + LDS loads in flight)
         const unsigned vm0 = __builtin_amdgcn_ubfe(d.x, 16, 8);
         const unsigned im0 = __builtin_amdgcn_ubfe(d.x, 8, 8);
         const unsigned sm = d.x & vm0;                                  // solid & visible
         unsigned cand = ((im0 & vm0) | sm) & passMask;
+#if defined(RTO_STAMP)
+        asm volatile("" :: "v"(cand));
+#endif
+        RTO_T(1);                                   // wait for the descriptor
         const unsigned solidHit = sm & passMask;
         cand &= 0xffffffffu << (31 - __builtin_clz(solidHit | 1u));      // nothing below the first solid hit is reached
         // ---- [B] merge with "resume at the deepest level that still has work"
@@ -714,6 +755,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed3(RenderParams P, const 
         steps = noWork ? stepsB : steps;
         const unsigned W = noWork ? e.x : ((d.x & 0x00ffff00u) | cand | (tailRun << 24));
         const unsigned base = noWork ? e.y : d.y;
+#if defined(RTO_STAMP)
+        asm volatile("" :: "v"(W), "v"(base));
+#endif
+        RTO_T(2);                                   // [B] up to the merged state word (waits for the LDS entry)
         const int lvl2 = noWork ? L : lvl;
         const int bpos = P.depth - 1 - lvl2;                             // log2 of the child edge at lvl2
         const unsigned childIdx = ((cx >> bpos) & 1) | (((cy >> bpos) & 1) << 1) | (((cz >> bpos) & 1) << 2);
@@ -744,8 +789,17 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed3(RenderParams P, const 
         cx |= (j & 1) ? hl : 0; cy |= (j & 2) ? hl : 0; cz |= (j & 4) ? hl : 0;   // the popped child (kept on a hit)
         lvl = lvl2 + 1;
         alive = descend;
+#if defined(RTO_STAMP)
+        asm volatile("" :: "v"(cur), "v"(cx), "v"(lvlPending), "v"(tailRun));
+#endif
+        RTO_T(3);                                   // [C] pop, stack write, next node
     }
     if (!hit && steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
+    if (P.tileCost && lane == 0 && ty < P.tilesY) {
+        P.tileCost[tile] = trips;
+        // zero-cost tiles (most of a typical frame) are not counted: their number follows from the block size
+        if (trips > 0) atomicAdd(&P.tileHist[(tile >> 10) * 64 + (trips < 63 ? trips : 63)], 1);
+    }
 
     if (MODE == kModeColor || MODE == kModeTimeline) {
         if (valid) {
@@ -765,12 +819,75 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed3(RenderParams P, const 
                 rec[0] = (int)(tl0 & 0xffffffffu); rec[1] = (int)(tl0 >> 32);
                 rec[2] = (int)(tl1 & 0xffffffffu); rec[3] = (int)(tl1 >> 32);
                 rec[4] = it; rec[5] = (int)hwid; rec[6] = (int)xcc; rec[7] = act;
+#if defined(RTO_STAMP)
+                rec[0] = (int)stampSum[0]; rec[1] = (int)stampSum[1]; rec[5] = (int)stampSum[2]; rec[6] = (int)stampSum[3]; rec[7] = (int)stampSum[4];
+#endif
             }
         }
     } else {
         if (inImage) stepsOut[(size_t)py * P.W + px] = hit ? steps : -steps;
         wave_accumulate(counters, steps, hit, inImage);
     }
+}
+
+// Counting sort of the tiles by descending cost (64 buckets of min(trips, 63)) -> next frame's launch order.
+// Two small multi-block kernels, no global atomics: (1) each 1024-tile block writes its 64-bucket histogram,
+// built in LDS with wave-aggregated atomics (one LDS atomic per DISTINCT bucket per wave: costs cluster
+// spatially); (2) each block derives its write offsets from the block-histogram table (costlier buckets first,
+// lower blocks first) and scatters.  Runs after the render kernel on the same stream.
+constexpr int kSortBlock = 1024;
+
+__device__ __forceinline__ void wave_bucket_add(int b, int lane, int* counters, int& posOut) {
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(b >= 0);
+    posOut = 0;
+    while (todo) {
+        const int lead = __builtin_ctzll(todo);
+        const int bl = __shfl(b, lead);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(b == bl);
+        int p0 = 0;
+        if (lane == lead) p0 = atomicAdd(&counters[bl], __builtin_popcountll(m));
+        p0 = __shfl(p0, lead);
+        if (b == bl) posOut = p0 + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+    }
+}
+
+__global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const int* __restrict__ tileCost, int tiles, const int* __restrict__ blockHist,
+                                                              int numBlocks, int* __restrict__ order, int* __restrict__ nextHist) {
+    extern __shared__ int tab[];                       // [numBlocks][64] copy of the histogram table
+    __shared__ int base[64], fill[64], total[64];
+    for (int i = threadIdx.x; i < numBlocks * 64; i += kSortBlock) tab[i] = blockHist[i];
+    if (threadIdx.x < 64) nextHist[blockIdx.x * 64 + threadIdx.x] = 0;      // the table the NEXT frame accumulates into
+    __syncthreads();
+    // bucket 0 is implicit: a block's tiles minus the counted ones (zero-cost tiles do no atomics)
+    for (int k = threadIdx.x; k < numBlocks; k += kSortBlock) {
+        int counted = 0;
+        for (int bk = 1; bk < 64; bk++) counted += tab[k * 64 + bk];
+        tab[k * 64] = min(kSortBlock, tiles - k * kSortBlock) - counted;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int before = 0, all = 0;                       // tiles of this bucket in earlier blocks / in all blocks
+        for (int k = 0; k < numBlocks; k++) {
+            const int h = tab[k * 64 + threadIdx.x];
+            all += h;
+            if (k < (int)blockIdx.x) before += h;
+        }
+        total[threadIdx.x] = all;
+        fill[threadIdx.x] = before;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int sum = 0;
+        for (int k = 63; k > (int)threadIdx.x; k--) sum += total[k];   // costlier buckets first
+        base[threadIdx.x] = sum;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * kSortBlock + threadIdx.x;
+    const int bkt = i < tiles ? min(tileCost[i], 63) : -1;
+    int pos;
+    wave_bucket_add(bkt, threadIdx.x & 63, fill, pos);
+    if (bkt >= 0) order[base[bkt] + pos] = i;
 }
 
 // ================================================================ frustum culling (N3)

@@ -25,11 +25,11 @@ NODE_DTYPE = np.dtype(
 # every symbol include/rto_hip.h declares
 SYMBOLS = (
     "rto_create", "rto_destroy", "rto_last_error", "rto_device_name",
-    "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel",
+    "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel", "rto_set_launch_order",
     "rto_update_frustum", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
     "rto_upload_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host",
-    "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_last_kernel_ms", "rto_stream", "rto_synchronize",
+    "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
 )
 
 
@@ -94,6 +94,7 @@ def load():
     L.rto_download_nodes.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.rto_last_build_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rto_set_kernel.argtypes = [vp, C.c_int]
+    L.rto_set_launch_order.argtypes = [vp, C.c_int]
     L.rto_update_frustum.argtypes = [vp, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int]
     L.rto_download_visible_nodes.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.rto_render_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp]
@@ -107,8 +108,12 @@ def load():
     L.rto_octree_ray_skip.argtypes = [vp, C.POINTER(C.c_float), vp, C.c_int64, C.c_float, C.c_float, C.c_int, vp]
     L.rto_render_steps_host.argtypes = [vp, C.POINTER(Frame), vp]
     L.rto_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.rto_debug_tile_cost.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.rto_debug_set_tile_order.argtypes = [vp, vp, C.c_int64]
     L.rto_debug_timeline.argtypes = [vp, C.POINTER(Frame), vp, C.c_int64, C.POINTER(C.c_int64)]
     L.rto_synchronize.argtypes = [vp]
+    L.rto_timing_begin.argtypes = [vp, C.c_int]
+    L.rto_timing_read.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.rto_stream.argtypes = [vp]
     L.rto_stream.restype = vp
     _lib = L
@@ -197,6 +202,10 @@ class Context:
     def set_kernel(self, kernel: int):
         self._check(self._L.rto_set_kernel(self._h, kernel))
 
+    def set_launch_order(self, policy: int):
+        """0 = centre-out, 1 = temporal (previous frame's per-tile cost; default)."""
+        self._check(self._L.rto_set_launch_order(self._h, policy))
+
     # -- culling -----------------------------------------------------------
     def update_frustum(self, view, fov_deg, aspect, enable=True):
         v = np.ascontiguousarray(np.asarray(view, dtype=np.float32).reshape(16))
@@ -273,10 +282,35 @@ class Context:
         self._check(self._L.rto_debug_timeline(self._h, C.byref(frame), out.ctypes.data, n.value, C.byref(n)))
         return out
 
+    def debug_tile_cost(self) -> np.ndarray:
+        n = C.c_int64()
+        self._check(self._L.rto_debug_tile_cost(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.int32)
+        self._check(self._L.rto_debug_tile_cost(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def debug_set_tile_order(self, order):
+        if order is None:
+            self._check(self._L.rto_debug_set_tile_order(self._h, None, 0))
+            return
+        o = np.ascontiguousarray(order, dtype=np.int32)
+        self._check(self._L.rto_debug_set_tile_order(self._h, o.ctypes.data, len(o)))
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         self._check(self._L.rto_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def timing_begin(self, capacity: int):
+        self._check(self._L.rto_timing_begin(self._h, capacity))
+
+    def timing_read(self) -> np.ndarray:
+        n = C.c_int()
+        self._check(self._L.rto_timing_read(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.float32)
+        if n.value:
+            self._check(self._L.rto_timing_read(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
 
     @property
     def stream(self) -> int:

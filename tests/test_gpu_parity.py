@@ -585,3 +585,22 @@ def test_cpp_dropin_class_triangle_path(orc, scenes):
     want, _ = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, oc.get_view(), oc.get_pos(), W / H, 45.0, W, H, shadow=True)
     assert_bit_exact(rt.framebuffer(), want, "C++ class, triangle path")
     rto.freeOctree(root)
+
+
+def test_root_screen_rectangle_never_changes_pixels(ctx, orc, scenes):
+    """The packed kernel skips ray setup for pixels outside a conservative screen rectangle of the root box.
+    Cameras that put the box partly off-screen, behind the eye, around the eye and far away must all stay exact."""
+    s = scenes("sphere32")
+    upload(ctx, s)
+    W, H = 200, 120
+    for (t, p, r, tgt, fov) in ((0.5, 0.7, 1.8, (0, 0, 0), 45.0), (0.5, 0.7, 1.8, (0.8, 0.3, 0.0), 45.0), (0.1, 0.2, 0.9, (0.0, 0.9, 0.0), 70.0),
+                                (0.5, 0.7, 0.3, (0, 0, 0), 45.0), (0.5, 0.7, 6.0, (0, 0, 0), 10.0), (0.5, 0.7, 1.8, (5.0, 5.0, 9.0), 45.0),
+                                (-1.2, 4.0, 0.75, (0.2, -0.1, 0.1), 120.0), (0.5, 0.7, 1.2, (0, 0, 2.0), 45.0)):
+        cam = orc.Camera(t, p, r)
+        cam._c.target[0], cam._c.target[1], cam._c.target[2] = tgt
+        view, pos = cam.get_view(), cam.get_pos()
+        want, st = oracle_frame(orc, s, view, pos, W, H, fov=fov)
+        f = rto.make_frame(view, pos, W / H, fov, W, H)
+        ctx.set_kernel(rto.KERNEL_PACKED)
+        assert_bit_exact(ctx.render_host(f), want, f"root rectangle cam {(t, p, r, tgt, fov)}")
+        np.testing.assert_array_equal(ctx.render_steps(f), orc.render_steps(s.nodes, s.min, s.voxel, view, pos, W / H, fov, W, H))
