@@ -50,7 +50,7 @@ struct rto_context {
     int orderPolicy = 1;            // 0 = centre-out only, 1 = temporal (falls back to centre-out without history)
     int* d_tileCost = nullptr;
     int* d_tileOrder = nullptr;
-    int* d_sortHist = nullptr;      // 2 x [sort blocks][64], ping-pong
+    int* d_sortHist = nullptr;      // 2 x [sort blocks][kCostBuckets], ping-pong
     int histPing = 0;
     int orderTiles = 0;             // tile count the buffers are sized for
     long orderKey[6] = { 0, 0, 0, 0, 0, 0 };   // W, H, numParts, part, bandRows, tiles of the frame the history belongs to
@@ -453,7 +453,7 @@ int rto_debug_set_tile_order(rto_context* c, const int32_t* host_order, int64_t 
         c->orderFixed = false; c->orderValid = false;
         if (c->d_sortHist) {
             RTO_HIP(c, hipDeviceSynchronize());
-            RTO_HIP(c, hipMemset(c->d_sortHist, 0, (size_t)((c->orderTiles + kSortBlock - 1) / kSortBlock) * 64 * 2 * sizeof(int)));
+            RTO_HIP(c, hipMemset(c->d_sortHist, 0, (size_t)((c->orderTiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * 2 * sizeof(int)));
         }
         return RTO_OK;
     }
@@ -692,14 +692,14 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             Q.tileOrder = nullptr; Q.tileCost = nullptr; Q.tileHist = nullptr;
             const long key[6] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles };
             const bool useOrder = c->orderPolicy == RTO_ORDER_TEMPORAL && MODE == kModeColor &&
-                                  (size_t)((tiles + kSortBlock - 1) / kSortBlock) * 64 * sizeof(int) <= 96 * 1024;   // table must fit LDS
+                                  (size_t)((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * sizeof(int) <= 96 * 1024;   // table must fit LDS
             if (useOrder) {
                 if (c->orderTiles != tiles) {
                     (void)hipFree(c->d_tileCost); (void)hipFree(c->d_tileOrder); c->d_tileCost = c->d_tileOrder = nullptr; c->orderTiles = 0;
                     RTO_HIP(c, hipMalloc(&c->d_tileCost, (size_t)tiles * sizeof(int)));
                     RTO_HIP(c, hipMalloc(&c->d_tileOrder, (size_t)tiles * sizeof(int)));
                     (void)hipFree(c->d_sortHist); c->d_sortHist = nullptr;
-                    const size_t histInts = (size_t)((tiles + kSortBlock - 1) / kSortBlock) * 64 * 2;   // ping-pong
+                    const size_t histInts = (size_t)((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * 2;   // ping-pong
                     RTO_HIP(c, hipMalloc(&c->d_sortHist, histInts * sizeof(int)));
                     RTO_HIP(c, hipMemsetAsync(c->d_sortHist, 0, histInts * sizeof(int), s));
                     c->histPing = 0;
@@ -708,16 +708,16 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 if (std::memcmp(key, c->orderKey, sizeof key) != 0) { c->orderValid = false; c->orderFixed = false; std::memcpy(c->orderKey, key, sizeof key); }
                 Q.tileOrder = c->orderValid ? c->d_tileOrder : nullptr;
                 Q.tileCost = c->d_tileCost;
-                Q.tileHist = c->d_sortHist + (size_t)c->histPing * ((tiles + kSortBlock - 1) / kSortBlock) * 64;
+                Q.tileHist = c->d_sortHist + (size_t)c->histPing * ((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets;
             }
             hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             RTO_HIP(c, hipEventRecord(evB, s));       // the traversal kernel alone; the order kernel follows
             stopRecorded = true;
             if (useOrder && !c->orderFixed) {
                 const int nsb = (tiles + kSortBlock - 1) / kSortBlock;
-                int* cur = c->d_sortHist + (size_t)c->histPing * nsb * 64;
-                int* nxt = c->d_sortHist + (size_t)(1 - c->histPing) * nsb * 64;
-                hipLaunchKernelGGL(k_sort_scatter, dim3(nsb), dim3(kSortBlock), (size_t)nsb * 64 * sizeof(int), s, c->d_tileCost, tiles, cur, nsb, c->d_tileOrder, nxt);
+                int* cur = c->d_sortHist + (size_t)c->histPing * nsb * kCostBuckets;
+                int* nxt = c->d_sortHist + (size_t)(1 - c->histPing) * nsb * kCostBuckets;
+                hipLaunchKernelGGL(k_sort_scatter, dim3(nsb), dim3(kSortBlock), (size_t)nsb * kCostBuckets * sizeof(int), s, c->d_tileCost, tiles, cur, nsb, c->d_tileOrder, nxt);
                 c->histPing = 1 - c->histPing;
                 c->orderValid = true;
             }

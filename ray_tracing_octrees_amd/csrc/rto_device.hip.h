@@ -43,6 +43,10 @@ constexpr int kMaxTraversalSteps = 512;   // S/RT:192
 constexpr int kWave = 64;
 constexpr int kBlock = 256;               // 4 waves, each owns one 8x8 pixel tile
 constexpr int kMaxDepth = 20;             // log2(root size) supported by the packed kernel
+// temporal launch order: tiles are bucketed by their trip count; 1024 tiles per sort block
+constexpr int kSortBlock = 1024;
+constexpr int kCostBuckets = 16;          // bucket 0: trip count 0; bucket b>=1: trips in (4b-4, 4b], last one open-ended
+__device__ __forceinline__ int cost_bucket(int trips) { return trips <= 0 ? 0 : min((trips + 3) >> 2, kCostBuckets - 1); }
 
 struct RenderParams {
     float invView[16];     // glm::inverse(view), hoisted from S/RT:348 (pixel independent)
@@ -62,7 +66,7 @@ struct RenderParams {
     int rootX0, rootY0, rootX1, rootY1;   // pixel rectangle (inclusive, GLOBAL rows) outside of which no ray can meet the root box
     const int* tileOrder;           // launch slot -> tile, costliest tiles of the PREVIOUS frame first (null: centre-out)
     int* tileCost;                  // tile -> loop trip count of its wave in THIS frame (null: not recorded)
-    int* tileHist;                  // [tile / 1024][64] histogram of min(cost, 63) of THIS frame (zeroed beforehand)
+    int* tileHist;                  // [tile / 1024][kCostBuckets] histogram of this frame's trip counts (zeroed beforehand)
     const float* rayX;              // [W]  ((px+.5)/W*2-1)*aspect*tanHalfFov, the separable part of S/RT:341-346 (host-computed)
     const float* rayY;              // [H]  (1-(py+.5)/H*2)*tanHalfFov
 };
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed3(RenderParams P, const 
     if (P.tileCost && lane == 0 && ty < P.tilesY) {
         P.tileCost[tile] = trips;
         // zero-cost tiles (most of a typical frame) are not counted: their number follows from the block size
-        if (trips > 0) atomicAdd(&P.tileHist[(tile >> 10) * 64 + (trips < 63 ? trips : 63)], 1);
+        if (trips > 0) atomicAdd(&P.tileHist[(tile >> 10) * kCostBuckets + cost_bucket(trips)], 1);
     }
 
     if (MODE == kModeColor || MODE == kModeTimeline) {
@@ -835,7 +839,6 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed3(RenderParams P, const 
 // built in LDS with wave-aggregated atomics (one LDS atomic per DISTINCT bucket per wave: costs cluster
 // spatially); (2) each block derives its write offsets from the block-histogram table (costlier buckets first,
 // lower blocks first) and scatters.  Runs after the render kernel on the same stream.
-constexpr int kSortBlock = 1024;
 
 __device__ __forceinline__ void wave_bucket_add(int b, int lane, int* counters, int& posOut) {
     unsigned long long todo = __builtin_amdgcn_ballot_w64(b >= 0);
@@ -854,22 +857,23 @@ __device__ __forceinline__ void wave_bucket_add(int b, int lane, int* counters, 
 
 __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const int* __restrict__ tileCost, int tiles, const int* __restrict__ blockHist,
                                                               int numBlocks, int* __restrict__ order, int* __restrict__ nextHist) {
-    extern __shared__ int tab[];                       // [numBlocks][64] copy of the histogram table
-    __shared__ int base[64], fill[64], total[64];
-    for (int i = threadIdx.x; i < numBlocks * 64; i += kSortBlock) tab[i] = blockHist[i];
-    if (threadIdx.x < 64) nextHist[blockIdx.x * 64 + threadIdx.x] = 0;      // the table the NEXT frame accumulates into
+    extern __shared__ int tab[];                       // [numBlocks][kCostBuckets] copy of the histogram table
+    __shared__ int base[kCostBuckets], fill[kCostBuckets], total[kCostBuckets];
+    for (int i = threadIdx.x; i < numBlocks * kCostBuckets; i += kSortBlock) tab[i] = blockHist[i];
+    if (threadIdx.x < kCostBuckets) nextHist[blockIdx.x * kCostBuckets + threadIdx.x] = 0;   // the table the NEXT frame accumulates into
     __syncthreads();
     // bucket 0 is implicit: a block's tiles minus the counted ones (zero-cost tiles do no atomics)
     for (int k = threadIdx.x; k < numBlocks; k += kSortBlock) {
         int counted = 0;
-        for (int bk = 1; bk < 64; bk++) counted += tab[k * 64 + bk];
-        tab[k * 64] = min(kSortBlock, tiles - k * kSortBlock) - counted;
+#pragma unroll
+        for (int bk = 1; bk < kCostBuckets; bk++) counted += tab[k * kCostBuckets + bk];
+        tab[k * kCostBuckets] = min(kSortBlock, tiles - k * kSortBlock) - counted;
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < kCostBuckets) {
         int before = 0, all = 0;                       // tiles of this bucket in earlier blocks / in all blocks
         for (int k = 0; k < numBlocks; k++) {
-            const int h = tab[k * 64 + threadIdx.x];
+            const int h = tab[k * kCostBuckets + threadIdx.x];
             all += h;
             if (k < (int)blockIdx.x) before += h;
         }
@@ -877,14 +881,14 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const int* __restri
         fill[threadIdx.x] = before;
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < kCostBuckets) {
         int sum = 0;
-        for (int k = 63; k > (int)threadIdx.x; k--) sum += total[k];   // costlier buckets first
+        for (int k = kCostBuckets - 1; k > (int)threadIdx.x; k--) sum += total[k];   // costlier buckets first
         base[threadIdx.x] = sum;
     }
     __syncthreads();
     const int i = blockIdx.x * kSortBlock + threadIdx.x;
-    const int bkt = i < tiles ? min(tileCost[i], 63) : -1;
+    const int bkt = i < tiles ? cost_bucket(tileCost[i]) : -1;
     int pos;
     wave_bucket_add(bkt, threadIdx.x & 63, fill, pos);
     if (bkt >= 0) order[base[bkt] + pos] = i;
