@@ -691,7 +691,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             RenderParams Q = P;
             Q.tileOrder = nullptr; Q.tileCost = nullptr; Q.tileHist = nullptr;
             const long key[6] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles };
-            const bool useOrder = c->orderPolicy == RTO_ORDER_TEMPORAL && MODE == kModeColor &&
+            const bool useOrder = c->orderPolicy == RTO_ORDER_TEMPORAL && (MODE == kModeColor || MODE == kModeTimeline) &&
                                   (size_t)((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * sizeof(int) <= 96 * 1024;   // table must fit LDS
             if (useOrder) {
                 if (c->orderTiles != tiles) {
@@ -707,13 +707,13 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 }
                 if (std::memcmp(key, c->orderKey, sizeof key) != 0) { c->orderValid = false; c->orderFixed = false; std::memcpy(c->orderKey, key, sizeof key); }
                 Q.tileOrder = c->orderValid ? c->d_tileOrder : nullptr;
-                Q.tileCost = c->d_tileCost;
+                Q.tileCost = MODE == kModeColor ? c->d_tileCost : nullptr;
                 Q.tileHist = c->d_sortHist + (size_t)c->histPing * ((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets;
             }
             hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             RTO_HIP(c, hipEventRecord(evB, s));       // the traversal kernel alone; the order kernel follows
             stopRecorded = true;
-            if (useOrder && !c->orderFixed) {
+            if (useOrder && !c->orderFixed && MODE == kModeColor) {
                 const int nsb = (tiles + kSortBlock - 1) / kSortBlock;
                 int* cur = c->d_sortHist + (size_t)c->histPing * nsb * kCostBuckets;
                 int* nxt = c->d_sortHist + (size_t)(1 - c->histPing) * nsb * kCostBuckets;

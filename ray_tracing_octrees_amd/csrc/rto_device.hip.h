@@ -42,6 +42,9 @@ namespace rto {
 constexpr int kMaxTraversalSteps = 512;   // S/RT:192
 constexpr int kWave = 64;
 constexpr int kBlock = 256;               // 4 waves, each owns one 8x8 pixel tile
+#ifndef RTO_PACKED3_WAVES
+#define RTO_PACKED3_WAVES 6       // waves per SIMD for the default traversal kernel (8 forces spills and measured 6 % slower)
+#endif
 constexpr int kMaxDepth = 20;             // log2(root size) supported by the packed kernel
 // temporal launch order: tiles are bucketed by their trip count; 1024 tiles per sort block
 constexpr int kSortBlock = 1024;
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed2(RenderParams P, const 
 // tailAbove<<24 that comes either from the node's descriptor or from the LDS stack entry.  The LDS read is
 // unconditional (harmless when unused), the only predicated memory operation is the stack write.
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_trace_packed3(RenderParams P, const uint2* __restrict__ desc,
+__global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3(RenderParams P, const uint2* __restrict__ desc,
                                                            float4* __restrict__ out, int* __restrict__ stepsOut,
                                                            Counters* __restrict__ counters) {
     extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
