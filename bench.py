@@ -40,6 +40,10 @@ def parse_args():
     ap.add_argument("--band-rows", type=int, default=16)
     ap.add_argument("--kernel", choices=["auto", "packed", "generic"], default="auto")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo (+ --share-gpu) rehearses the multi-rank path on one GPU; the gather is staged through host memory")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
+    ap.add_argument("--verify", action="store_true", help="rank 0 compares the assembled frame with the CPU oracle (outside the timed region)")
     ap.add_argument("--order", choices=["temporal", "centre-out"], default="temporal",
                     help="tile launch order of the packed kernel (scheduling only; pixels are identical)")
     ap.add_argument("--frames-in-flight", type=int, default=1,
@@ -109,13 +113,18 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     # ---- scene: the product's own host layer (C++), not the oracle --------------------------------
     W, H = args.width, args.height
@@ -132,13 +141,20 @@ def main():
     ctx.set_kernel({"auto": rto.KERNEL_AUTO, "packed": rto.KERNEL_PACKED, "generic": rto.KERNEL_GENERIC}[args.kernel])
     ctx.set_launch_order(1 if args.order == "temporal" else 0)
     info = ctx.info()
-    renderer = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows)
+    renderer = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows,
+                                           stage_through_host=(args.dist_backend == "gloo"))
 
     def sync_all():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def max_over_ranks(x: float) -> float:
+        dev = "cuda" if args.dist_backend == "nccl" else "cpu"
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     # a side stream: kernels, events and (for N > 1) the RCCL gather all order themselves on it
     stream = torch.cuda.Stream()
@@ -168,9 +184,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed)
 
     # ---- everything below is outside the timed region ---------------------------------------------
     rays = W * H
@@ -228,6 +242,13 @@ def main():
             got = img.cpu().numpy()
             if got.tobytes() != want.tobytes():
                 sys.exit("bench: the timed frame differs from the oracle's -- result void")
+        elif args.verify:
+            from oracle import orc   # the checker, outside the timed region
+
+            want = np.zeros((H, W, 4), np.float32)
+            orc.render(nodes, grid.min, grid.voxelSize, view, pos, W / H, 45.0, W, H, nthreads=host_cores(), out=want)
+            if img.cpu().numpy().tobytes() != want.tobytes():
+                sys.exit("bench: the assembled frame differs from the oracle's -- result void")
         result = {
             "metric": "Mrays/s (primary rays), 1920x1080" if (W, H) == (1920, 1080) else f"Mrays/s (primary rays), {W}x{H}",
             "value": round(rays * args.steps / elapsed / 1e6, 2),
@@ -247,6 +268,7 @@ def main():
                 "kernel": args.kernel,
             },
             "hit_rays": stats["hits"], "capped_rays": stats["capped"],
+            "verified_against_oracle": bool((world == 1 and args.cpu_frames > 0) or args.verify),
             "device": ctx.device_name,
         }
         if roofline is not None:

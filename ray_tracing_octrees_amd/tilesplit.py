@@ -72,9 +72,12 @@ class _Buffers:
 
 
 class TileSplitRenderer:
-    """renders `frame` cooperatively; rank 0 gets the (H, W, 4) image, the others None."""
+    """renders `frame` cooperatively; rank 0 gets the (H, W, 4) image, the others None.
 
-    def __init__(self, backend, rank: int, world_size: int, band_rows: int = 16, group=None):
+    `stage_through_host=True` moves the gather payload through CPU tensors: only for rehearsing the multi-rank
+    path with the gloo backend (e.g. several ranks sharing one GPU); the product path gathers device to device."""
+
+    def __init__(self, backend, rank: int, world_size: int, band_rows: int = 16, group=None, stage_through_host: bool = False):
         if band_rows <= 0 or band_rows % 8:
             raise ValueError("band_rows must be a positive multiple of 8")
         self.backend = backend
@@ -82,6 +85,7 @@ class TileSplitRenderer:
         self.world = world_size
         self.band_rows = band_rows
         self.group = group
+        self.stage_through_host = stage_through_host
         self._buf: _Buffers | None = None
 
     def partition(self, part: int | None = None) -> hip.Partition:
@@ -107,6 +111,17 @@ class TileSplitRenderer:
         import torch.distributed as dist
 
         self.backend.render_part(frame, self.partition(), b.local)
+        if self.stage_through_host:
+            local = b.local.cpu()
+            if self.rank == 0:
+                parts = [local.new_empty(local.shape) for _ in range(self.world)]
+                dist.gather(local, parts, dst=0, group=self.group)
+                for i, p in enumerate(parts):
+                    b.gathered[i].copy_(p)
+                self.backend.assemble(frame, self.partition(0), b.gathered, b.frame)
+                return b.frame
+            dist.gather(local, None, dst=0, group=self.group)
+            return None
         if self.rank == 0:
             dist.gather(b.local, [b.gathered[i] for i in range(self.world)], dst=0, group=self.group)
             self.backend.assemble(frame, self.partition(0), b.gathered, b.frame)
