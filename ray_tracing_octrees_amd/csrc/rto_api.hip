@@ -486,7 +486,7 @@ int rto_octree_info_get(const rto_context* c, rto_octree_info* out) {
 
 int rto_set_kernel(rto_context* c, int kernel) {
     if (!c) return RTO_E_INVALID;
-    if (kernel < RTO_KERNEL_AUTO || kernel > RTO_KERNEL_PACKED_V2)
+    if (kernel < RTO_KERNEL_AUTO || kernel > RTO_KERNEL_PACKED_V1)
         return fail(c, RTO_E_INVALID, "rto_set_kernel: unknown kernel id");
     if (kernel >= RTO_KERNEL_PACKED && c->numNodes > 0 && !c->canonical)
         return fail(c, RTO_E_UNSUPPORTED, "rto_set_kernel: packed kernel needs a canonical BFS octree");
@@ -684,8 +684,6 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
         if (const char* pad = std::getenv("RTO_LDS_PAD")) lds += (size_t)std::atoi(pad);   // tuning aid: caps workgroups per CU
         if (c->kernelMode == RTO_KERNEL_PACKED_V1)
             hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
-        else if (c->kernelMode == RTO_KERNEL_PACKED_V2)
-            hipLaunchKernelGGL(k_trace_packed2<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
         else {
             // temporal launch order: this frame consumes the table built from the previous frame of the same geometry
             RenderParams Q = P;

@@ -427,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed(RenderParams P, const u
     }
 }
 
-// ================================================================ packed kernel, low-latency form
+// ================================================================ packed kernel, low-latency form (helpers)
 // Same traversal as k_trace_packed, restructured so that ONE loop iteration (= one internal node per
 // lane) is a short straight-line block -- the frame time of this path is set by the deepest rays
 // (~65 internal nodes) times the latency of one iteration, not by bandwidth:
@@ -510,150 +510,8 @@ __device__ __forceinline__ unsigned child_pass_mask_fast(const RenderParams& P, 
     return (b0 | b1 | b2) | (b3 | b4 | b5) | (b6 | b7);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_trace_packed2(RenderParams P, const uint2* __restrict__ desc,
-                                                           float4* __restrict__ out, int* __restrict__ stepsOut,
-                                                           Counters* __restrict__ counters) {
-    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;   // entry(level) = stk[level * 64]
-
-    unsigned long long tl0 = 0;
-    int tlIters = 0;
-    if (MODE == kModeTimeline) tl0 = wall_clock64();
-
-    const int tile = blockIdx.x * (kBlock / kWave) + wave;
-    int tx = 0, ty = P.tilesY;
-    if (tile < P.tilesX * P.tilesY) tile_of(P, tile, tx, ty);
-    const int px = tx * 8 + (lane & 7);
-    const int ly = ty * 8 + (lane >> 3);
-    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
-    const int py = global_row(P, ly);
-    const bool inImage = valid && (py < P.H);
-
-    bool hit = false;
-    int steps = 0;
-    int hx = 0, hy = 0, hz = 0, hs = 0;
-    Ray r;
-    bool alive = false;
-    if (inImage && P.rootVisible) {
-        r = generate_ray(P, px, py);
-        float tNear, tFar, a0, a1, a2, a3, a4, a5;
-        steps = 1;   // the root's own pop
-        alive = slab_exact(P, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
-    }
-    const bool risky = alive && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
-                                  __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
-
-    unsigned cur = 0;             // descriptor of the node being entered
-    int cx = 0, cy = 0, cz = 0;   // its integer position
-    int lvl = 0;                  // its level (root = 0); its children have edge rootSize >> (lvl + 1)
-    unsigned lvlPending = 0;      // bit l: stack level l still has interesting children to pop
-    unsigned tailRun = 0;         // steps owed by the exhausted levels directly above this node
-
-    int waveIter = 0;             // wave-uniform trip count (scalar): deep waves are the frame's critical path
-    while (alive) {
-        if (MODE == kModeTimeline) tlIters++;
-        // The frame ends when the deepest rays end (~65 nodes deep at 1080p/256^3) and a wave that shares its
-        // SIMD with 7 others advances slowly: raise the priority of waves as they get old so the long pole
-        // runs at near-solo speed while the many short waves fill the remaining issue slots.
-        waveIter++;
-        if (waveIter == 12) __builtin_amdgcn_s_setprio(1);
-        else if (waveIter == 24) __builtin_amdgcn_s_setprio(2);
-        else if (waveIter == 40) __builtin_amdgcn_s_setprio(3);
-        // ---------------- [A] enter node `cur`: which children matter?
-        const uint2 d = desc[cur];
-        const int half = P.rootSize >> (lvl + 1);
-        unsigned passMask;
-        if (__builtin_amdgcn_ballot_w64(risky) != 0ull) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
-        else passMask = child_pass_mask_fast(P, r, cx, cy, cz, half);
-        unsigned vm = (d.x >> 16) & 0xffu;
-        unsigned im = (d.x >> 8) & 0xffu;
-        const unsigned sm = d.x & vm;                                   // solid & visible (bits 0..7; higher bits cut by passMask)
-        unsigned hdr = d.x & 0x00ffff00u;                               // im | vm in stack-entry position
-        unsigned pending = ((im & vm) | sm) & passMask;
-        const unsigned solidHit = sm & passMask;
-        if (solidHit) pending &= ~((1u << (31 - __builtin_clz(solidHit))) - 1u);   // nothing below the first solid hit is reached
-        unsigned base = d.y;
-        unsigned tailAbove = tailRun;
-        int prev = 8;
-
-        // ---------------- [B] nothing to do here: count the children, jump to the deepest level with work
-        if (pending == 0) {
-            steps += __builtin_popcount(vm) + (int)tailRun;
-            if (lvlPending == 0 || steps >= kMaxTraversalSteps) {
-                alive = false;
-            } else {
-                const int L = 31 - __builtin_clz(lvlPending);
-                const uint2 e = stk[L * kWave];
-                pending = e.x & 0xffu; hdr = e.x & 0x00ffff00u; tailAbove = e.x >> 24; base = e.y;
-                im = (e.x >> 8) & 0xffu; vm = (e.x >> 16) & 0xffu;
-                const int bpos = P.depth - 1 - L;                        // log2 of level L's child edge
-                prev = ((cx >> bpos) & 1) | (((cy >> bpos) & 1) << 1) | (((cz >> bpos) & 1) << 2);
-                const int keep = (int)(0xffffffffu << (bpos + 1));
-                cx &= keep; cy &= keep; cz &= keep;
-                lvl = L;
-            }
-        }
-        // ---------------- [C] pop the next interesting child of level `lvl`
-        if (alive) {
-            const int j = 31 - __builtin_clz(pending);
-            const unsigned bitj = 1u << j;
-            const int skipped = __builtin_popcount(vm & ((1u << prev) - 1u) & ~((bitj << 1) - 1u));
-            if (steps + skipped >= kMaxTraversalSteps) {                 // S/RT:254: the cap ends the loop before this pop
-                steps = kMaxTraversalSteps;
-                alive = false;
-            } else {
-                steps += skipped + 1;
-                pending ^= bitj;
-                const int hl = P.rootSize >> (lvl + 1);
-                const int nx = cx | ((j & 1) ? hl : 0), ny = cy | ((j & 2) ? hl : 0), nz = cz | ((j & 4) ? hl : 0);
-                if (!(im & bitj)) {                                      // solid leaf: S/RT:278-288
-                    hit = true; hx = nx; hy = ny; hz = nz; hs = hl;
-                    alive = false;
-                } else {
-                    stk[lvl * kWave] = make_uint2(hdr | pending | (tailAbove << 24), base);
-                    const unsigned below = vm & (bitj - 1u);
-                    if (pending) { lvlPending |= (1u << lvl); tailRun = 0; }
-                    else { lvlPending &= ~(1u << lvl); tailRun = tailAbove + (unsigned)__builtin_popcount(below); }
-                    cur = base + (unsigned)__builtin_popcount(im & (bitj - 1u));
-                    cx = nx; cy = ny; cz = nz;
-                    lvl++;
-                }
-            }
-        }
-    }
-    if (!hit && steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
-
-    if (MODE == kModeColor || MODE == kModeTimeline) {
-        if (valid) {
-            float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
-            if (hit) color = shade_hit(P, r, hx, hy, hz, hs);
-            out[(size_t)ly * P.W + px] = color;
-        }
-        if (MODE == kModeTimeline) {
-            int it = tlIters;
-            for (int off = 32; off > 0; off >>= 1) it = max(it, __shfl_down(it, off));
-            int act = __builtin_popcountll(__builtin_amdgcn_ballot_w64(tlIters > 0));
-            if (lane == 0 && ty < P.tilesY) {
-                const unsigned long long tl1 = wall_clock64();
-                unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-                unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
-                int* rec = stepsOut + (size_t)tile * 8;
-                rec[0] = (int)(tl0 & 0xffffffffu); rec[1] = (int)(tl0 >> 32);
-                rec[2] = (int)(tl1 & 0xffffffffu); rec[3] = (int)(tl1 >> 32);
-                rec[4] = it; rec[5] = (int)hwid; rec[6] = (int)xcc; rec[7] = act;
-            }
-        }
-    } else {
-        if (inImage) stepsOut[(size_t)py * P.W + px] = hit ? steps : -steps;
-        wave_accumulate(counters, steps, hit, inImage);
-    }
-}
-
 // ================================================================ packed kernel, branch-free loop body
-// k_trace_packed2's algorithm with the loop body written as straight-line selects: the two lane classes of
+// The low-latency algorithm above with the loop body written as straight-line selects: the two lane classes of
 // an iteration ("entered a node with work" / "entered a node without work, resume at the deepest level
 // that has some") are merged through one packed state word W = pending | internal<<8 | visible<<16 |
 // tailAbove<<24 that comes either from the node's descriptor or from the LDS stack entry.  The LDS read is
@@ -730,20 +588,11 @@ __global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3(Ren
         const uint2 d = desc[cur];
         // the resume entry depends only on lvlPending: fetch it now, under the descriptor load and the slab math
         const int L = 31 - __builtin_clz(lvlPending | 1u);
-#if defined(RTO_ABLATE_LDS)
-        const uint2 e = make_uint2(0x00ffff01u, cur + 1);   // timing experiment only
-#else
         const uint2 e = stk[L * kWave];
-#endif
         const int half = 1 << (P.depth - 1 - lvl);
         unsigned passMask;
-#if defined(RTO_ABLATE_SLAB)
-        passMask = 0xa5u ^ (unsigned)(cx & 0xff);   // timing experiment only: no slab math
-        (void)half;
-#else
         if (anyRisky) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
         else passMask = child_pass_mask_fast(P, r, cx, cy, cz, half);
-#endif
         RTO_T(0);                                   // slab math (descriptor + LDS loads in flight)
         const unsigned vm0 = __builtin_amdgcn_ubfe(d.x, 16, 8);
         const unsigned im0 = __builtin_amdgcn_ubfe(d.x, 8, 8);

@@ -16,7 +16,7 @@ def timeit(f, reps=30):
     for _ in range(reps):
         ctx.render_host(f); ms.append(ctx.last_kernel_ms())
     return np.median(ms), min(ms)
-for name, k in (("packed", rto.KERNEL_PACKED), ("v2", rto.KERNEL_PACKED_V2), ("generic", rto.KERNEL_GENERIC)):
+for name, k in (("packed", rto.KERNEL_PACKED), ("generic", rto.KERNEL_GENERIC)):
     ctx.set_kernel(k)
     for label, (t, p, r, tgt) in (("normal", (0.5, 0.7, 1.8, (0, 0, 0))), ("all-miss (look away)", (0.5, 0.7, 1.8, (5.0, 5.0, 9.0))),
                                   ("tiny sphere r=40", (0.5, 0.7, 40.0, (0, 0, 0))), ("inside r=0.3 (all hit fast)", (0.5, 0.7, 0.3, (0, 0, 0)))):

@@ -30,7 +30,7 @@ def check(dim, W, H, ctx, reps=20):
     print(f"--- sphere {dim}^3 {W}x{H}: nodes {info.num_nodes} internal {info.num_internal} canonical {info.canonical} "
           f"depth {info.depth}; oracle {st} ({t_cpu * 1e3:.0f} ms, {orc.max_threads()} threads)")
     f = rto.make_frame(view, pos, W / H, 45.0, W, H)
-    for name, k in (("packed", rto.KERNEL_PACKED), ("packed_v2", rto.KERNEL_PACKED_V2), ("packed_v1", rto.KERNEL_PACKED_V1), ("generic", rto.KERNEL_GENERIC)):
+    for name, k in (("packed", rto.KERNEL_PACKED), ("packed_v1", rto.KERNEL_PACKED_V1), ("generic", rto.KERNEL_GENERIC)):
         ctx.set_kernel(k)
         got = ctx.render_host(f)
         bad = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=-1).sum())
