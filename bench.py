@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--verify", action="store_true", help="rank 0 compares the assembled frame with the CPU oracle (outside the timed region)")
     ap.add_argument("--order", choices=["temporal", "centre-out"], default="temporal",
                     help="tile launch order of the packed kernel (scheduling only; pixels are identical)")
+    ap.add_argument("--order-period", type=int, default=4, help="temporal order: rebuild the table every n-th frame")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="N=1 only: render consecutive frames on this many HIP streams (own framebuffers) so that the "
                          "deep-ray tail of one frame overlaps the start of the next; 1 = strictly one frame at a time")
@@ -139,7 +140,7 @@ def main():
     ctx = rto.Context(local_rank)
     ctx.upload_octree(nodes, grid.min, grid.voxelSize)
     ctx.set_kernel({"auto": rto.KERNEL_AUTO, "packed": rto.KERNEL_PACKED, "generic": rto.KERNEL_GENERIC}[args.kernel])
-    ctx.set_launch_order(1 if args.order == "temporal" else 0)
+    ctx.set_launch_order(1 if args.order == "temporal" else 0, args.order_period)
     info = ctx.info()
     renderer = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows,
                                            stage_through_host=(args.dist_backend == "gloo"))
@@ -217,7 +218,7 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": ("k_trace_packed3" if args.kernel in ("auto", "packed") else "k_trace_packed") if (info.canonical and args.kernel != "generic") else "k_trace_generic",
-                "launch_order": "temporal (tiles sorted by the previous frame's trip counts; k_sort_scatter follows each frame)" if args.order == "temporal" else "centre-out",
+                "launch_order": f"temporal (tiles sorted by an earlier frame's trip counts; k_sort_scatter after every {args.order_period}-th frame)" if args.order == "temporal" else "centre-out",
                 "kernel_ms_avg": round(k_avg, 5), "kernel_ms_median": round(kms[len(kms) // 2], 5),
                 "event_pair_overhead_ms": round(pair_overhead, 5),
                 "algorithmic_bytes_per_ray": round(bytes_per_ray, 2), "pops_per_ray": round(pops_per_ray, 4),

@@ -111,10 +111,11 @@ int  rto_set_kernel(rto_context* ctx, int kernel /* RTO_KERNEL_* */);
 /* Launch order of the 8x8-pixel tiles in the packed kernel (a scheduling hint; pixels never depend on it).
  * The frame ends when its deepest rays end, so the waves that will run longest should start first.
  * CENTRE_OUT: outwards from the projection of the solid geometry's centre.  TEMPORAL (default): by the per-tile
- * trip counts the previous frame of the same size recorded (falls back to CENTRE_OUT for the first frame). */
+ * trip counts an earlier frame of the same size recorded (CENTRE_OUT until one exists); the table is rebuilt
+ * every refresh_period-th frame (default 4; 0 keeps the current period) by one small kernel after that frame. */
 #define RTO_ORDER_CENTRE_OUT 0
 #define RTO_ORDER_TEMPORAL   1
-int  rto_set_launch_order(rto_context* ctx, int policy);
+int  rto_set_launch_order(rto_context* ctx, int policy, int refresh_period);
 
 /* ---- frustum culling ------------------------------------------------------
  * replaces: the CPU loop + compaction + SSBO re-upload of

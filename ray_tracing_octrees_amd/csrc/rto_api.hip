@@ -56,6 +56,8 @@ struct rto_context {
     long orderKey[6] = { 0, 0, 0, 0, 0, 0 };   // W, H, numParts, part, bandRows, tiles of the frame the history belongs to
     bool orderValid = false;
     bool orderFixed = false;        // debug: the caller supplied the table, do not rebuild it
+    int orderPeriod = 4;            // rebuild the table every orderPeriod-th frame (cost maps change slowly)
+    int orderAge = 0;               // frames rendered since the table was built
 
     // leaf triangles (config 5 extension)
     float* d_tris = nullptr;
@@ -464,11 +466,14 @@ int rto_debug_set_tile_order(rto_context* c, const int32_t* host_order, int64_t 
     return RTO_OK;
 }
 
-int rto_set_launch_order(rto_context* c, int policy) {
+int rto_set_launch_order(rto_context* c, int policy, int refresh_period) {
     if (!c) return RTO_E_INVALID;
     if (policy != RTO_ORDER_CENTRE_OUT && policy != RTO_ORDER_TEMPORAL) return fail(c, RTO_E_INVALID, "rto_set_launch_order: unknown policy");
+    if (refresh_period < 0) return fail(c, RTO_E_INVALID, "rto_set_launch_order: refresh_period must be >= 0 (0 keeps the current one)");
     c->orderPolicy = policy;
+    if (refresh_period > 0) c->orderPeriod = refresh_period;
     c->orderValid = false;
+    c->orderAge = 0;
     return RTO_OK;
 }
 
@@ -689,6 +694,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             RenderParams Q = P;
             Q.tileOrder = nullptr; Q.tileCost = nullptr; Q.tileHist = nullptr;
             const long key[6] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles };
+            bool recordCost = false;
             const bool useOrder = c->orderPolicy == RTO_ORDER_TEMPORAL && (MODE == kModeColor || MODE == kModeTimeline) &&
                                   (size_t)((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * sizeof(int) <= 96 * 1024;   // table must fit LDS
             if (useOrder) {
@@ -705,19 +711,23 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 }
                 if (std::memcmp(key, c->orderKey, sizeof key) != 0) { c->orderValid = false; c->orderFixed = false; std::memcpy(c->orderKey, key, sizeof key); }
                 Q.tileOrder = c->orderValid ? c->d_tileOrder : nullptr;
-                Q.tileCost = MODE == kModeColor ? c->d_tileCost : nullptr;
+                // costs are recorded only by the frame whose epilogue is followed by a rebuild
+                recordCost = MODE == kModeColor && !c->orderFixed && (!c->orderValid || c->orderAge + 1 >= c->orderPeriod);
+                Q.tileCost = recordCost ? c->d_tileCost : nullptr;
                 Q.tileHist = c->d_sortHist + (size_t)c->histPing * ((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets;
             }
             hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             RTO_HIP(c, hipEventRecord(evB, s));       // the traversal kernel alone; the order kernel follows
             stopRecorded = true;
-            if (useOrder && !c->orderFixed && MODE == kModeColor) {
+            if (useOrder && MODE == kModeColor && !recordCost) c->orderAge++;
+            if (useOrder && recordCost) {
                 const int nsb = (tiles + kSortBlock - 1) / kSortBlock;
                 int* cur = c->d_sortHist + (size_t)c->histPing * nsb * kCostBuckets;
                 int* nxt = c->d_sortHist + (size_t)(1 - c->histPing) * nsb * kCostBuckets;
                 hipLaunchKernelGGL(k_sort_scatter, dim3(nsb), dim3(kSortBlock), (size_t)nsb * kCostBuckets * sizeof(int), s, c->d_tileCost, tiles, cur, nsb, c->d_tileOrder, nxt);
                 c->histPing = 1 - c->histPing;
                 c->orderValid = true;
+                c->orderAge = 0;
             }
         }
     } else {

@@ -94,7 +94,7 @@ def load():
     L.rto_download_nodes.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.rto_last_build_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rto_set_kernel.argtypes = [vp, C.c_int]
-    L.rto_set_launch_order.argtypes = [vp, C.c_int]
+    L.rto_set_launch_order.argtypes = [vp, C.c_int, C.c_int]
     L.rto_update_frustum.argtypes = [vp, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int]
     L.rto_download_visible_nodes.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.rto_render_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp]
@@ -202,9 +202,10 @@ class Context:
     def set_kernel(self, kernel: int):
         self._check(self._L.rto_set_kernel(self._h, kernel))
 
-    def set_launch_order(self, policy: int):
-        """0 = centre-out, 1 = temporal (previous frame's per-tile cost; default)."""
-        self._check(self._L.rto_set_launch_order(self._h, policy))
+    def set_launch_order(self, policy: int, refresh_period: int = 0):
+        """0 = centre-out, 1 = temporal (an earlier frame's per-tile cost; default). refresh_period: rebuild the
+        table every n-th frame (0 keeps the current period, default 4)."""
+        self._check(self._L.rto_set_launch_order(self._h, policy, refresh_period))
 
     # -- culling -----------------------------------------------------------
     def update_frustum(self, view, fov_deg, aspect, enable=True):
