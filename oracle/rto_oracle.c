@@ -650,6 +650,26 @@ void orc_render_steps(const orc_node* nodes, int64_t n, const float gridMin[3], 
         }
 }
 
+/* per-pixel count of internal nodes whose children were pushed (analysis aid for the GPU work distribution) */
+void orc_render_visits(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                       const float view[16], const float camPos[3], float aspect, float fovDeg,
+                       int W, int H, int32_t* visits) {
+    (void)n;
+    frame_consts fc;
+    frame_setup(&fc, gridMin, voxelSize, view, camPos, aspect, fovDeg, W, H);
+    v3 ro = v3_(camPos[0], camPos[1], camPos[2]);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            v3 rd;
+            generate_ray(&fc, px, py, &rd);
+            trace_result tr = trace(nodes, &fc, ro, rd);
+            visits[(size_t)py * W + px] = tr.internal;
+        }
+}
+
 /* ------------------------------------------------------------------ */
 /* N1: octreeRaySkip (S/VolumeRaycastRenderer.cpp:50-155), on the flat array */
 /* ------------------------------------------------------------------ */

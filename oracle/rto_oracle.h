@@ -106,6 +106,10 @@ void orc_render_steps(const orc_node* nodes, int64_t n, const float gridMin[3], 
                       const float view[16], const float camPos[3], float aspect, float fovDeg,
                       int W, int H, int32_t* steps);
 
+void orc_render_visits(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                       const float view[16], const float camPos[3], float aspect, float fovDeg,
+                       int W, int H, int32_t* visits);
+
 /* ---- N1: front-to-back nearest hit (S/VolumeRaycastRenderer.cpp:50-155) - */
 float orc_octree_ray_skip(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
                           const float ro[3], const float rd[3], float tMin, float tMax);
