@@ -872,6 +872,12 @@ int rto_upload_leaf_triangles(rto_context* c, const float* tris, int64_t num_tri
     if (num_tris) RTO_HIP(c, hipMemcpy(c->d_tris, tris, (size_t)num_tris * 12 * sizeof(float), hipMemcpyHostToDevice));
     RTO_HIP(c, hipMemcpy(c->d_triOffset, tri_offset, (size_t)(c->numNodes + 1) * sizeof(int), hipMemcpyHostToDevice));
     c->numTris = num_tris;
+    if (c->canonical && c->numInternal > 0) {     // third child mask of the packed form: leaf children that own triangles
+        hipLaunchKernelGGL(k_desc_trimask, dim3((unsigned)((c->numInternal + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                           c->d_descFirstChild, c->d_triOffset, c->numInternal, c->d_desc);
+        RTO_HIP(c, hipGetLastError());
+        RTO_HIP(c, hipStreamSynchronize(c->stream));
+    }
     return RTO_OK;
 }
 
@@ -885,10 +891,18 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
     const int tiles = P.tilesX * P.tilesY;
     if (tiles <= 0) return RTO_OK;
     const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
-    TriScene S{ c->d_nodes, c->d_tris, c->d_triOffset };
+    const bool packed = c->canonical && c->numInternal > 0 && c->kernelMode != RTO_KERNEL_GENERIC;
     RTO_HIP(c, hipEventRecord(c->ev0, s));
-    if (count) hipLaunchKernelGGL(k_trace_triangles<kModeSteps>, dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
-    else hipLaunchKernelGGL(k_trace_triangles<kModeColor>, dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
+    if (packed) {
+        PackedTriScene S{ c->d_desc, c->d_descFirstChild, c->d_tris, c->d_triOffset };
+        const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint4);
+        if (count) hipLaunchKernelGGL(k_trace_packed_triangles<kModeSteps>, dim3(blocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+        else hipLaunchKernelGGL(k_trace_packed_triangles<kModeColor>, dim3(blocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+    } else {
+        TriScene S{ c->d_nodes, c->d_tris, c->d_triOffset };
+        if (count) hipLaunchKernelGGL(k_trace_triangles<kModeSteps>, dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
+        else hipLaunchKernelGGL(k_trace_triangles<kModeColor>, dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
+    }
     RTO_HIP(c, hipGetLastError());
     RTO_HIP(c, hipEventRecord(c->ev1, s));
     c->timed = true;

@@ -856,7 +856,7 @@ __global__ __launch_bounds__(kBlock) void k_desc_vismask(const uint8_t* __restri
     unsigned m = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) m |= vis[c0 + k] ? (1u << k) : 0u;
-    desc[d].x = (desc[d].x & 0xffffu) | (m << 16);
+    desc[d].x = (desc[d].x & 0xff00ffffu) | (m << 16);
 }
 
 __global__ __launch_bounds__(kBlock) void k_desc_visall(int64_t nInternal, uint2* __restrict__ desc) {
@@ -979,6 +979,170 @@ __global__ __launch_bounds__(kBlock) void k_trace_triangles(RenderParams P, TriS
     if (valid) out[(size_t)ly * P.W + px] = color;
     if (MODE == kModeSteps) {
         // counters: pops = steps of the primary + shadow traversals; capped = primary misses that ran into the cap
+        unsigned long long pops = inImage ? (unsigned long long)steps : 0ull, hits = (inImage && hit) ? 1ull : 0ull;
+        for (int off = 32; off > 0; off >>= 1) { pops += __shfl_down(pops, off); hits += __shfl_down(hits, off); }
+        if (lane == 0) { atomicAdd(&counters->pops, pops); atomicAdd(&counters->hits, hits); }
+    }
+}
+
+// ---------------------------------------------------------------- N2 on the packed descriptors
+// Same semantics as k_trace_triangles, on the child descriptors: bits 24..31 of a descriptor's .x mark the leaf
+// children that own triangles (k_desc_trimask).  Solid leaves are no longer hits by themselves; the interesting
+// children of a node are its internal children and its triangle-owning leaves that pass the slab test.  Popping a
+// triangle leaf runs Moeller-Trumbore over its range (triOffset is indexed by node: first child + slot) and, on a
+// miss, continues with the next child of the SAME node, so the per-level state (W, base, first child) is carried
+// in registers and the LDS entry is 16 bytes.
+struct PackedTriScene {
+    const uint2* desc;
+    const int* descFirstChild;
+    const float* tris;
+    const int* triOffset;
+};
+
+__global__ __launch_bounds__(kBlock) void k_desc_trimask(const int* __restrict__ descFirstChild, const int* __restrict__ triOffset,
+                                                          int64_t nInternal, uint2* __restrict__ desc) {
+    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (d >= nInternal) return;
+    const int c0 = descFirstChild[d];
+    const unsigned x = desc[d].x;
+    const unsigned im = (x >> 8) & 0xffu;
+    unsigned tm = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (!((im >> k) & 1u) && triOffset[c0 + k + 1] > triOffset[c0 + k]) tm |= 1u << k;
+    desc[d].x = (x & 0x00ffffffu) | (tm << 24);
+}
+
+struct PTriHit { bool hit; int steps; float t; int tri; };
+
+__device__ __forceinline__ PTriHit trace_packed_triangles(const RenderParams& P, const PackedTriScene& S, const Ray& r, uint4* stk) {
+    PTriHit h; h.hit = false; h.steps = 1; h.t = 1e30f; h.tri = -1;
+    {
+        float tNear, tFar, a0, a1, a2, a3, a4, a5;
+        if (!(slab_exact(P, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f))) return h;
+    }
+    const bool risky = !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
+                         __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
+    unsigned cur = 0;
+    int cx = 0, cy = 0, cz = 0;
+    int lvl = 0;                   // level of the node whose children are being popped (after the visit)
+    unsigned lvlPending = 0, tailRun = 0;
+    unsigned W = 0, base = 0;      // state of level `lvl`: pending | internal<<8 | visible<<16 | tailAbove<<24
+    int c0 = 0;                    // node index of its first child
+    unsigned belowPrev = 0xffu;    // children of it not popped yet
+    bool needVisit = true;
+    int steps = 1;
+    bool alive = true;
+    while (alive) {
+        if (needVisit) {
+            const uint2 d = S.desc[cur];
+            c0 = S.descFirstChild[cur];
+            const int half = 1 << (P.depth - 1 - lvl);
+            unsigned passMask;
+            if (__builtin_amdgcn_ballot_w64(risky) != 0ull) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
+            else passMask = child_pass_mask_fast(P, r, cx, cy, cz, half);
+            const unsigned vm0 = __builtin_amdgcn_ubfe(d.x, 16, 8);
+            const unsigned im0 = __builtin_amdgcn_ubfe(d.x, 8, 8);
+            const unsigned tm0 = d.x >> 24;
+            W = (d.x & 0x00ffff00u) | (((im0 | tm0) & vm0) & passMask) | (tailRun << 24);
+            base = d.y;
+            belowPrev = 0xffu;
+            needVisit = false;
+        }
+        if ((W & 0xffu) == 0) {
+            // this level is exhausted: its remaining children only count steps; resume at the deepest level with work
+            steps += __builtin_popcount(((W >> 16) & 0xffu) & belowPrev) + (int)(W >> 24);
+            if (lvlPending == 0 || steps >= kMaxTraversalSteps) { alive = false; break; }
+            const int L = 31 - __builtin_clz(lvlPending);
+            const uint4 e = stk[L * kWave];
+            W = e.x; base = e.y; c0 = (int)e.z;
+            lvlPending &= ~(1u << L);          // its state lives in registers again; a later descent re-files it
+            const int bpos = P.depth - 1 - L;
+            const unsigned childIdx = ((cx >> bpos) & 1) | (((cy >> bpos) & 1) << 1) | (((cz >> bpos) & 1) << 2);
+            belowPrev = (1u << childIdx) - 1u;
+            const int keep = (int)(0xffffffffu << (bpos + 1));
+            cx &= keep; cy &= keep; cz &= keep;
+            lvl = L;
+        }
+        // pop the next interesting child of level lvl
+        const unsigned pending = W & 0xffu, im = (W >> 8) & 0xffu, vm = (W >> 16) & 0xffu, tailAbove = W >> 24;
+        const int j = 31 - __builtin_clz(pending);
+        const unsigned bitj = 1u << j;
+        const int stepsC = steps + __builtin_popcount(vm & belowPrev & ~((bitj << 1) - 1u));
+        if (stepsC >= kMaxTraversalSteps) { steps = kMaxTraversalSteps; alive = false; break; }
+        steps = stepsC + 1;
+        W ^= bitj;
+        belowPrev = bitj - 1u;
+        if (im & bitj) {
+            stk[lvl * kWave] = make_uint4(W, base, (unsigned)c0, 0u);
+            if (W & 0xffu) { lvlPending |= (1u << lvl); tailRun = 0; }
+            else { lvlPending &= ~(1u << lvl); tailRun = tailAbove + (unsigned)__builtin_popcount(vm & (bitj - 1u)); }
+            cur = base + (unsigned)__builtin_popcount(im & (bitj - 1u));
+            const int hl = 1 << (P.depth - 1 - lvl);
+            cx |= (j & 1) ? hl : 0; cy |= (j & 2) ? hl : 0; cz |= (j & 4) ? hl : 0;
+            lvl++;
+            needVisit = true;
+        } else {
+            // a leaf that owns triangles and passed the slab test: nearest t > 0 within the leaf
+            const int node = c0 + j;
+            float bestT = 1e30f;
+            int best = -1;
+            const int k1 = S.triOffset[node + 1];
+            for (int k = S.triOffset[node]; k < k1; k++) {
+                float t;
+                if (ray_triangle(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, S.tris + (size_t)k * 12, t) && t < bestT) { bestT = t; best = k; }
+            }
+            if (best >= 0) { h.hit = true; h.t = bestT; h.tri = best; alive = false; }
+        }
+    }
+    if (!h.hit && steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
+    h.steps = steps;
+    return h;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_trace_packed_triangles(RenderParams P, PackedTriScene S, int shadow, float4* __restrict__ out,
+                                                                    Counters* __restrict__ counters) {
+    extern __shared__ uint4 lds_stack4[];   // [wave][level][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint4* stk = lds_stack4 + (size_t)wave * P.depth * kWave + lane;
+    const int slot = blockIdx.x * (kBlock / kWave) + wave;
+    int tx = 0, ty = P.tilesY;
+    if (slot < P.tilesX * P.tilesY) tile_of(P, slot, tx, ty);
+    const int px = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    const bool inImage = valid && (py < P.H);
+    float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+    int steps = 0;
+    bool hit = false;
+    if (inImage) {
+        const Ray r = generate_ray_tab(P, px, py);
+        const PTriHit h = trace_packed_triangles(P, S, r, stk);
+        steps = h.steps;
+        hit = h.hit;
+        if (h.hit) {
+            float nx = S.tris[(size_t)h.tri * 12 + 9], ny = S.tris[(size_t)h.tri * 12 + 10], nz = S.tris[(size_t)h.tri * 12 + 11];
+            if (nx * r.dx + ny * r.dy + nz * r.dz > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+            float ndotl = gmax(0.0f, nx * P.lightNeg[0] + ny * P.lightNeg[1] + nz * P.lightNeg[2]);
+            if (shadow) {
+                const float bias = P.voxelSize * 1e-3f;
+                const float hx = r.ox + r.dx * h.t, hy = r.oy + r.dy * h.t, hz = r.oz + r.dz * h.t;
+                Ray s;
+                s.ox = hx + nx * bias; s.oy = hy + ny * bias; s.oz = hz + nz * bias;
+                s.dx = P.lightNeg[0]; s.dy = P.lightNeg[1]; s.dz = P.lightNeg[2];
+                s.ix = 1.0f / s.dx; s.iy = 1.0f / s.dy; s.iz = 1.0f / s.dz;
+                const PTriHit sh = trace_packed_triangles(P, S, s, stk);
+                steps += sh.steps;
+                if (sh.hit) ndotl = 0.0f;
+            }
+            color = make_float4(1.0f * ndotl + 0.1f, 0.8f * ndotl + 0.1f, 0.6f * ndotl + 0.1f, 1.0f);
+        }
+    }
+    if (valid) out[(size_t)ly * P.W + px] = color;
+    if (MODE == kModeSteps) {
         unsigned long long pops = inImage ? (unsigned long long)steps : 0ull, hits = (inImage && hit) ? 1ull : 0ull;
         for (int off = 32; off > 0; off >>= 1) { pops += __shfl_down(pops, off); hits += __shfl_down(hits, off); }
         if (lane == 0) { atomicAdd(&counters->pops, pops); atomicAdd(&counters->hits, hits); }

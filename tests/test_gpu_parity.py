@@ -505,10 +505,15 @@ def test_config5_leaf_triangles_and_shadow_ray(ctx, orc, scenes, scene, W, H, ca
     for shadow in (False, True):
         want, st = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, view, pos, W / H, 45.0, W, H, shadow=shadow,
                                         nthreads=min(16, orc.max_threads()))
-        got, gs = ctx.render_triangles_host(f, shadow=shadow, stats=True)
-        assert_bit_exact(got, want, f"{scene} triangles shadow={shadow}")
-        assert (gs["pops"], gs["hits"]) == (st["pops"], st["hits"])
         assert st["hits"] > 0
+        # AUTO = packed descriptors + "leaf owns triangles" mask; GENERIC = the 60-byte node skeleton
+        for kname, kernel in (("packed", rto.KERNEL_AUTO), ("generic", rto.KERNEL_GENERIC)):
+            ctx.set_kernel(kernel)
+            got, gs = ctx.render_triangles_host(f, shadow=shadow, stats=True)
+            assert_bit_exact(got, want, f"{scene} triangles shadow={shadow} {kname}")
+            assert (gs["pops"], gs["hits"]) == (st["pops"], st["hits"]), kname
+            got2 = ctx.render_triangles_host(f, shadow=shadow)              # colour-only instantiation
+            assert_bit_exact(got2, want, f"{scene} triangles shadow={shadow} {kname} (no counters)")
 
 
 def test_config5_shadows_exist_and_partitions_agree(ctx, orc, scenes):
@@ -549,8 +554,6 @@ def test_config5_shadows_exist_and_partitions_agree(ctx, orc, scenes):
 
 def test_config5_full_size_512_4k_triangles_shadow(ctx, orc, scenes, camera):
     """BASELINE config 5 at full size on one GPU: 512^3 sphere, 3840x2160, MC leaf triangles + 1 shadow ray per hit."""
-    import time
-
     s = scenes("sphere512")
     view, pos = camera("sphere")
     W, H = 3840, 2160
@@ -561,11 +564,13 @@ def test_config5_full_size_512_4k_triangles_shadow(ctx, orc, scenes, camera):
     f = rto.make_frame(view, pos, W / H, 45.0, W, H)
     want, st = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, view, pos, W / H, 45.0, W, H, shadow=True,
                                     nthreads=min(16, orc.max_threads()))
-    t = time.perf_counter()
-    got, gs = ctx.render_triangles_host(f, shadow=True, stats=True)
-    assert_bit_exact(got, want, "config 5 full size")
-    assert (gs["pops"], gs["hits"]) == (st["pops"], st["hits"])
-    print(f"config5 4K triangles+shadow: {st['hits']} hits, {len(wt)} triangles, kernel {ctx.last_kernel_ms():.3f} ms")
+    for kname, kernel in (("packed", rto.KERNEL_AUTO), ("generic", rto.KERNEL_GENERIC)):
+        ctx.set_kernel(kernel)
+        got, gs = ctx.render_triangles_host(f, shadow=True, stats=True)
+        assert_bit_exact(got, want, f"config 5 full size {kname}")
+        assert (gs["pops"], gs["hits"]) == (st["pops"], st["hits"]), kname
+        ctx.render_triangles_host(f, shadow=True)
+        print(f"config5 4K triangles+shadow [{kname}]: {st['hits']} hits, {len(wt)} triangles, kernel {ctx.last_kernel_ms():.3f} ms")
 
 
 def test_cpp_dropin_class_triangle_path(orc, scenes):
