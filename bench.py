@@ -8,7 +8,9 @@ Step     : one frame = one pass of the hot path over 2,073,600 rays, octree and 
 N = 1    : one kernel launch per frame into a device framebuffer.
 N > 1    : launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; every rank
            holds the octree, renders its round-robin bands and ONE torch.distributed.gather (RCCL over
-           xGMI) per frame lands the image on rank 0, which re-interleaves it (strong scaling).
+           xGMI) per frame lands the image on rank 0, which re-interleaves it (strong scaling).  The payload
+           is 4 bytes per pixel (the Lambert term; rank 0 finishes the colour, bit-identical) and the gather
+           of frame k overlaps the render of frame k+1; all K frames are complete inside the timed region.
 
 Prints ONE JSON line on rank 0.  `cpu_baseline` is this repo's own C restatement of the reference's GLSL
 kernel (the reference has no CPU path and publishes no numbers), timed here on the box's host cores.
@@ -47,6 +49,9 @@ def parse_args():
     ap.add_argument("--order", choices=["temporal", "centre-out"], default="temporal",
                     help="tile launch order of the packed kernel (scheduling only; pixels are identical)")
     ap.add_argument("--order-period", type=int, default=4, help="temporal order: rebuild the table every n-th frame")
+    ap.add_argument("--payload", choices=["shade", "rgba"], default="shade",
+                    help="N>1: what a part ships to rank 0 -- 4-byte Lambert term per pixel (default) or the 16-byte pixel")
+    ap.add_argument("--no-pipeline", action="store_true", help="N>1: finish the gather of a frame before rendering the next")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="N=1 only: render consecutive frames on this many HIP streams (own framebuffers) so that the "
                          "deep-ray tail of one frame overlaps the start of the next; 1 = strictly one frame at a time")
@@ -143,7 +148,8 @@ def main():
     ctx.set_launch_order(1 if args.order == "temporal" else 0, args.order_period)
     info = ctx.info()
     renderer = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows,
-                                           stage_through_host=(args.dist_backend == "gloo"))
+                                           stage_through_host=(args.dist_backend == "gloo"), payload=args.payload)
+    pipelined = world > 1 and not args.no_pipeline
 
     def sync_all():
         torch.cuda.synchronize()
@@ -180,8 +186,12 @@ def main():
             s_ = streams[k % fif]
             ctx.render_device(frame, bufs[k % fif].data_ptr(), None, s_.cuda_stream)
             img = bufs[k % fif]
+        elif pipelined:
+            renderer.submit(frame)        # render k, then complete frame k-1 (its gather ran meanwhile), then start gather k
         else:
             img = renderer.render(frame)
+    if pipelined:
+        img = renderer.flush()            # frame K-1: all K frames are assembled on rank 0 before the clock stops
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -265,7 +275,8 @@ def main():
                 "workload": f"{args.dim}^3 test-sphere voxel grid, octree to min-leaf 1 ({info.num_nodes} nodes), "
                             f"{W}x{H} primary rays, Camera(0.5,0.7,1.8), fov 45",
                 "parallelism": ("1 GPU" if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else f"screen split over {world} GPUs, {args.band_rows}-row bands "
-                                                          f"round-robin, 1 RCCL gather per frame",
+                                                          f"round-robin, 1 RCCL gather per frame ({'4-byte Lambert term' if args.payload == 'shade' else 'RGBA32F'} per pixel"
+                                                          f"{', gather k overlaps render k+1' if pipelined else ''})",
                 "kernel": args.kernel,
             },
             "hit_rays": stats["hits"], "capped_rays": stats["capped"],

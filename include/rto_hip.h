@@ -146,6 +146,15 @@ int  rto_partition_rows(const rto_frame* frame, const rto_partition* part);
  * every part padded to rto_partition_rows(part 0) rows) into a row-major frame. */
 int  rto_assemble_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part,
                          const void* d_gathered, void* d_frame, void* hip_stream);
+/* The same pair with a 4-byte payload per pixel, for the xGMI gather (no reference counterpart: the reference is
+ * single-GPU).  Every pixel of S/RayTracerBVH.cpp:331-336 / :363 is a function of ONE float -- the Lambert term
+ * max(dot(n, -L), 0) of the hit, or "no hit" -- so a part ships that float (-1.0f = no hit: rows*width*4 bytes
+ * instead of *16) and the gathering GPU finishes `vec3(1,.8,.6) * term + .1` while it re-interleaves.  Same float
+ * operations in the same order: the assembled frame is bit-identical to rto_render_device's. */
+int  rto_render_shade_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part /* NULL = whole frame */,
+                             void* d_shade, void* hip_stream);
+int  rto_assemble_shade_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part,
+                               const void* d_gathered_shade, void* d_frame, void* hip_stream);
 
 /* ---- N2: leaf triangles + shadow ray (BASELINE config 5) -------------------------
  * No upstream counterpart: the reference has no ray/triangle code (its MC triangles are rasterised).  The
@@ -159,6 +168,9 @@ int  rto_upload_leaf_triangles(rto_context* ctx, const float* tris, int64_t num_
 int  rto_render_triangles_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part, int shadow,
                                  void* d_out, void* hip_stream);
 int  rto_render_triangles_host(rto_context* ctx, const rto_frame* frame, int shadow, float* host_rgba, rto_stats* stats);
+/* 4-byte payload variant (see rto_render_shade_device); reassemble with rto_assemble_shade_device. */
+int  rto_render_triangles_shade_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part, int shadow,
+                                       void* d_shade, void* hip_stream);
 
 /* ---- N1: octreeRaySkip --------------------------------------------------------
  * replaces: the CPU recursion octreeRaySkip(root, ro, rd, tMin, tMax, grid, &visibility)

@@ -695,7 +695,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             Q.tileOrder = nullptr; Q.tileCost = nullptr; Q.tileHist = nullptr;
             const long key[6] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles };
             bool recordCost = false;
-            const bool useOrder = c->orderPolicy == RTO_ORDER_TEMPORAL && (MODE == kModeColor || MODE == kModeTimeline) &&
+            const bool useOrder = c->orderPolicy == RTO_ORDER_TEMPORAL && (MODE == kModeColor || MODE == kModeShade || MODE == kModeTimeline) &&
                                   (size_t)((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * sizeof(int) <= 96 * 1024;   // table must fit LDS
             if (useOrder) {
                 if (c->orderTiles != tiles) {
@@ -712,14 +712,14 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 if (std::memcmp(key, c->orderKey, sizeof key) != 0) { c->orderValid = false; c->orderFixed = false; std::memcpy(c->orderKey, key, sizeof key); }
                 Q.tileOrder = c->orderValid ? c->d_tileOrder : nullptr;
                 // costs are recorded only by the frame whose epilogue is followed by a rebuild
-                recordCost = MODE == kModeColor && !c->orderFixed && (!c->orderValid || c->orderAge + 1 >= c->orderPeriod);
+                recordCost = (MODE == kModeColor || MODE == kModeShade) && !c->orderFixed && (!c->orderValid || c->orderAge + 1 >= c->orderPeriod);
                 Q.tileCost = recordCost ? c->d_tileCost : nullptr;
                 Q.tileHist = c->d_sortHist + (size_t)c->histPing * ((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets;
             }
             hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             RTO_HIP(c, hipEventRecord(evB, s));       // the traversal kernel alone; the order kernel follows
             stopRecorded = true;
-            if (useOrder && MODE == kModeColor && !recordCost) c->orderAge++;
+            if (useOrder && (MODE == kModeColor || MODE == kModeShade) && !recordCost) c->orderAge++;
             if (useOrder && recordCost) {
                 const int nsb = (tiles + kSortBlock - 1) / kSortBlock;
                 int* cur = c->d_sortHist + (size_t)c->histPing * nsb * kCostBuckets;
@@ -772,6 +772,16 @@ int rto_render_device(rto_context* c, const rto_frame* f, const rto_partition* p
     return launch_trace<kModeColor>(c, P, (float4*)d_out, (hipStream_t)hip_stream);
 }
 
+int rto_render_shade_device(rto_context* c, const rto_frame* f, const rto_partition* p, void* d_shade, void* hip_stream) {
+    if (!c) return RTO_E_INVALID;
+    if (!d_shade) return fail(c, RTO_E_INVALID, "rto_render_shade_device: d_shade is NULL");
+    RTO_HIP(c, hipSetDevice(c->device));
+    RenderParams P;
+    int rc = fill_params(c, f, p, P);
+    if (rc != RTO_OK) return rc;
+    return launch_trace<kModeShade>(c, P, (float4*)d_shade, (hipStream_t)hip_stream);
+}
+
 int rto_render_host(rto_context* c, const rto_frame* f, float* host_rgba) {
     if (!c) return RTO_E_INVALID;
     if (!host_rgba) return fail(c, RTO_E_INVALID, "rto_render_host: host_rgba is NULL");
@@ -796,6 +806,19 @@ int rto_assemble_device(rto_context* c, const rto_frame* f, const rto_partition*
     const int partRows = rto_partition_rows(f, &p0);
     hipStream_t s = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(k_assemble, dim3(2048), dim3(256), 0, s, (const float4*)d_gathered, (float4*)d_frame,
+                       f->width, f->height, p->num_parts, p->num_parts > 1 ? p->band_rows : f->height, partRows);
+    RTO_HIP(c, hipGetLastError());
+    return RTO_OK;
+}
+
+int rto_assemble_shade_device(rto_context* c, const rto_frame* f, const rto_partition* p, const void* d_gathered,
+                              void* d_frame, void* hip_stream) {
+    if (!c || !f || !p || !d_gathered || !d_frame) return c ? fail(c, RTO_E_INVALID, "rto_assemble_shade_device: NULL argument") : RTO_E_INVALID;
+    if (p->num_parts < 1 || p->band_rows <= 0) return fail(c, RTO_E_INVALID, "rto_assemble_shade_device: bad partition");
+    RTO_HIP(c, hipSetDevice(c->device));
+    rto_partition p0 = *p; p0.part = 0;
+    const int partRows = rto_partition_rows(f, &p0);
+    hipLaunchKernelGGL(k_assemble_shade, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, (const float*)d_gathered, (float4*)d_frame,
                        f->width, f->height, p->num_parts, p->num_parts > 1 ? p->band_rows : f->height, partRows);
     RTO_HIP(c, hipGetLastError());
     return RTO_OK;
@@ -882,7 +905,7 @@ int rto_upload_leaf_triangles(rto_context* c, const float* tris, int64_t num_tri
 }
 
 static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partition* p, int shadow, float4* d_out, hipStream_t s,
-                            bool count) {
+                            bool count, bool shadeOut = false) {
     if (!c->d_triOffset) return fail(c, RTO_E_NO_OCTREE, "render_triangles: no leaf triangles uploaded");
     if (c->culling) return fail(c, RTO_E_UNSUPPORTED, "render_triangles: not available while frustum culling is active");
     RenderParams P;
@@ -896,12 +919,14 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
     if (packed) {
         PackedTriScene S{ c->d_desc, c->d_descFirstChild, c->d_tris, c->d_triOffset };
         const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint4);
-        if (count) hipLaunchKernelGGL(k_trace_packed_triangles<kModeSteps>, dim3(blocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
-        else hipLaunchKernelGGL(k_trace_packed_triangles<kModeColor>, dim3(blocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+        if (shadeOut) hipLaunchKernelGGL((k_trace_packed_triangles<kModeColor, true>), dim3(blocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+        else if (count) hipLaunchKernelGGL((k_trace_packed_triangles<kModeSteps, false>), dim3(blocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+        else hipLaunchKernelGGL((k_trace_packed_triangles<kModeColor, false>), dim3(blocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
     } else {
         TriScene S{ c->d_nodes, c->d_tris, c->d_triOffset };
-        if (count) hipLaunchKernelGGL(k_trace_triangles<kModeSteps>, dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
-        else hipLaunchKernelGGL(k_trace_triangles<kModeColor>, dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
+        if (shadeOut) hipLaunchKernelGGL((k_trace_triangles<kModeColor, true>), dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
+        else if (count) hipLaunchKernelGGL((k_trace_triangles<kModeSteps, false>), dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
+        else hipLaunchKernelGGL((k_trace_triangles<kModeColor, false>), dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
     }
     RTO_HIP(c, hipGetLastError());
     RTO_HIP(c, hipEventRecord(c->ev1, s));
@@ -914,6 +939,13 @@ int rto_render_triangles_device(rto_context* c, const rto_frame* f, const rto_pa
     if (!d_out) return fail(c, RTO_E_INVALID, "rto_render_triangles_device: d_out is NULL");
     RTO_HIP(c, hipSetDevice(c->device));
     return launch_triangles(c, f, p, shadow, (float4*)d_out, (hipStream_t)hip_stream, false);
+}
+
+int rto_render_triangles_shade_device(rto_context* c, const rto_frame* f, const rto_partition* p, int shadow, void* d_shade, void* hip_stream) {
+    if (!c) return RTO_E_INVALID;
+    if (!d_shade) return fail(c, RTO_E_INVALID, "rto_render_triangles_shade_device: d_shade is NULL");
+    RTO_HIP(c, hipSetDevice(c->device));
+    return launch_triangles(c, f, p, shadow, (float4*)d_shade, (hipStream_t)hip_stream, false, true);
 }
 
 int rto_render_triangles_host(rto_context* c, const rto_frame* f, int shadow, float* host_rgba, rto_stats* stats) {

@@ -171,7 +171,11 @@ __device__ __forceinline__ bool slab_exact(const RenderParams& P, const Ray& r, 
 }
 
 // Hit epilogue: S/RT:279-285 (tHit, centre pseudo-normal) + S/RT:331-336 (Lambert).
-__device__ __forceinline__ float4 shade_hit(const RenderParams& P, const Ray& r, int x, int y, int z, int size) {
+// Split in two so that the multi-GPU path can ship the 4-byte Lambert term instead of the 16-byte pixel:
+// shade_term() is everything up to max(dot(n, -L), 0); shade_color() is the final colour expression, evaluated
+// either in the traversal kernel (RGBA32F output) or in k_assemble_shade on the gathering GPU.  Same float
+// operations in the same order either way, so the pixel bits do not depend on where the second half runs.
+__device__ __forceinline__ float shade_term(const RenderParams& P, const Ray& r, int x, int y, int z, int size) {
     float tNear, tFar, mnx, mny, mnz, mxx, mxy, mxz;
     slab_exact(P, r, x, y, z, size, tNear, tFar, mnx, mny, mnz, mxx, mxy, mxz);
     float tHit = gmax(0.0f, tNear);
@@ -180,14 +184,25 @@ __device__ __forceinline__ float4 shade_hit(const RenderParams& P, const Ray& r,
     float qx = px - cx, qy = py - cy, qz = pz - cz;
     float inv = inversesqrt(qx * qx + qy * qy + qz * qz);
     float nx = qx * inv, ny = qy * inv, nz = qz * inv;
-    float ndotl = gmax(0.0f, nx * P.lightNeg[0] + ny * P.lightNeg[1] + nz * P.lightNeg[2]);
+    return gmax(0.0f, nx * P.lightNeg[0] + ny * P.lightNeg[1] + nz * P.lightNeg[2]);   // >= +0, never NaN (glm max keeps 0)
+}
+
+constexpr float kShadeMiss = -1.0f;   // shade-buffer code of a ray without a hit (the Lambert term is never negative)
+
+__device__ __forceinline__ float4 shade_color(float ndotl) {
+    if (ndotl < 0.0f) return make_float4(0.f, 0.f, 0.f, 1.f);                             // S/RT:363 background
     return make_float4(1.0f * ndotl + 0.1f, 0.8f * ndotl + 0.1f, 0.6f * ndotl + 0.1f, 1.0f);
+}
+
+__device__ __forceinline__ float4 shade_hit(const RenderParams& P, const Ray& r, int x, int y, int z, int size) {
+    return shade_color(shade_term(P, r, x, y, z, size));
 }
 
 // Output modes of the traversal kernels.
 constexpr int kModeColor = 0;   // RGBA32F framebuffer
 constexpr int kModeSteps = 1;   // per-pixel +/-steps and frame counters (instrumentation)
 constexpr int kModeTimeline = 2; // per-wave {start, end (100 MHz wall clock), loop iterations, HW_ID} in stepsOut (8 ints / tile)
+constexpr int kModeShade = 3;    // one float per pixel: the Lambert term of the hit, kShadeMiss for a miss (multi-GPU payload)
 
 struct Counters { unsigned long long pops, hits, capped; };
 
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_generic(RenderParams P, const 
 
     bool hit = false;
     int steps = 0;
-    float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+    float shade = kShadeMiss;
     if (inImage && P.rootVisible) {
         Ray r = generate_ray(P, px, py);
         int stack[128];                 // S/RT:247
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_generic(RenderParams P, const 
                     float tHit = gmax(0.0f, tNear);
                     if (tHit < closestT && tHit <= tFar) {
                         hit = true;
-                        color = shade_hit(P, r, nd.x, nd.y, nd.z, nd.size);
+                        shade = shade_term(P, r, nd.x, nd.y, nd.z, nd.size);
                         break;
                     }
                 }
@@ -260,7 +275,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_generic(RenderParams P, const 
         }
     }
     if (MODE == kModeColor) {
-        if (valid) out[(size_t)ly * P.W + px] = color;
+        if (valid) out[(size_t)ly * P.W + px] = shade_color(shade);
+    } else if (MODE == kModeShade) {
+        if (valid) reinterpret_cast<float*>(out)[(size_t)ly * P.W + px] = shade;
     } else {
         if (inImage) stepsOut[(size_t)py * P.W + px] = hit ? steps : -steps;
         wave_accumulate(counters, steps, hit, inImage);
@@ -400,7 +417,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed(RenderParams P, const u
     }
     if (!hit && steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
 
-    if (MODE == kModeColor || MODE == kModeTimeline) {
+    if (MODE == kModeShade) {
+        if (valid) reinterpret_cast<float*>(out)[(size_t)ly * P.W + px] = hit ? shade_term(P, r, hx, hy, hz, hs) : kShadeMiss;
+    } else if (MODE == kModeColor || MODE == kModeTimeline) {
         if (valid) {
             float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
             if (hit) color = shade_hit(P, r, hx, hy, hz, hs);
@@ -657,7 +676,9 @@ __global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3(Ren
         if (trips > 0) atomicAdd(&P.tileHist[(tile >> 10) * kCostBuckets + cost_bucket(trips)], 1);
     }
 
-    if (MODE == kModeColor || MODE == kModeTimeline) {
+    if (MODE == kModeShade) {
+        if (valid) reinterpret_cast<float*>(out)[(size_t)ly * P.W + px] = hit ? shade_term(P, r, cx, cy, cz, P.rootSize >> lvl) : kShadeMiss;
+    } else if (MODE == kModeColor || MODE == kModeTimeline) {
         if (valid) {
             float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
             if (hit) color = shade_hit(P, r, cx, cy, cz, P.rootSize >> lvl);
@@ -939,7 +960,7 @@ __device__ __forceinline__ TriHit trace_triangles(const RenderParams& P, const T
     return h;
 }
 
-template <int MODE>
+template <int MODE, bool SHADE>
 __global__ __launch_bounds__(kBlock) void k_trace_triangles(RenderParams P, TriScene S, int shadow, float4* __restrict__ out,
                                                              Counters* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
@@ -950,7 +971,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_triangles(RenderParams P, TriS
     const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
     const int py = global_row(P, ly);
     const bool inImage = valid && (py < P.H);
-    float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+    float shade = kShadeMiss;
     int steps = 0;
     bool hit = false;
     if (inImage) {
@@ -973,10 +994,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_triangles(RenderParams P, TriS
                 steps += sh.steps;
                 if (sh.hit) ndotl = 0.0f;
             }
-            color = make_float4(1.0f * ndotl + 0.1f, 0.8f * ndotl + 0.1f, 0.6f * ndotl + 0.1f, 1.0f);
+            shade = ndotl;
         }
     }
-    if (valid) out[(size_t)ly * P.W + px] = color;
+    if (valid) {
+        if (SHADE) reinterpret_cast<float*>(out)[(size_t)ly * P.W + px] = shade;
+        else out[(size_t)ly * P.W + px] = shade_color(shade);
+    }
     if (MODE == kModeSteps) {
         // counters: pops = steps of the primary + shadow traversals; capped = primary misses that ran into the cap
         unsigned long long pops = inImage ? (unsigned long long)steps : 0ull, hits = (inImage && hit) ? 1ull : 0ull;
@@ -1100,7 +1124,7 @@ __device__ __forceinline__ PTriHit trace_packed_triangles(const RenderParams& P,
     return h;
 }
 
-template <int MODE>
+template <int MODE, bool SHADE>
 __global__ __launch_bounds__(kBlock) void k_trace_packed_triangles(RenderParams P, PackedTriScene S, int shadow, float4* __restrict__ out,
                                                                     Counters* __restrict__ counters) {
     extern __shared__ uint4 lds_stack4[];   // [wave][level][lane]
@@ -1115,7 +1139,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed_triangles(RenderParams 
     const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
     const int py = global_row(P, ly);
     const bool inImage = valid && (py < P.H);
-    float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+    float shade = kShadeMiss;
     int steps = 0;
     bool hit = false;
     if (inImage) {
@@ -1138,10 +1162,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed_triangles(RenderParams 
                 steps += sh.steps;
                 if (sh.hit) ndotl = 0.0f;
             }
-            color = make_float4(1.0f * ndotl + 0.1f, 0.8f * ndotl + 0.1f, 0.6f * ndotl + 0.1f, 1.0f);
+            shade = ndotl;
         }
     }
-    if (valid) out[(size_t)ly * P.W + px] = color;
+    if (valid) {
+        if (SHADE) reinterpret_cast<float*>(out)[(size_t)ly * P.W + px] = shade;
+        else out[(size_t)ly * P.W + px] = shade_color(shade);
+    }
     if (MODE == kModeSteps) {
         unsigned long long pops = inImage ? (unsigned long long)steps : 0ull, hits = (inImage && hit) ? 1ull : 0ull;
         for (int off = 32; off > 0; off >>= 1) { pops += __shfl_down(pops, off); hits += __shfl_down(hits, off); }
@@ -1363,6 +1390,19 @@ __global__ void k_assemble(const float4* __restrict__ gathered, float4* __restri
         int part = gband % numParts, band = gband / numParts;
         size_t src = ((size_t)part * partRows + (size_t)band * bandRows + r) * W + x;
         frame[i] = gathered[src];
+    }
+}
+
+// Same re-interleave for the 4-byte shade payload, finishing the colour expression (shade_color) on the way.
+__global__ void k_assemble_shade(const float* __restrict__ gathered, float4* __restrict__ frame,
+                                 int W, int H, int numParts, int bandRows, int partRows) {
+    const size_t n = (size_t)W * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        int gband = y / bandRows, r = y - gband * bandRows;
+        int part = gband % numParts, band = gband / numParts;
+        size_t src = ((size_t)part * partRows + (size_t)band * bandRows + r) * W + x;
+        frame[i] = shade_color(gathered[src]);
     }
 }
 

@@ -28,7 +28,8 @@ SYMBOLS = (
     "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel", "rto_set_launch_order",
     "rto_update_frustum", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
-    "rto_upload_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host",
+    "rto_render_shade_device", "rto_assemble_shade_device",
+    "rto_upload_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
 )
 
@@ -101,6 +102,9 @@ def load():
     L.rto_render_host.argtypes = [vp, C.POINTER(Frame), vp]
     L.rto_partition_rows.argtypes = [C.POINTER(Frame), C.POINTER(Partition)]
     L.rto_assemble_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp, vp]
+    L.rto_render_shade_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp]
+    L.rto_assemble_shade_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp, vp]
+    L.rto_render_triangles_shade_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), C.c_int, vp, vp]
     L.rto_frame_stats.argtypes = [vp, C.POINTER(Frame), C.POINTER(Stats)]
     L.rto_upload_leaf_triangles.argtypes = [vp, vp, C.c_int64, vp]
     L.rto_render_triangles_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), C.c_int, vp, vp]
@@ -235,6 +239,15 @@ class Context:
         self._check(self._L.rto_assemble_device(self._h, C.byref(frame), C.byref(part), C.c_void_p(d_gathered),
                                                 C.c_void_p(d_frame), C.c_void_p(stream) if stream else None))
 
+    def render_shade_device(self, frame: Frame, d_shade: int, part: Partition | None = None, stream: int = 0):
+        """4 bytes per pixel (Lambert term of the hit, -1 = miss): the multi-GPU gather payload."""
+        self._check(self._L.rto_render_shade_device(self._h, C.byref(frame), C.byref(part) if part else None,
+                                                    C.c_void_p(d_shade), C.c_void_p(stream) if stream else None))
+
+    def assemble_shade_device(self, frame: Frame, part: Partition, d_gathered: int, d_frame: int, stream: int = 0):
+        self._check(self._L.rto_assemble_shade_device(self._h, C.byref(frame), C.byref(part), C.c_void_p(d_gathered),
+                                                      C.c_void_p(d_frame), C.c_void_p(stream) if stream else None))
+
     def partition_rows(self, frame: Frame, part: Partition | None) -> int:
         return self._L.rto_partition_rows(C.byref(frame), C.byref(part) if part else None)
 
@@ -255,6 +268,10 @@ class Context:
     def render_triangles_device(self, frame: Frame, d_out: int, shadow: bool = True, part: Partition | None = None, stream: int = 0):
         self._check(self._L.rto_render_triangles_device(self._h, C.byref(frame), C.byref(part) if part else None,
                                                         1 if shadow else 0, C.c_void_p(d_out), C.c_void_p(stream) if stream else None))
+
+    def render_triangles_shade_device(self, frame: Frame, d_shade: int, shadow: bool = True, part: Partition | None = None, stream: int = 0):
+        self._check(self._L.rto_render_triangles_shade_device(self._h, C.byref(frame), C.byref(part) if part else None,
+                                                              1 if shadow else 0, C.c_void_p(d_shade), C.c_void_p(stream) if stream else None))
 
     def octree_ray_skip(self, ro, rd, t_min=0.0, t_max=1e30, use_visibility=False) -> np.ndarray:
         """octreeRaySkip (VolumeRaycastRenderer.cpp:50-155) for n rays sharing the origin ro; rd: (n, 3)."""

@@ -3,8 +3,16 @@
 No reference counterpart (the reference is single-GPU).  Every rank holds the whole
 octree (<= 90 MB) and renders the bands `b % world == rank` of the image (bands of `band_rows` rows,
 round-robin so that the lit centre rows are spread over all ranks) into a compact buffer; a single
-`torch.distributed.gather` to rank 0 (RCCL over xGMI: 7 point-to-point links into the root, W*H*16/N bytes
-each) delivers the buffers, and rank 0 re-interleaves them with one copy kernel (rto_assemble_device).
+`torch.distributed.gather` to rank 0 (RCCL over xGMI: 7 point-to-point links into the root) delivers the
+buffers, and rank 0 re-interleaves them with one kernel.
+
+Two things keep the xGMI links and the root GPU off the critical path:
+  payload   "shade" (default): a part ships ONE float per pixel -- the Lambert term of the hit, -1 for a miss
+            (rto_render_shade_device) -- and rank 0 finishes the colour expression while it re-interleaves
+            (rto_assemble_shade_device): W*H*4/N bytes per link instead of W*H*16/N, bit-identical frame.
+            "rgba": the plain RGBA32F pixels (rto_render_device / rto_assemble_device).
+  pipeline  submit()/flush(): the gather of frame k runs on RCCL's stream while this rank already renders its
+            part of frame k+1 (double-buffered local buffers); render() is the one-frame-at-a-time form.
 
 The class is backend-agnostic so the rank/partition/gather logic can be exercised with gloo on CPU:
   HipBackend     device buffers + the C ABI (the product path)
@@ -52,79 +60,139 @@ class HipBackend:
         self.ctx = ctx
         self.device = torch.device("cuda", ctx.device)
 
+    def _stream(self) -> int:
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
     def empty(self, shape):
         return self.torch.empty(shape, dtype=self.torch.float32, device=self.device)
 
-    def render_part(self, frame: hip.Frame, part: hip.Partition | None, out):
-        self.ctx.render_device(frame, out.data_ptr(), part, self.torch.cuda.current_stream(self.device).cuda_stream)
+    def render_part(self, frame: hip.Frame, part: hip.Partition | None, out, payload: str = "rgba"):
+        if payload == "shade":
+            self.ctx.render_shade_device(frame, out.data_ptr(), part, self._stream())
+        else:
+            self.ctx.render_device(frame, out.data_ptr(), part, self._stream())
 
-    def assemble(self, frame: hip.Frame, part0: hip.Partition, gathered, out):
-        self.ctx.assemble_device(frame, part0, gathered.data_ptr(), out.data_ptr(),
-                                 self.torch.cuda.current_stream(self.device).cuda_stream)
+    def assemble(self, frame: hip.Frame, part0: hip.Partition, gathered, out, payload: str = "rgba"):
+        if payload == "shade":
+            self.ctx.assemble_shade_device(frame, part0, gathered.data_ptr(), out.data_ptr(), self._stream())
+        else:
+            self.ctx.assemble_device(frame, part0, gathered.data_ptr(), out.data_ptr(), self._stream())
 
 
 @dataclass
 class _Buffers:
     key: tuple
-    local: object
-    gathered: object
+    local: list          # two compact part buffers (double-buffered for the pipelined form)
+    gathered: object     # rank 0: world x part-0-sized buffers, as the gather delivers them
+    frame: object        # rank 0: the assembled RGBA32F frame
+
+
+@dataclass
+class _InFlight:
+    work: object         # the gather's Work handle (None for the blocking host-staged form)
     frame: object
+    keep: object         # tensors that must outlive the gather
 
 
 class TileSplitRenderer:
-    """renders `frame` cooperatively; rank 0 gets the (H, W, 4) image, the others None.
+    """Renders `frame` cooperatively; rank 0 gets the (H, W, 4) image, the others None.
+
+    render(frame)            one frame at a time (everything stream-ordered, no host sync)
+    submit(frame) / flush()  pipelined: submit(k) returns the image of frame k-1 (None for the first call),
+                             flush() the last one; the returned tensor is overwritten by the next assemble.
 
     `stage_through_host=True` moves the gather payload through CPU tensors: only for rehearsing the multi-rank
     path with the gloo backend (e.g. several ranks sharing one GPU); the product path gathers device to device."""
 
-    def __init__(self, backend, rank: int, world_size: int, band_rows: int = 16, group=None, stage_through_host: bool = False):
+    def __init__(self, backend, rank: int, world_size: int, band_rows: int = 16, group=None, stage_through_host: bool = False,
+                 payload: str = "shade"):
         if band_rows <= 0 or band_rows % 8:
             raise ValueError("band_rows must be a positive multiple of 8")
+        if payload not in ("shade", "rgba"):
+            raise ValueError("payload must be 'shade' or 'rgba'")
         self.backend = backend
         self.rank = rank
         self.world = world_size
         self.band_rows = band_rows
         self.group = group
         self.stage_through_host = stage_through_host
+        self.payload = payload
         self._buf: _Buffers | None = None
+        self._seq = 0
+        self._inflight: _InFlight | None = None
 
     def partition(self, part: int | None = None) -> hip.Partition:
         return hip.Partition(self.world, self.rank if part is None else part, self.band_rows)
 
+    def _part_shape(self, rows: int, width: int) -> tuple:
+        return (rows, width) if self.payload == "shade" else (rows, width, 4)
+
     def _buffers(self, frame: hip.Frame) -> _Buffers:
         key = (frame.width, frame.height)
         if self._buf is None or self._buf.key != key:
-            rows0 = partition_rows(frame.height, self.world, 0, self.band_rows)   # part 0 owns the most rows
-            local = self.backend.empty((rows0, frame.width, 4))
+            if self._inflight is not None:
+                raise RuntimeError("frame size changed with a frame in flight: call flush() first")
             gathered = frm = None
+            local = []
             if self.rank == 0:
                 frm = self.backend.empty((frame.height, frame.width, 4))
-                gathered = self.backend.empty((self.world, rows0, frame.width, 4)) if self.world > 1 else None
+            if self.world > 1:
+                rows0 = partition_rows(frame.height, self.world, 0, self.band_rows)   # part 0 owns the most rows
+                local = [self.backend.empty(self._part_shape(rows0, frame.width)) for _ in range(2)]
+                if self.rank == 0:
+                    gathered = self.backend.empty((self.world,) + self._part_shape(rows0, frame.width))
             self._buf = _Buffers(key, local, gathered, frm)
         return self._buf
 
-    def render(self, frame: hip.Frame):
-        b = self._buffers(frame)
-        if self.world == 1:
-            self.backend.render_part(frame, None, b.frame)
-            return b.frame
+    # ---- the three steps of a frame ---------------------------------------------------------------
+    def _issue_gather(self, b: _Buffers, local, frame) -> _InFlight:
         import torch.distributed as dist
 
-        self.backend.render_part(frame, self.partition(), b.local)
         if self.stage_through_host:
-            local = b.local.cpu()
-            if self.rank == 0:
-                parts = [local.new_empty(local.shape) for _ in range(self.world)]
-                dist.gather(local, parts, dst=0, group=self.group)
-                for i, p in enumerate(parts):
-                    b.gathered[i].copy_(p)
-                self.backend.assemble(frame, self.partition(0), b.gathered, b.frame)
-                return b.frame
-            dist.gather(local, None, dst=0, group=self.group)
+            src = local.cpu()
+            parts = [src.new_empty(src.shape) for _ in range(self.world)] if self.rank == 0 else None
+            work = dist.gather(src, parts, dst=0, group=self.group, async_op=True)
+            return _InFlight(work, frame, (src, parts))
+        parts = [b.gathered[i] for i in range(self.world)] if self.rank == 0 else None
+        work = dist.gather(local, parts, dst=0, group=self.group, async_op=True)
+        return _InFlight(work, frame, (local, parts))
+
+    def _complete(self, b: _Buffers, fl: _InFlight):
+        fl.work.wait()          # RCCL: the current stream waits for the gather; gloo: the host does
+        if self.rank != 0:
             return None
-        if self.rank == 0:
-            dist.gather(b.local, [b.gathered[i] for i in range(self.world)], dst=0, group=self.group)
-            self.backend.assemble(frame, self.partition(0), b.gathered, b.frame)
+        if self.stage_through_host:
+            for i, p in enumerate(fl.keep[1]):
+                b.gathered[i].copy_(p)
+        self.backend.assemble(fl.frame, self.partition(0), b.gathered, b.frame, self.payload)
+        return b.frame
+
+    # ---- public ------------------------------------------------------------------------------------
+    def submit(self, frame: hip.Frame):
+        b = self._buffers(frame)
+        if self.world == 1:
+            self.backend.render_part(frame, None, b.frame, "rgba")
             return b.frame
-        dist.gather(b.local, None, dst=0, group=self.group)
-        return None
+        local = b.local[self._seq % 2]
+        self._seq += 1
+        self.backend.render_part(frame, self.partition(), local, self.payload)     # overlaps the gather in flight
+        done = None
+        if self._inflight is not None:
+            done = self._complete(b, self._inflight)       # ... and only now waits for it
+            self._inflight = None
+        self._inflight = self._issue_gather(b, local, frame)
+        return done
+
+    def flush(self):
+        if self.world == 1:
+            return self._buf.frame if self._buf is not None else None
+        if self._inflight is None:
+            return None
+        fl, self._inflight = self._inflight, None
+        return self._complete(self._buf, fl)
+
+    def render(self, frame: hip.Frame):
+        if self._inflight is not None:
+            raise RuntimeError("render() with a pipelined frame in flight: call flush() first")
+        self.submit(frame)
+        return self.flush()

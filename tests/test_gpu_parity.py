@@ -268,6 +268,44 @@ def test_partitions_assemble_to_the_full_frame(ctx, orc, scenes, camera):
             assert_bit_exact(frame.cpu().numpy(), want, f"{W}x{H} parts={nparts} band={band}")
 
 
+def test_shade_payload_assembles_to_the_same_frame(ctx, orc, scenes, camera):
+    """The 4-byte multi-GPU payload: every kernel writes the Lambert term (-1 = miss) per pixel of its part,
+    rto_assemble_shade_device finishes the colour expression while re-interleaving -- bit-identical to the
+    RGBA32F path and to the oracle, whole-frame and split 2/3/8 ways; also through the TileSplitRenderer."""
+    torch = pytest.importorskip("torch")
+    from ray_tracing_octrees_amd import tilesplit
+
+    for scene, cam in (("sphere64", "sphere"), ("calgary", "calgary_oblique")):
+        s = scenes(scene)
+        view, pos = camera(cam)
+        upload(ctx, s)
+        W, H = 417, 250
+        f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+        want, _ = oracle_frame(orc, s, view, pos, W, H)
+        for kname, kernel in KERNELS:
+            ctx.set_kernel(kernel)
+            for nparts, band in ((1, 16), (2, 16), (3, 8), (8, 24)):
+                rows0 = ctx.partition_rows(f, hip.Partition(nparts, 0, band)) if nparts > 1 else H
+                gathered = torch.full((nparts, rows0, W), 7.0, dtype=torch.float32, device="cuda")
+                for p in range(nparts):
+                    ctx.render_shade_device(f, gathered[p].data_ptr(), hip.Partition(nparts, p, band) if nparts > 1 else None)
+                frame = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+                ctx.assemble_shade_device(f, hip.Partition(nparts, 0, band), gathered.data_ptr(), frame.data_ptr())
+                ctx.synchronize()
+                assert_bit_exact(frame.cpu().numpy(), want, f"{scene} {kname} shade payload, parts={nparts}")
+                if nparts == 1:
+                    sh = gathered[0].cpu().numpy()
+                    hit = want[..., 0] != 0
+                    assert ((sh == -1.0) == ~hit).all() and (sh[hit] >= 0).all()
+        ctx.set_kernel(rto.KERNEL_AUTO)
+        # world size 1 through the renderer class (no process group needed): both payload settings give the frame
+        for payload in ("shade", "rgba"):
+            r = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), 0, 1, payload=payload)
+            img = r.render(f)
+            torch.cuda.synchronize()
+            assert_bit_exact(img.cpu().numpy(), want, f"{scene} TileSplitRenderer world 1 {payload}")
+
+
 def test_render_device_on_a_caller_stream(ctx, scenes, camera):
     torch = pytest.importorskip("torch")
     s = scenes("sphere32")
@@ -540,6 +578,16 @@ def test_config5_shadows_exist_and_partitions_agree(ctx, orc, scenes):
     ctx.assemble_device(f, hip.Partition(nparts, 0, band), gathered.data_ptr(), frame.data_ptr())
     ctx.synchronize()
     assert_bit_exact(frame.cpu().numpy(), shd, "triangle path, 3 parts")
+    # ... and with the 4-byte shade payload, on both triangle kernels
+    for kname, kernel in (("packed", rto.KERNEL_AUTO), ("generic", rto.KERNEL_GENERIC)):
+        ctx.set_kernel(kernel)
+        gs = torch.zeros((nparts, rows0, W), dtype=torch.float32, device="cuda")
+        for p in range(nparts):
+            ctx.render_triangles_shade_device(f, gs[p].data_ptr(), True, hip.Partition(nparts, p, band))
+        ctx.assemble_shade_device(f, hip.Partition(nparts, 0, band), gs.data_ptr(), frame.data_ptr())
+        ctx.synchronize()
+        assert_bit_exact(frame.cpu().numpy(), shd, f"triangle path, 3 parts, shade payload, {kname}")
+    ctx.set_kernel(rto.KERNEL_AUTO)
     # error paths
     fresh = rto.Context(0)
     fresh.upload_octree(scenes("sphere16").nodes, scenes("sphere16").min, scenes("sphere16").voxel)
