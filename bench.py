@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 NODE_BYTES = 60                # struct GPUNodes, the reference's node record (constant even if repacked)
 PIXEL_BYTES = 16               # RGBA32F
+SIMDS, CLOCK_GHZ, VALU_CYCLES_PER_WAVE_INST = 1024, 2.4, 2   # 256 CUs x 4 SIMD-32: a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
 
 
 def parse_args():
@@ -218,12 +219,21 @@ def main():
             pair_overhead = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
             achieved = rays * bytes_per_ray / (k_avg * 1e-3) / 1e9
             traffic = None
+            valu = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("dim") == args.dim and tj.get("width") == W and tj.get("height") == H:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    if tj.get("SQ_INSTS_VALU"):
+                        # the bound that actually holds (informational): wave-level VALU instructions (PMC) against the
+                        # chip's issue rate -- 1024 SIMDs x 2.4 GHz, 2 cycles per wave64 instruction (v_pk_* count once here but do two lanes' worth)
+                        insts = float(tj["SQ_INSTS_VALU"])
+                        floor_ms = insts * VALU_CYCLES_PER_WAVE_INST / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
+                        valu = {"wave_insts_per_launch": int(insts), "lane_utilisation": round(tj["SQ_THREAD_CYCLES_VALU"] / (64.0 * insts), 3),
+                                "issue_floor_ms": round(floor_ms, 5), "frac_of_issue_peak": round(floor_ms / k_avg, 3),
+                                "model": f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz, {VALU_CYCLES_PER_WAVE_INST} cycles per wave64 VALU instruction"}
             roofline = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -236,6 +246,8 @@ def main():
                 "note": "algorithmic bytes = pops x 60 B reference node + 16 B pixel (SURVEY 8d); the packed kernel "
                         "reads 8-byte descriptors of internal nodes only, so frac may exceed 1: the real bound is VALU",
             }
+            if valu is not None:
+                roofline["valu"] = valu
         pcie = None
         if world == 1:
             # the C ABI's host-buffer entry point (kernel + 33 MB D2H over PCIe): informational, never `value`

@@ -58,7 +58,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     deps = _sources(CSRC, (".hip", ".h")) + [os.path.join(HOST, "rtmath.h"), os.path.join(ROOT, "include", "rto_hip.h")]
     if not force and _newer(LIB_HIP, deps):
         return LIB_HIP
-    cmd = [hipcc, *HIP_FLAGS, os.path.join(CSRC, "rto_api.hip"), "-o", LIB_HIP]
+    extra = os.environ.get("RTO_HIP_EXTRA_FLAGS", "").split()      # developer aid: A/B builds such as -DRTO_STAMP
+    cmd = [hipcc, *HIP_FLAGS, *extra, os.path.join(CSRC, "rto_api.hip"), "-o", LIB_HIP]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

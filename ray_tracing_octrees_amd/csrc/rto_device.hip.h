@@ -520,13 +520,17 @@ __device__ __forceinline__ unsigned child_pass_mask_fast(const RenderParams& P, 
     // fold "tFar > 0" and "tNear < 1e30" into the x terms
     tmn[0][0] = __builtin_fmaxf(tmn[0][0], kEps); tmn[0][1] = __builtin_fmaxf(tmn[0][1], kEps);
     tmx[0][0] = __builtin_fminf(tmx[0][0], kBelow1e30); tmx[0][1] = __builtin_fminf(tmx[0][1], kBelow1e30);
-    // 8 independent verdicts, OR-ed as a tree: a lone deep wave is bound by dependency depth, not op count
-#define RTO_CHILD(k) ((max3f(tmn[0][(k) & 1], tmn[1][((k) >> 1) & 1], tmn[2][(k) >> 2]) <= \
-                       min3f(tmx[0][(k) & 1], tmx[1][((k) >> 1) & 1], tmx[2][(k) >> 2])) ? (1u << (k)) : 0u)
-    const unsigned b0 = RTO_CHILD(0), b1 = RTO_CHILD(1), b2 = RTO_CHILD(2), b3 = RTO_CHILD(3);
-    const unsigned b4 = RTO_CHILD(4), b5 = RTO_CHILD(5), b6 = RTO_CHILD(6), b7 = RTO_CHILD(7);
-#undef RTO_CHILD
-    return (b0 | b1 | b2) | (b3 | b4 | b5) | (b6 | b7);
+    // verdict of child k = sign bit of (min3 - max3): no NaN can occur here, and a float difference carries the
+    // exact sign of the comparison (x - x is +0).  v_alignbit shifts the sign into an accumulator: two 4-deep chains.
+#define RTO_D(k) __float_as_uint(min3f(tmx[0][(k) & 1], tmx[1][((k) >> 1) & 1], tmx[2][(k) >> 2]) - \
+                                 max3f(tmn[0][(k) & 1], tmn[1][((k) >> 1) & 1], tmn[2][(k) >> 2]))
+    unsigned fa = 0, fb = 0;
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(7), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(3), 31);
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(6), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(2), 31);
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(5), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(1), 31);
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(4), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(0), 31);
+#undef RTO_D
+    return ~((fa << 4) | fb) & 0xffu;
 }
 
 // ================================================================ packed kernel, branch-free loop body

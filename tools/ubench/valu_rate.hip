@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <vector>
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int KIND, int CHAINS>
 __global__ void k(float* out, int iters, unsigned long long* cyc) {
     float a[CHAINS];
@@ -22,6 +24,22 @@ __global__ void k(float* out, int iters, unsigned long long* cyc) {
                 else if (KIND == 2) a[i] = __builtin_fmaxf(a[i], m) + 1.0f;    // v_max + v_add
                 else if (KIND == 3) u[i] = __builtin_popcount(u[i]) + u[i];    // v_bcnt (with add)
                 else if (KIND == 4) a[i] = (a[i] < m) ? a[i] + 1.0f : a[i] * 0.5f;  // cmp + add + mul + cndmask
+                else if (KIND == 5) {                                               // v_pk_mul_f32 + v_pk_add_f32 (2 ops, 2 chains' worth)
+                    if (i + 1 < CHAINS && (i & 1) == 0) {
+                        f32x2 v = { a[i], a[i + 1] };
+                        v = v * (f32x2){ m, m };
+                        asm volatile("" : "+v"(v));
+                        v = v + (f32x2){ 1.0f, 1.0f };
+                        a[i] = v.x; a[i + 1] = v.y;
+                    }
+                }
+                else if (KIND == 6) {                                               // v_max3_f32 + v_min3_f32
+                    float t;
+                    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(a[i]), "v"(m), "v"(a[(i + 1) % CHAINS]));
+                    asm volatile("v_min3_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(t), "v"(m), "v"(a[(i + 2) % CHAINS]));
+                }
+                else if (KIND == 7) u[i] |= (a[i] <= m) ? (1u << (r & 7)) : 0u;     // v_cmp + v_cndmask + v_or (the RTO_CHILD shape)
+                else if (KIND == 8) a[i] = (float)(int)u[i] + a[i];                 // v_cvt_f32_i32 + v_add
             }
         }
     }
@@ -59,13 +77,17 @@ void run(const char* name, int opsPerStep, int wavesPerSimd) {
 }
 
 int main() {
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 4}) {
         run<0, 1>("fma dep-chain", 1, w);
         run<0, 8>("fma 8 chains", 1, w);
         run<1, 8>("and+add 8 chains", 2, w);
         run<2, 8>("max+add 8 chains", 2, w);
         run<3, 8>("bcnt 8 chains", 1, w);
         run<4, 8>("cmp/add/mul/cndmask", 4, w);
+        run<5, 8>("pk_mul+pk_add (per pk op)", 1, w);     // 8 chains = 4 pairs x 2 pk ops = 8 pk instructions per step
+        run<6, 8>("max3+min3", 2, w);
+        run<7, 8>("cmp+cndmask+or", 3, w);
+        run<8, 8>("cvt_f32_i32+add", 2, w);
     }
     return 0;
 }
