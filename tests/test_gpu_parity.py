@@ -306,6 +306,67 @@ def test_shade_payload_assembles_to_the_same_frame(ctx, orc, scenes, camera):
             assert_bit_exact(img.cpu().numpy(), want, f"{scene} TileSplitRenderer world 1 {payload}")
 
 
+@pytest.mark.parametrize("scene,cam0,dtheta", [("sphere64", (0.5, 0.7, 1.8), 0.21), ("calgary", (0.6, 0.5, 3500.0), 0.35)])
+def test_temporal_launch_order_is_only_a_schedule(ctx, orc, scenes, scene, cam0, dtheta):
+    """The packed kernel launches its tiles in the order of an EARLIER frame's trip counts.  Whatever that table
+    holds -- stale (camera moved a lot), rebuilt every frame or every 4th, built for another image size or another
+    partition, or a hostile caller-supplied permutation -- every tile is rendered exactly once and the pixels are
+    the oracle's.  Frames go into a buffer pre-filled with a sentinel so that a skipped tile cannot hide."""
+    torch = pytest.importorskip("torch")
+    s = scenes(scene)
+    upload(ctx, s)
+    try:
+        for period in (1, 2, 4):
+            ctx.set_launch_order(1, period)
+            frame_no = 0
+            for (W, H) in ((400, 240), (333, 250), (400, 240)):
+                buf = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+                for k in range(6):
+                    c = orc.Camera(cam0[0] + dtheta * frame_no, cam0[1] + 0.03 * frame_no, cam0[2])
+                    frame_no += 1
+                    view, pos = c.get_view(), c.get_pos()
+                    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+                    want, _ = oracle_frame(orc, s, view, pos, W, H)
+                    buf.fill_(7.0)
+                    ctx.render_device(f, buf.data_ptr())
+                    ctx.synchronize()
+                    assert_bit_exact(buf.cpu().numpy(), want, f"{scene} period {period} {W}x{H} frame {k}")
+                    if k == 3:      # a partition render in between shares (and invalidates) the table
+                        part = hip.Partition(2, 1, 16)
+                        rows = ctx.partition_rows(f, part)
+                        pb = torch.full((rows, W, 4), 7.0, dtype=torch.float32, device="cuda")
+                        ctx.render_device(f, pb.data_ptr(), part)
+                        ctx.synchronize()
+                        from ray_tracing_octrees_amd import tilesplit
+                        assert_bit_exact(pb.cpu().numpy(), want[tilesplit.partition_row_map(H, 2, 1, 16)], f"{scene} part 1/2 mid-sequence")
+        # caller-supplied tables: reversed and random permutations
+        W, H = 400, 240
+        c = orc.Camera(*cam0)
+        view, pos = c.get_view(), c.get_pos()
+        f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+        want, _ = oracle_frame(orc, s, view, pos, W, H)
+        ctx.set_launch_order(1, 1)
+        ctx.render_host(f)
+        tiles = ((W + 7) // 8) * ((H + 7) // 8)
+        assert len(ctx.debug_tile_cost()) == tiles
+        rng = np.random.default_rng(5)
+        for order in (np.arange(tiles)[::-1], rng.permutation(tiles)):
+            ctx.debug_set_tile_order(order)
+            buf = torch.full((H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+            ctx.render_device(f, buf.data_ptr())
+            ctx.render_device(f, buf.data_ptr())
+            ctx.synchronize()
+            assert_bit_exact(buf.cpu().numpy(), want, f"{scene} caller-supplied order")
+        ctx.debug_set_tile_order(None)
+        assert_bit_exact(ctx.render_host(f), want, f"{scene} automatic order restored")
+        # centre-out policy
+        ctx.set_launch_order(0)
+        assert_bit_exact(ctx.render_host(f), want, f"{scene} centre-out")
+    finally:
+        ctx.debug_set_tile_order(None)
+        ctx.set_launch_order(1, 4)
+
+
 def test_render_device_on_a_caller_stream(ctx, scenes, camera):
     torch = pytest.importorskip("torch")
     s = scenes("sphere32")
