@@ -404,7 +404,7 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     RTO_HIP(c, scratch.alloc(&d_bbox, 6));
     const int initBox[6] = { 0x7fffffff, 0x7fffffff, 0x7fffffff, -0x7fffffff, -0x7fffffff, -0x7fffffff };
     RTO_HIP(c, hipMemcpyAsync(d_bbox, initBox, sizeof initBox, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_solid_bbox, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, c->d_nodes, total, d_bbox);
+    hipLaunchKernelGGL(k_solid_bbox, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, s, c->d_nodes, total, d_bbox);
     RTO_HIP(c, hipGetLastError());
     RTO_HIP(c, hipEventRecord(e2, s));
     int box[6];

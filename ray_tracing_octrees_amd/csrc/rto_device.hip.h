@@ -1359,15 +1359,17 @@ __global__ __launch_bounds__(kBlock) void k_build_emit(const int4* __restrict__ 
     nodes[levelBase + i] = nd;
 }
 
-// bounding box of the solid leaves (voxel units) for the launch-order heuristic: 6 atomics per wave
+// bounding box of the solid leaves (voxel units) for the launch-order heuristic.  Grid-stride over the nodes, one
+// wave reduction at the end and at most 6 atomics per wave that saw a solid leaf (same-address atomics serialise:
+// one set per 64 nodes cost 1 ms at 1.5 M nodes).
 __global__ __launch_bounds__(kBlock) void k_solid_bbox(const rto_node* __restrict__ nodes, int64_t n, int* __restrict__ bbox /* lo[3], hi[3] */) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
-    if (i < n) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const rto_node* nd = nodes + i;
         if ((nd->isLeaf == 1 || nd->isUniform == 1) && nd->isSolid == 1) {
-            lo[0] = nd->x; lo[1] = nd->y; lo[2] = nd->z;
-            hi[0] = nd->x + nd->size; hi[1] = nd->y + nd->size; hi[2] = nd->z + nd->size;
+            const int x = nd->x, y = nd->y, z = nd->z, sz = nd->size;
+            lo[0] = min(lo[0], x); lo[1] = min(lo[1], y); lo[2] = min(lo[2], z);
+            hi[0] = max(hi[0], x + sz); hi[1] = max(hi[1], y + sz); hi[2] = max(hi[2], z + sz);
         }
     }
 #pragma unroll
@@ -1377,7 +1379,7 @@ __global__ __launch_bounds__(kBlock) void k_solid_bbox(const rto_node* __restric
             hi[a] = max(hi[a], __shfl_down(hi[a], off));
         }
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && lo[0] != 0x7fffffff) {
 #pragma unroll
         for (int a = 0; a < 3; a++) { atomicMin(&bbox[a], lo[a]); atomicMax(&bbox[3 + a], hi[a]); }
     }
