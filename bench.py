@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 NODE_BYTES = 60                # struct GPUNodes, the reference's node record (constant even if repacked)
 PIXEL_BYTES = 16               # RGBA32F
+VALU_MIX_CYCLES = 2.85          # measured issue cost of the traversal loop's instruction mix
 SIMDS, CLOCK_GHZ, VALU_CYCLES_PER_WAVE_INST = 1024, 2.4, 2   # 256 CUs x 4 SIMD-32: a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
 
 
@@ -231,9 +232,13 @@ def main():
                         # chip's issue rate -- 1024 SIMDs x 2.4 GHz, 2 cycles per wave64 instruction (v_pk_* count once here but do two lanes' worth)
                         insts = float(tj["SQ_INSTS_VALU"])
                         floor_ms = insts * VALU_CYCLES_PER_WAVE_INST / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
+                        mix_ms = insts * VALU_MIX_CYCLES / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
                         valu = {"wave_insts_per_launch": int(insts), "lane_utilisation": round(tj["SQ_THREAD_CYCLES_VALU"] / (64.0 * insts), 3),
                                 "issue_floor_ms": round(floor_ms, 5), "frac_of_issue_peak": round(floor_ms / k_avg, 3),
-                                "model": f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz, {VALU_CYCLES_PER_WAVE_INST} cycles per wave64 VALU instruction"}
+                                "mix_weighted_floor_ms": round(mix_ms, 5), "frac_of_mix_weighted_peak": round(mix_ms / k_avg, 3),
+                                "model": f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz; issue floor at {VALU_CYCLES_PER_WAVE_INST} cycles per wave64 VALU instruction; "
+                                         f"mix-weighted at {VALU_MIX_CYCLES} (loop body: 27 v_pk_*, 16 v_max3/min3, 4 v_bcnt at ~4.3-4.5 cycles, "
+                                         f"~158 single-rate ops at ~2.4; tools/ubench/valu_rate.hip)"}
             roofline = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -7,6 +7,7 @@
 #include "../host/rtmath.h"
 
 #include <algorithm>
+#include <map>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -46,18 +47,25 @@ struct rto_context {
     rto_node* d_compact = nullptr;
     int64_t visibleNodes = 0;
 
-    // temporal launch order (packed kernel): previous frame's per-tile cost -> this frame's slot->tile table
+    // temporal launch order (packed kernel): an earlier frame's per-tile cost -> this frame's slot->tile table.
+    // The tables are written and read by kernels in stream order, so every launch stream owns a set of its own:
+    // frames in flight on different streams of one context never share (or race on) a table.
     int orderPolicy = 1;            // 0 = centre-out only, 1 = temporal (falls back to centre-out without history)
-    int* d_tileCost = nullptr;
-    int* d_tileOrder = nullptr;
-    int* d_sortHist = nullptr;      // 2 x [sort blocks][kCostBuckets], ping-pong
-    int histPing = 0;
-    int orderTiles = 0;             // tile count the buffers are sized for
-    long orderKey[6] = { 0, 0, 0, 0, 0, 0 };   // W, H, numParts, part, bandRows, tiles of the frame the history belongs to
-    bool orderValid = false;
-    bool orderFixed = false;        // debug: the caller supplied the table, do not rebuild it
     int orderPeriod = 4;            // rebuild the table every orderPeriod-th frame (cost maps change slowly)
-    int orderAge = 0;               // frames rendered since the table was built
+    struct OrderState {
+        int* d_tileCost = nullptr;
+        int* d_tileOrder = nullptr;
+        int* d_sortHist = nullptr;      // 2 x [sort blocks][kCostBuckets], ping-pong
+        int histPing = 0;
+        int tiles = 0;                  // tile count the buffers are sized for
+        long key[6] = { 0, 0, 0, 0, 0, 0 };   // W, H, numParts, part, bandRows, tiles of the frame the history belongs to
+        bool valid = false;
+        bool fixed = false;             // debug: the caller supplied the table, do not rebuild it
+        int age = 0;                    // frames rendered since the table was built
+    };
+    std::map<hipStream_t, OrderState> orders;
+    hipStream_t lastOrderStream = nullptr;      // what the rto_debug_* order functions refer to
+    static constexpr size_t kMaxOrderStreams = 16;   // further streams render centre-out
 
     // leaf triangles (config 5 extension)
     float* d_tris = nullptr;
@@ -112,7 +120,7 @@ static void free_octree(rto_context* c) {
     (void)hipFree(c->d_tris); c->d_tris = nullptr;
     (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
     c->numTris = 0;
-    c->orderValid = false;
+    for (auto& kv : c->orders) kv.second.valid = false;
     c->numNodes = c->numInternal = 0;
     c->canonical = false; c->culling = false; c->rootVisible = 1; c->visibleNodes = 0;
 }
@@ -161,9 +169,8 @@ void rto_destroy(rto_context* c) {
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_rayX);
     (void)hipFree(c->d_rayY);
-    (void)hipFree(c->d_tileCost);
-    (void)hipFree(c->d_tileOrder);
-    (void)hipFree(c->d_sortHist);
+    for (auto& kv : c->orders) { (void)hipFree(kv.second.d_tileCost); (void)hipFree(kv.second.d_tileOrder); (void)hipFree(kv.second.d_sortHist); }
+    c->orders.clear();
     (void)hipFree(c->d_steps);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_visibleCount);
@@ -441,28 +448,36 @@ int rto_download_nodes(rto_context* c, rto_node* out, int64_t capacity, int64_t*
 
 int rto_debug_tile_cost(rto_context* c, int32_t* host_cost, int64_t capacity, int64_t* count) {
     if (!c || !count) return RTO_E_INVALID;
-    *count = c->orderTiles;
+    auto it = c->orders.find(c->lastOrderStream);
+    *count = it == c->orders.end() ? 0 : it->second.tiles;
     if (!host_cost) return RTO_OK;
-    if (capacity < c->orderTiles || !c->d_tileCost) return fail(c, RTO_E_INVALID, "rto_debug_tile_cost: nothing recorded / capacity");
+    if (it == c->orders.end() || capacity < it->second.tiles || !it->second.d_tileCost)
+        return fail(c, RTO_E_INVALID, "rto_debug_tile_cost: nothing recorded / capacity");
     RTO_HIP(c, hipDeviceSynchronize());
-    RTO_HIP(c, hipMemcpy(host_cost, c->d_tileCost, (size_t)c->orderTiles * sizeof(int), hipMemcpyDeviceToHost));
+    RTO_HIP(c, hipMemcpy(host_cost, it->second.d_tileCost, (size_t)it->second.tiles * sizeof(int), hipMemcpyDeviceToHost));
     return RTO_OK;
 }
 
 int rto_debug_set_tile_order(rto_context* c, const int32_t* host_order, int64_t n) {
     if (!c) return RTO_E_INVALID;
+    auto it = c->orders.find(c->lastOrderStream);
     if (!host_order) {
-        c->orderFixed = false; c->orderValid = false;
-        if (c->d_sortHist) {
+        if (it == c->orders.end()) return RTO_OK;
+        rto_context::OrderState& o = it->second;
+        o.fixed = false; o.valid = false;
+        if (o.d_sortHist) {
             RTO_HIP(c, hipDeviceSynchronize());
-            RTO_HIP(c, hipMemset(c->d_sortHist, 0, (size_t)((c->orderTiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * 2 * sizeof(int)));
+            RTO_HIP(c, hipMemset(o.d_sortHist, 0, (size_t)((o.tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * 2 * sizeof(int)));
         }
         return RTO_OK;
     }
-    if (n != c->orderTiles || !c->d_tileOrder) return fail(c, RTO_E_INVALID, "rto_debug_set_tile_order: render one frame first; n must equal the tile count");
+    if (it == c->orders.end() || n != it->second.tiles || !it->second.d_tileOrder)
+        return fail(c, RTO_E_INVALID, "rto_debug_set_tile_order: render one frame first; n must equal the tile count");
+    for (int64_t i = 0; i < n; i++)
+        if (host_order[i] < 0 || host_order[i] >= n) return fail(c, RTO_E_INVALID, "rto_debug_set_tile_order: entry out of range");
     RTO_HIP(c, hipDeviceSynchronize());
-    RTO_HIP(c, hipMemcpy(c->d_tileOrder, host_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-    c->orderFixed = true; c->orderValid = true;
+    RTO_HIP(c, hipMemcpy(it->second.d_tileOrder, host_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    it->second.fixed = true; it->second.valid = true;
     return RTO_OK;
 }
 
@@ -472,8 +487,7 @@ int rto_set_launch_order(rto_context* c, int policy, int refresh_period) {
     if (refresh_period < 0) return fail(c, RTO_E_INVALID, "rto_set_launch_order: refresh_period must be >= 0 (0 keeps the current one)");
     c->orderPolicy = policy;
     if (refresh_period > 0) c->orderPeriod = refresh_period;
-    c->orderValid = false;
-    c->orderAge = 0;
+    for (auto& kv : c->orders) { kv.second.valid = false; kv.second.age = 0; }
     return RTO_OK;
 }
 
@@ -697,37 +711,45 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             bool recordCost = false;
             const bool useOrder = c->orderPolicy == RTO_ORDER_TEMPORAL && (MODE == kModeColor || MODE == kModeShade || MODE == kModeTimeline) &&
                                   (size_t)((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * sizeof(int) <= 96 * 1024;   // table must fit LDS
+            rto_context::OrderState* o = nullptr;
             if (useOrder) {
-                if (c->orderTiles != tiles) {
-                    (void)hipFree(c->d_tileCost); (void)hipFree(c->d_tileOrder); c->d_tileCost = c->d_tileOrder = nullptr; c->orderTiles = 0;
-                    RTO_HIP(c, hipMalloc(&c->d_tileCost, (size_t)tiles * sizeof(int)));
-                    RTO_HIP(c, hipMalloc(&c->d_tileOrder, (size_t)tiles * sizeof(int)));
-                    (void)hipFree(c->d_sortHist); c->d_sortHist = nullptr;
+                auto it = c->orders.find(s);
+                if (it != c->orders.end()) o = &it->second;
+                else if (c->orders.size() < rto_context::kMaxOrderStreams) o = &c->orders[s];
+            }
+            if (o) {
+                c->lastOrderStream = s;
+                if (o->tiles != tiles) {
+                    // hipFree waits for the device: no kernel still reads the old tables
+                    (void)hipFree(o->d_tileCost); (void)hipFree(o->d_tileOrder); (void)hipFree(o->d_sortHist);
+                    o->d_tileCost = o->d_tileOrder = o->d_sortHist = nullptr; o->tiles = 0;
+                    RTO_HIP(c, hipMalloc(&o->d_tileCost, (size_t)tiles * sizeof(int)));
+                    RTO_HIP(c, hipMalloc(&o->d_tileOrder, (size_t)tiles * sizeof(int)));
                     const size_t histInts = (size_t)((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * 2;   // ping-pong
-                    RTO_HIP(c, hipMalloc(&c->d_sortHist, histInts * sizeof(int)));
-                    RTO_HIP(c, hipMemsetAsync(c->d_sortHist, 0, histInts * sizeof(int), s));
-                    c->histPing = 0;
-                    c->orderTiles = tiles; c->orderValid = false; c->orderFixed = false;
+                    RTO_HIP(c, hipMalloc(&o->d_sortHist, histInts * sizeof(int)));
+                    RTO_HIP(c, hipMemsetAsync(o->d_sortHist, 0, histInts * sizeof(int), s));
+                    o->histPing = 0;
+                    o->tiles = tiles; o->valid = false; o->fixed = false;
                 }
-                if (std::memcmp(key, c->orderKey, sizeof key) != 0) { c->orderValid = false; c->orderFixed = false; std::memcpy(c->orderKey, key, sizeof key); }
-                Q.tileOrder = c->orderValid ? c->d_tileOrder : nullptr;
+                if (std::memcmp(key, o->key, sizeof key) != 0) { o->valid = false; o->fixed = false; std::memcpy(o->key, key, sizeof key); }
+                Q.tileOrder = o->valid ? o->d_tileOrder : nullptr;
                 // costs are recorded only by the frame whose epilogue is followed by a rebuild
-                recordCost = (MODE == kModeColor || MODE == kModeShade) && !c->orderFixed && (!c->orderValid || c->orderAge + 1 >= c->orderPeriod);
-                Q.tileCost = recordCost ? c->d_tileCost : nullptr;
-                Q.tileHist = c->d_sortHist + (size_t)c->histPing * ((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets;
+                recordCost = (MODE == kModeColor || MODE == kModeShade) && !o->fixed && (!o->valid || o->age + 1 >= c->orderPeriod);
+                Q.tileCost = recordCost ? o->d_tileCost : nullptr;
+                Q.tileHist = o->d_sortHist + (size_t)o->histPing * ((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets;
             }
             hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             RTO_HIP(c, hipEventRecord(evB, s));       // the traversal kernel alone; the order kernel follows
             stopRecorded = true;
-            if (useOrder && (MODE == kModeColor || MODE == kModeShade) && !recordCost) c->orderAge++;
-            if (useOrder && recordCost) {
+            if (o && (MODE == kModeColor || MODE == kModeShade) && !recordCost) o->age++;
+            if (o && recordCost) {
                 const int nsb = (tiles + kSortBlock - 1) / kSortBlock;
-                int* cur = c->d_sortHist + (size_t)c->histPing * nsb * kCostBuckets;
-                int* nxt = c->d_sortHist + (size_t)(1 - c->histPing) * nsb * kCostBuckets;
-                hipLaunchKernelGGL(k_sort_scatter, dim3(nsb), dim3(kSortBlock), (size_t)nsb * kCostBuckets * sizeof(int), s, c->d_tileCost, tiles, cur, nsb, c->d_tileOrder, nxt);
-                c->histPing = 1 - c->histPing;
-                c->orderValid = true;
-                c->orderAge = 0;
+                int* cur = o->d_sortHist + (size_t)o->histPing * nsb * kCostBuckets;
+                int* nxt = o->d_sortHist + (size_t)(1 - o->histPing) * nsb * kCostBuckets;
+                hipLaunchKernelGGL(k_sort_scatter, dim3(nsb), dim3(kSortBlock), (size_t)nsb * kCostBuckets * sizeof(int), s, o->d_tileCost, tiles, cur, nsb, o->d_tileOrder, nxt);
+                o->histPing = 1 - o->histPing;
+                o->valid = true;
+                o->age = 0;
             }
         }
     } else {

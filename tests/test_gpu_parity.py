@@ -367,6 +367,34 @@ def test_temporal_launch_order_is_only_a_schedule(ctx, orc, scenes, scene, cam0,
         ctx.set_launch_order(1, 4)
 
 
+def test_frames_in_flight_on_several_streams_of_one_context(ctx, orc, scenes):
+    """Three HIP streams render interleaved frames of one context without any host sync in between; every stream
+    owns its launch-order tables (rebuilt after every frame here), so nothing is shared between frames in flight."""
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere64")
+    upload(ctx, s)
+    W, H = 640, 360
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    bufs = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(3)]
+    cams = [orc.Camera(0.5 + 0.3 * i, 0.7, 1.8 + 0.1 * i) for i in range(3)]
+    frames = [rto.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H) for c in cams]
+    wants = [oracle_frame(orc, s, c.get_view(), c.get_pos(), W, H)[0] for c in cams]
+    try:
+        for period in (1, 3):
+            ctx.set_launch_order(1, period)
+            for b in bufs:
+                b.fill_(7.0)
+            torch.cuda.synchronize()
+            for k in range(60):
+                i = k % 3
+                ctx.render_device(frames[i], bufs[i].data_ptr(), None, streams[i].cuda_stream)
+            torch.cuda.synchronize()
+            for i in range(3):
+                assert_bit_exact(bufs[i].cpu().numpy(), wants[i], f"stream {i}, period {period}")
+    finally:
+        ctx.set_launch_order(1, 4)
+
+
 def test_render_device_on_a_caller_stream(ctx, scenes, camera):
     torch = pytest.importorskip("torch")
     s = scenes("sphere32")
