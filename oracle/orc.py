@@ -185,6 +185,10 @@ class Camera:
     def target(self):
         return np.array(list(self._c.target), np.float32)
 
+    def set_target(self, x, y, z):
+        """Camera::target is a public member upstream (S/Camera.h); tests aim the orbit camera at arbitrary grids."""
+        self._c.target[0], self._c.target[1], self._c.target[2] = float(np.float32(x)), float(np.float32(y)), float(np.float32(z))
+
 
 def mat4_inverse(m):
     out = np.zeros(16, np.float32)

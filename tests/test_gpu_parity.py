@@ -5,13 +5,14 @@ Bar: BIT-EXACT RGBA32F pixels (stricter than BASELINE.json's 1e-4 per channel --
 the north star is 1e-4; every comparison below asserts equality of the float bit patterns) and exact
 per-pixel traversal step counts (the reference's first-hit-in-DFS-order + 512-pop-cap semantics)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 import ray_tracing_octrees_amd as rto
 from ray_tracing_octrees_amd import hip
-from conftest import assert_bit_exact
+from conftest import Scene, assert_bit_exact
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4   # north-star tolerance; never reached: see assert_bit_exact
@@ -50,6 +51,69 @@ def test_pixels_and_steps_match_oracle(ctx, orc, scenes, camera, scene, W, H, kn
     np.testing.assert_array_equal(ctx.render_steps(f), orc.render_steps(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H))
     gs = ctx.frame_stats(f)
     assert (gs["rays"], gs["pops"], gs["hits"], gs["capped"]) == (W * H, st["pops"], st["hits"], st["capped"])
+
+
+def _random_grid(orc, rng):
+    """Random occupancy with structure at several scales (blobs, slabs, noise), random dims / origin / voxel size."""
+    dims = tuple(int(rng.integers(3, 41)) for _ in range(3))            # (dimX, dimY, dimZ), mostly not powers of two
+    dz, dy, dx = dims[2], dims[1], dims[0]
+    data = np.zeros((dz, dy, dx), np.uint8)
+    zz, yy, xx = np.meshgrid(np.arange(dz), np.arange(dy), np.arange(dx), indexing="ij")
+    for _ in range(int(rng.integers(1, 5))):                            # solid blobs -> large uniform leaves
+        c = rng.uniform(0, 1, 3) * (dz, dy, dx)
+        r = rng.uniform(1.5, 0.45 * max(dims))
+        data[(zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2 <= r * r] = 1
+    if rng.random() < 0.5:                                              # a thin slab
+        data[:, int(rng.integers(0, dy)), :] = 1
+    noise = rng.random(data.shape) < rng.choice([0.0, 0.02, 0.3])
+    data ^= noise.astype(np.uint8)                                      # salt and pepper -> depth to min-leaf 1
+    gmin = rng.uniform(-50, 50, 3).astype(np.float32)
+    voxel = np.float32(rng.choice([0.03125, 0.7, 1.0, 3.3]))
+    return orc.Grid(dims, gmin, voxel, data)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTO_FUZZ_SEEDS", "12"))))     # a larger sweep: RTO_FUZZ_SEEDS=400
+def test_fuzz_random_scenes_and_cameras(ctx, orc, seed):
+    """Seeded fuzz: random grids, cameras outside / inside / grazing, random image sizes, fov and aspect; every
+    kernel must reproduce the oracle's pixel bits, per-pixel step counts and frame counters; the triangle path too."""
+    rng = np.random.default_rng(1000 + seed)
+    g = _random_grid(orc, rng)
+    nodes = orc.build_flat_octree(g)
+    s = Scene(g, nodes)
+    upload(ctx, s)
+    ext = np.float32(max(g.dims)) * g.voxel_size
+    centre = g.min + 0.5 * np.array(g.dims, np.float32) * g.voxel_size
+    tris = off = None
+    for shot in range(3):
+        kind = ("outside", "inside", "grazing")[shot]
+        radius = float(ext * {"outside": rng.uniform(1.2, 4.0), "inside": rng.uniform(0.05, 0.45), "grazing": rng.uniform(0.7, 1.0)}[kind])
+        cam = orc.Camera(float(rng.uniform(0, 6.28)), float(rng.uniform(-1.4, 1.4)), radius)
+        cam.set_target(*[float(x) for x in centre + rng.uniform(-0.2, 0.2, 3).astype(np.float32) * ext])
+        view, pos = cam.get_view(), cam.get_pos()
+        W, H = int(rng.integers(1, 200)), int(rng.integers(1, 150))
+        fov = float(rng.choice([20.0, 45.0, 90.0, 120.0]))
+        aspect = float(rng.choice([W / H, 1.0, 2.5]))
+        f = rto.make_frame(view, pos, aspect, fov, W, H)
+        want, st = oracle_frame(orc, s, view, pos, W, H, aspect=aspect, fov=fov)
+        steps = orc.render_steps(s.nodes, s.min, s.voxel, view, pos, aspect, fov, W, H)
+        for kname, kernel in KERNELS:
+            ctx.set_kernel(kernel)
+            what = f"seed {seed} {kind} {g.dims} {W}x{H} fov {fov} {kname}"
+            assert_bit_exact(ctx.render_host(f), want, what)
+            np.testing.assert_array_equal(ctx.render_steps(f), steps, err_msg=what)
+            gs = ctx.frame_stats(f)
+            assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"]), what
+        if shot == 0:
+            tris, off = orc.build_leaf_triangles(s.grid, s.nodes)
+            ctx.upload_leaf_triangles(tris, off)
+        if len(tris):
+            wt, wst = orc.render_triangles(s.nodes, tris, off, s.min, s.voxel, view, pos, aspect, fov, W, H, shadow=True)
+            for kname, kernel in (("packed", rto.KERNEL_AUTO), ("generic", rto.KERNEL_GENERIC)):
+                ctx.set_kernel(kernel)
+                got, gs = ctx.render_triangles_host(f, shadow=True, stats=True)
+                assert_bit_exact(got, wt, f"seed {seed} {kind} triangles {kname}")
+                assert (gs["pops"], gs["hits"]) == (wst["pops"], wst["hits"]), f"seed {seed} {kind} triangles {kname}"
+    ctx.set_kernel(rto.KERNEL_AUTO)
 
 
 @pytest.mark.parametrize("kname,kernel", KERNELS)
