@@ -165,6 +165,14 @@ int  rto_assemble_shade_device(rto_context* ctx, const rto_frame* frame, const r
  * t > 0 in the leaf); shading = the reference's Lambert term on the ray-facing face normal; shadow != 0 adds one
  * ray towards the light (any hit => ambient only).  stats may be NULL (pops counts both traversals). */
 int  rto_upload_leaf_triangles(rto_context* ctx, const float* tris, int64_t num_tris, const int32_t* tri_offset);
+/* The same buffer built in HBM (replaces the CPU loop MarchingCubesRenderer::render -> localMC per leaf,
+ * S/Renderer.cpp:14-36, S/OctreeVoxel.cpp:780-879): identical triangles in identical order, for the resident octree.
+ * voxels: dimX*dimY*dimZ bytes (x fastest, 0 EMPTY / 1 FILLED) of the grid the octree was made from; NULL (dims
+ * ignored) reuses the voxels rto_build_octree kept in HBM.  rto_last_build_ms() then reports this build.
+ * rto_download_leaf_triangles copies the result out for parity checks (tris / tri_offset may be NULL). */
+int  rto_build_leaf_triangles(rto_context* ctx, const uint8_t* voxels, int dimX, int dimY, int dimZ);
+int  rto_download_leaf_triangles(rto_context* ctx, float* tris, int64_t tri_capacity, int32_t* tri_offset /* numNodes+1 */,
+                                 int64_t* num_tris);
 int  rto_render_triangles_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part, int shadow,
                                  void* d_out, void* hip_stream);
 int  rto_render_triangles_host(rto_context* ctx, const rto_frame* frame, int shadow, float* host_rgba, rto_stats* stats);

@@ -67,6 +67,11 @@ struct rto_context {
     hipStream_t lastOrderStream = nullptr;      // what the rto_debug_* order functions refer to
     static constexpr size_t kMaxOrderStreams = 16;   // further streams render centre-out
 
+    // voxels retained by rto_build_octree (so that rto_build_leaf_triangles can run without a second upload)
+    uint8_t* d_vox = nullptr;
+    int voxDim[3] = { 0, 0, 0 };
+    unsigned long long* d_mcCases = nullptr;    // 256 packed Marching-Cubes cases
+
     // leaf triangles (config 5 extension)
     float* d_tris = nullptr;
     int* d_triOffset = nullptr;
@@ -119,6 +124,8 @@ static void free_octree(rto_context* c) {
     (void)hipFree(c->d_compact); c->d_compact = nullptr;
     (void)hipFree(c->d_tris); c->d_tris = nullptr;
     (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
+    (void)hipFree(c->d_vox); c->d_vox = nullptr;
+    c->voxDim[0] = c->voxDim[1] = c->voxDim[2] = 0;
     c->numTris = 0;
     for (auto& kv : c->orders) kv.second.valid = false;
     c->numNodes = c->numInternal = 0;
@@ -171,6 +178,7 @@ void rto_destroy(rto_context* c) {
     (void)hipFree(c->d_rayY);
     for (auto& kv : c->orders) { (void)hipFree(kv.second.d_tileCost); (void)hipFree(kv.second.d_tileOrder); (void)hipFree(kv.second.d_sortHist); }
     c->orders.clear();
+    (void)hipFree(c->d_mcCases);
     (void)hipFree(c->d_steps);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_visibleCount);
@@ -332,7 +340,8 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     // ---- voxels -> HBM
     const size_t nvox = (size_t)dimX * dimY * dimZ;
     uint8_t* d_vox = nullptr;
-    RTO_HIP(c, scratch.alloc(&d_vox, nvox));
+    RTO_HIP(c, hipMalloc(&d_vox, nvox));
+    c->d_vox = d_vox; c->voxDim[0] = dimX; c->voxDim[1] = dimY; c->voxDim[2] = dimZ;    // kept: rto_build_leaf_triangles reads it
     RTO_HIP(c, hipEventRecord(e0, s));
     RTO_HIP(c, hipMemcpyAsync(d_vox, voxels, nvox, hipMemcpyHostToDevice, s));
     RTO_HIP(c, hipEventRecord(e1, s));
@@ -923,6 +932,121 @@ int rto_upload_leaf_triangles(rto_context* c, const float* tris, int64_t num_tri
         RTO_HIP(c, hipGetLastError());
         RTO_HIP(c, hipStreamSynchronize(c->stream));
     }
+    return RTO_OK;
+}
+
+}  // extern "C"
+
+namespace {
+#include "../host/mc_cases.inc"
+// 256 cases -> triangle count << 60 | edge nibbles (first edge lowest)
+void pack_mc_cases(unsigned long long out[256]) {
+    for (int i = 0; i < 256; i++) {
+        unsigned long long v = 0;
+        int n = 0;
+        for (const char* e = kMcCaseEdges[i]; *e != 'f'; e++, n++) {
+            const unsigned long long d = (unsigned long long)(*e <= '9' ? *e - '0' : *e - 'a' + 10);
+            v |= d << (4 * n);
+        }
+        out[i] = v | ((unsigned long long)(n / 3) << 60);
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int rto_build_leaf_triangles(rto_context* c, const uint8_t* voxels, int dimX, int dimY, int dimZ) {
+    if (!c) return RTO_E_INVALID;
+    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_build_leaf_triangles: upload or build the octree first");
+    RTO_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    RTO_HIP(c, hipStreamSynchronize(s));
+    BuildScratch scratch;
+    hipEvent_t e0, e1, e2;
+    RTO_HIP(c, hipEventCreate(&e0)); RTO_HIP(c, hipEventCreate(&e1)); RTO_HIP(c, hipEventCreate(&e2));
+    struct EvGuard { hipEvent_t a, b, d; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(d); } } evg{ e0, e1, e2 };
+    const uint8_t* d_vox = nullptr;
+    RTO_HIP(c, hipEventRecord(e0, s));
+    if (voxels) {
+        if (dimX <= 0 || dimY <= 0 || dimZ <= 0) return fail(c, RTO_E_INVALID, "rto_build_leaf_triangles: bad grid dimensions");
+        int maxDim = dimX > dimY ? dimX : dimY;
+        if (dimZ > maxDim) maxDim = dimZ;
+        if (maxDim > c->rootSize) return fail(c, RTO_E_INVALID, "rto_build_leaf_triangles: the grid is larger than the resident octree's root");
+        uint8_t* up = nullptr;
+        RTO_HIP(c, scratch.alloc(&up, (size_t)dimX * dimY * dimZ));
+        RTO_HIP(c, hipMemcpyAsync(up, voxels, (size_t)dimX * dimY * dimZ, hipMemcpyHostToDevice, s));
+        d_vox = up;
+    } else {
+        if (!c->d_vox) return fail(c, RTO_E_INVALID, "rto_build_leaf_triangles: voxels == NULL needs an octree made by rto_build_octree");
+        d_vox = c->d_vox; dimX = c->voxDim[0]; dimY = c->voxDim[1]; dimZ = c->voxDim[2];
+    }
+    RTO_HIP(c, hipEventRecord(e1, s));
+    if (!c->d_mcCases) {
+        unsigned long long packed[256];
+        pack_mc_cases(packed);
+        RTO_HIP(c, hipMalloc(&c->d_mcCases, sizeof packed));
+        RTO_HIP(c, hipMemcpy(c->d_mcCases, packed, sizeof packed, hipMemcpyHostToDevice));
+    }
+    (void)hipFree(c->d_tris); c->d_tris = nullptr;
+    (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
+    c->numTris = 0;
+
+    const int64_t n = c->numNodes;
+    const int nb = (int)((n + kBlock - 1) / kBlock);
+    LeafTriParams P{ c->d_nodes, n, d_vox, dimX, dimY, dimZ, c->gridMin[0], c->gridMin[1], c->gridMin[2], c->voxelSize, c->d_mcCases };
+    int *d_count = nullptr, *d_big = nullptr, *d_bigCount = nullptr, *d_bs = nullptr, *d_bb = nullptr;
+    int64_t* d_total = nullptr;
+    RTO_HIP(c, scratch.alloc(&d_count, (size_t)n)); RTO_HIP(c, scratch.alloc(&d_big, (size_t)n)); RTO_HIP(c, scratch.alloc(&d_bigCount, 1));
+    RTO_HIP(c, scratch.alloc(&d_bs, (size_t)nb)); RTO_HIP(c, scratch.alloc(&d_bb, (size_t)nb)); RTO_HIP(c, scratch.alloc(&d_total, 1));
+    RTO_HIP(c, hipMalloc(&c->d_triOffset, (size_t)(n + 1) * sizeof(int)));
+    RTO_HIP(c, hipMemsetAsync(d_bigCount, 0, sizeof(int), s));
+    // pass 1: counts
+    hipLaunchKernelGGL(k_leaftri_small<false>, dim3(nb), dim3(kBlock), 0, s, P, d_count, (const int*)nullptr, d_big, d_bigCount, (float*)nullptr);
+    RTO_HIP(c, hipGetLastError());
+    int bigCount = 0;
+    RTO_HIP(c, hipMemcpyAsync(&bigCount, d_bigCount, sizeof bigCount, hipMemcpyDeviceToHost, s));
+    RTO_HIP(c, hipStreamSynchronize(s));
+    const int nbBig = (bigCount + (kBlock / kWave) - 1) / (kBlock / kWave);
+    if (bigCount > 0) hipLaunchKernelGGL(k_leaftri_big<false>, dim3(nbBig), dim3(kBlock), 0, s, P, d_big, bigCount, d_count, (const int*)nullptr, (float*)nullptr);
+    // scan -> triOffset
+    hipLaunchKernelGGL(k_block_sums, dim3(nb), dim3(kBlock), 0, s, d_count, n, d_bs);
+    hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, s, d_bs, nb, d_bb, d_total);
+    hipLaunchKernelGGL(k_block_exclusive_scan, dim3(nb), dim3(kBlock), 0, s, d_count, n, d_bb, d_total, c->d_triOffset);
+    RTO_HIP(c, hipGetLastError());
+    int64_t total = 0;
+    RTO_HIP(c, hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, s));
+    RTO_HIP(c, hipStreamSynchronize(s));
+    if (total > 0x7fffffff / 12) return fail(c, RTO_E_UNSUPPORTED, "rto_build_leaf_triangles: triangle offsets are int32");
+    RTO_HIP(c, hipMalloc(&c->d_tris, (size_t)(total ? total : 1) * 12 * sizeof(float)));
+    // pass 2: triangles
+    hipLaunchKernelGGL(k_leaftri_small<true>, dim3(nb), dim3(kBlock), 0, s, P, d_count, c->d_triOffset, d_big, d_bigCount, c->d_tris);
+    if (bigCount > 0) hipLaunchKernelGGL(k_leaftri_big<true>, dim3(nbBig), dim3(kBlock), 0, s, P, d_big, bigCount, d_count, c->d_triOffset, c->d_tris);
+    RTO_HIP(c, hipGetLastError());
+    c->numTris = total;
+    if (c->canonical && c->numInternal > 0) {
+        hipLaunchKernelGGL(k_desc_trimask, dim3((unsigned)((c->numInternal + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                           c->d_descFirstChild, c->d_triOffset, c->numInternal, c->d_desc);
+        RTO_HIP(c, hipGetLastError());
+    }
+    RTO_HIP(c, hipEventRecord(e2, s));
+    RTO_HIP(c, hipStreamSynchronize(s));
+    RTO_HIP(c, hipEventElapsedTime(&c->buildUploadMs, e0, e1));
+    RTO_HIP(c, hipEventElapsedTime(&c->buildMs, e1, e2));
+    return RTO_OK;
+}
+
+int rto_download_leaf_triangles(rto_context* c, float* tris, int64_t tri_capacity, int32_t* tri_offset, int64_t* num_tris) {
+    if (!c || !num_tris) return RTO_E_INVALID;
+    if (!c->d_triOffset) return fail(c, RTO_E_NO_OCTREE, "rto_download_leaf_triangles: no leaf triangles resident");
+    *num_tris = c->numTris;
+    if (!tris && !tri_offset) return RTO_OK;
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    if (tris) {
+        if (tri_capacity < c->numTris) return fail(c, RTO_E_INVALID, "rto_download_leaf_triangles: capacity too small");
+        if (c->numTris) RTO_HIP(c, hipMemcpy(tris, c->d_tris, (size_t)c->numTris * 12 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (tri_offset) RTO_HIP(c, hipMemcpy(tri_offset, c->d_triOffset, (size_t)(c->numNodes + 1) * sizeof(int), hipMemcpyDeviceToHost));
     return RTO_OK;
 }
 

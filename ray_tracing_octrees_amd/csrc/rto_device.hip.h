@@ -1385,6 +1385,187 @@ __global__ __launch_bounds__(kBlock) void k_solid_bbox(const rto_node* __restric
     }
 }
 
+// ================================================================ N2: leaf-triangle buffer on the GPU
+// What MarchingCubesRenderer::render emits per leaf (S/Renderer.cpp:14-36 -> localMC, S/OctreeVoxel.cpp:780-879), as
+// host/LocalMC.cpp states it, built in HBM: node i's triangles at triOffset[i]..triOffset[i+1], 12 floats each, in
+// the host builder's order (cells of a leaf in z, y, x order, a cell's triangles in case-table order) and with its
+// float operations (pos = min + float(c)*voxel; vertex = p1 + 0.5*(p2 - p1); normal = normalize(cross(..))).
+// Only cells on a leaf's three max faces can straddle occupancy (a leaf is uniform, a cell reads corners x..x+1),
+// so a leaf of edge s has at most 3s^2-3s+1 candidate cells, enumerated in the same z, y, x order.
+//   count:  one thread per leaf up to kLeafSerialCandidates candidates, one wave per larger leaf
+//   scan :  block sums -> k_scan_block_counts -> per-block exclusive scan = triOffset
+//   emit :  same walk, writing at triOffset[node] + running count
+struct LeafTriParams {
+    const rto_node* nodes;
+    int64_t n;
+    const uint8_t* vox;          // x fastest, 0 EMPTY / 1 FILLED
+    int dimX, dimY, dimZ;
+    float minX, minY, minZ, vs;
+    const unsigned long long* cases;   // 256 x (triangle count << 60 | 15 edge nibbles, first edge in the low nibble)
+};
+
+constexpr int kLeafSerialCandidates = 64;
+
+struct LeafCells { int x0, y0, z0, s, ex, ey, ez, perLayer, nonTop, rowsNotMax, total; };
+
+__device__ __forceinline__ LeafCells leaf_cells(const LeafTriParams& P, const rto_node& nd) {
+    LeafCells L;
+    L.x0 = nd.x; L.y0 = nd.y; L.z0 = nd.z; L.s = nd.size;
+    // localMC's loop bounds: c < c0 + size && c < dim - 1
+    L.ex = max(0, min(nd.x + nd.size, P.dimX - 1) - nd.x);
+    L.ey = max(0, min(nd.y + nd.size, P.dimY - 1) - nd.y);
+    L.ez = max(0, min(nd.z + nd.size, P.dimZ - 1) - nd.z);
+    if (L.ex == 0 || L.ey == 0 || L.ez == 0) { L.perLayer = L.nonTop = L.rowsNotMax = L.total = 0; return L; }
+    const bool fullX = L.ex == L.s, fullY = L.ey == L.s, fullZ = L.ez == L.s;
+    L.rowsNotMax = L.ey - (fullY ? 1 : 0);                    // rows of a non-top layer that only contribute x = s-1
+    L.perLayer = (fullX ? L.rowsNotMax : 0) + (fullY ? L.ex : 0);
+    L.nonTop = L.ez - (fullZ ? 1 : 0);
+    L.total = L.nonTop * L.perLayer + (fullZ ? L.ex * L.ey : 0);
+    return L;
+}
+
+// candidate c (0 <= c < L.total) in z, y, x order -> local cell (i, j, k)
+__device__ __forceinline__ void leaf_candidate(const LeafCells& L, int c, int& i, int& j, int& k) {
+    const int below = L.nonTop * L.perLayer;
+    if (c >= below) { const int r = c - below; k = L.s - 1; j = r / L.ex; i = r - j * L.ex; return; }
+    k = c / L.perLayer;
+    int r = c - k * L.perLayer;
+    if (L.ex == L.s) {
+        if (r < L.rowsNotMax) { j = r; i = L.s - 1; return; }
+        r -= L.rowsNotMax;
+    }
+    j = L.s - 1; i = r;                                        // the max row (exists: perLayer counted it)
+}
+
+__device__ __forceinline__ int cell_case(const LeafTriParams& P, int x, int y, int z) {
+    // corner numbering of S/OctreeVoxel.cpp:802-817: 0 (0,0,0) 1 (1,0,0) 2 (1,1,0) 3 (0,1,0) 4..7 the same at z+1
+    const size_t sy = (size_t)P.dimX, sz = (size_t)P.dimX * P.dimY;
+    const uint8_t* v = P.vox + (size_t)z * sz + (size_t)y * sy + x;
+    int idx = 0;
+    idx |= (v[0] == 1) ? 1 : 0;           idx |= (v[1] == 1) ? 2 : 0;
+    idx |= (v[sy + 1] == 1) ? 4 : 0;      idx |= (v[sy] == 1) ? 8 : 0;
+    idx |= (v[sz] == 1) ? 16 : 0;         idx |= (v[sz + 1] == 1) ? 32 : 0;
+    idx |= (v[sz + sy + 1] == 1) ? 64 : 0; idx |= (v[sz + sy] == 1) ? 128 : 0;
+    return idx;
+}
+
+__device__ __forceinline__ void emit_cell_triangles(const LeafTriParams& P, int x, int y, int z, unsigned long long cs, float* __restrict__ out) {
+    const int cornerOff[8][3] = { { 0, 0, 0 }, { 1, 0, 0 }, { 1, 1, 0 }, { 0, 1, 0 }, { 0, 0, 1 }, { 1, 0, 1 }, { 1, 1, 1 }, { 0, 1, 1 } };
+    const int edgeCorner[12][2] = { { 0, 1 }, { 1, 2 }, { 2, 3 }, { 3, 0 }, { 4, 5 }, { 5, 6 }, { 6, 7 }, { 7, 4 }, { 0, 4 }, { 1, 5 }, { 2, 6 }, { 3, 7 } };
+    const int ntri = (int)(cs >> 60);
+    for (int t = 0; t < ntri; t++) {
+        float v[3][3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int e = (int)((cs >> (4 * (3 * t + q))) & 15ull);
+            const int a = edgeCorner[e][0], b = edgeCorner[e][1];
+            const float p1x = P.minX + (float)(x + cornerOff[a][0]) * P.vs, p1y = P.minY + (float)(y + cornerOff[a][1]) * P.vs,
+                        p1z = P.minZ + (float)(z + cornerOff[a][2]) * P.vs;
+            const float p2x = P.minX + (float)(x + cornerOff[b][0]) * P.vs, p2y = P.minY + (float)(y + cornerOff[b][1]) * P.vs,
+                        p2z = P.minZ + (float)(z + cornerOff[b][2]) * P.vs;
+            // vertexInterp with values -1 / +1 and iso 0: mu = (0 - v1) / (v2 - v1) = 0.5 exactly
+            v[q][0] = p1x + 0.5f * (p2x - p1x); v[q][1] = p1y + 0.5f * (p2y - p1y); v[q][2] = p1z + 0.5f * (p2z - p1z);
+        }
+        const float ax = v[1][0] - v[0][0], ay = v[1][1] - v[0][1], az = v[1][2] - v[0][2];
+        const float bx = v[2][0] - v[0][0], by = v[2][1] - v[0][1], bz = v[2][2] - v[0][2];
+        const float cx = ay * bz - by * az, cy = az * bx - bz * ax, cz = ax * by - bx * ay;      // glm cross
+        const float tx = cx * cx, ty = cy * cy, tz = cz * cz;
+        const float inv = inversesqrt(tx + ty + tz);
+        float* o = out + (size_t)t * 12;
+#pragma unroll
+        for (int q = 0; q < 3; q++) { o[3 * q] = v[q][0]; o[3 * q + 1] = v[q][1]; o[3 * q + 2] = v[q][2]; }
+        o[9] = cx * inv; o[10] = cy * inv; o[11] = cz * inv;
+    }
+}
+
+__device__ __forceinline__ bool is_leaf_node(const rto_node& nd) { return nd.isLeaf == 1; }
+
+// pass 1 (EMIT = false): triCount[node]; leaves with more candidates than a thread should walk go to bigList.
+// pass 2 (EMIT = true) : the same walk writing the triangles.
+template <bool EMIT>
+__global__ __launch_bounds__(kBlock) void k_leaftri_small(LeafTriParams P, int* __restrict__ triCount, const int* __restrict__ triOffset,
+                                                           int* __restrict__ bigList, int* __restrict__ bigCount, float* __restrict__ tris) {
+    const int64_t node = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (node >= P.n) return;
+    const rto_node nd = P.nodes[node];
+    if (!is_leaf_node(nd)) { if (!EMIT) triCount[node] = 0; return; }
+    const LeafCells L = leaf_cells(P, nd);
+    if (L.total > kLeafSerialCandidates) {
+        if (!EMIT) { triCount[node] = 0; bigList[atomicAdd(bigCount, 1)] = (int)node; }
+        return;
+    }
+    int run = EMIT ? triOffset[node] : 0;
+    for (int c = 0; c < L.total; c++) {
+        int i, j, k;
+        leaf_candidate(L, c, i, j, k);
+        const unsigned long long cs = P.cases[cell_case(P, L.x0 + i, L.y0 + j, L.z0 + k)];
+        if (EMIT) emit_cell_triangles(P, L.x0 + i, L.y0 + j, L.z0 + k, cs, tris + (size_t)run * 12);
+        run += (int)(cs >> 60);
+    }
+    if (!EMIT) triCount[node] = run;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(kBlock) void k_leaftri_big(LeafTriParams P, const int* __restrict__ bigList, int bigCount, int* __restrict__ triCount,
+                                                         const int* __restrict__ triOffset, float* __restrict__ tris) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (slot >= bigCount) return;                              // wave-uniform
+    const int node = bigList[slot];
+    const rto_node nd = P.nodes[node];
+    const LeafCells L = leaf_cells(P, nd);
+    int run = EMIT ? triOffset[node] : 0;
+    for (int c0 = 0; c0 < L.total; c0 += kWave) {
+        const int c = c0 + lane;
+        unsigned long long cs = 0;
+        int i = 0, j = 0, k = 0;
+        if (c < L.total) {
+            leaf_candidate(L, c, i, j, k);
+            cs = P.cases[cell_case(P, L.x0 + i, L.y0 + j, L.z0 + k)];
+        }
+        const int nt = (int)(cs >> 60);
+        int incl = nt;                                         // inclusive wave prefix of the triangle counts
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (EMIT && nt) emit_cell_triangles(P, L.x0 + i, L.y0 + j, L.z0 + k, cs, tris + (size_t)(run + incl - nt) * 12);
+        run += __shfl(incl, kWave - 1);
+    }
+    if (!EMIT && lane == 0) triCount[node] = run;
+}
+
+// block sums of an int array (for the exclusive scan that turns triCount into triOffset)
+__global__ __launch_bounds__(kBlock) void k_block_sums(const int* __restrict__ v, int64_t n, int* __restrict__ blockSum) {
+    __shared__ int waveTotal[kBlock / kWave];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int x = i < n ? v[i] : 0;
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    if ((threadIdx.x & 63) == 0) waveTotal[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kBlock / kWave; w++) t += waveTotal[w]; blockSum[blockIdx.x] = t; }
+}
+
+// out[i] = blockBase[block] + exclusive prefix within the block; out[n] = total
+__global__ __launch_bounds__(kBlock) void k_block_exclusive_scan(const int* __restrict__ v, int64_t n, const int* __restrict__ blockBase,
+                                                                  const int64_t* __restrict__ total, int* __restrict__ out) {
+    __shared__ int waveTotal[kBlock / kWave];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = i < n ? v[i] : 0;
+    int incl = x;
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == kWave - 1) waveTotal[wave] = incl;
+    __syncthreads();
+    int base = blockBase[blockIdx.x];
+    for (int w = 0; w < wave; w++) base += waveTotal[w];
+    if (i < n) out[i] = base + incl - x;
+    if (i == 0) out[n] = (int)*total;
+}
+
 // ================================================================ multi-GPU reassembly
 // d_gathered: numParts compact buffers, each padded to partRows rows of W pixels.
 __global__ void k_assemble(const float4* __restrict__ gathered, float4* __restrict__ frame,

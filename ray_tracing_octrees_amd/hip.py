@@ -29,7 +29,7 @@ SYMBOLS = (
     "rto_update_frustum", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
     "rto_render_shade_device", "rto_assemble_shade_device",
-    "rto_upload_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
+    "rto_upload_leaf_triangles", "rto_build_leaf_triangles", "rto_download_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
 )
 
@@ -108,6 +108,8 @@ def load():
     L.rto_frame_stats.argtypes = [vp, C.POINTER(Frame), C.POINTER(Stats)]
     L.rto_upload_leaf_triangles.argtypes = [vp, vp, C.c_int64, vp]
     L.rto_render_triangles_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), C.c_int, vp, vp]
+    L.rto_build_leaf_triangles.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    L.rto_download_leaf_triangles.argtypes = [vp, vp, C.c_int64, vp, C.POINTER(C.c_int64)]
     L.rto_render_triangles_host.argtypes = [vp, C.POINTER(Frame), C.c_int, vp, C.POINTER(Stats)]
     L.rto_octree_ray_skip.argtypes = [vp, C.POINTER(C.c_float), vp, C.c_int64, C.c_float, C.c_float, C.c_int, vp]
     L.rto_render_steps_host.argtypes = [vp, C.POINTER(Frame), vp]
@@ -257,6 +259,24 @@ class Context:
         off = np.ascontiguousarray(tri_offset, dtype=np.int32)
         self._keep_tris = (tris, off)
         self._check(self._L.rto_upload_leaf_triangles(self._h, tris.ctypes.data if len(tris) else None, len(tris), off.ctypes.data))
+
+    def build_leaf_triangles(self, voxels: np.ndarray | None = None):
+        """Config 5: the leaf-triangle buffer built on the GPU for the resident octree.  voxels: uint8 (dimZ, dimY, dimX);
+        None reuses the voxels rto_build_octree kept in HBM."""
+        if voxels is None:
+            self._check(self._L.rto_build_leaf_triangles(self._h, None, 0, 0, 0))
+            return
+        v = np.ascontiguousarray(voxels, dtype=np.uint8)
+        dz, dy, dx = v.shape
+        self._check(self._L.rto_build_leaf_triangles(self._h, v.ctypes.data, dx, dy, dz))
+
+    def download_leaf_triangles(self):
+        n = C.c_int64()
+        self._check(self._L.rto_download_leaf_triangles(self._h, None, 0, None, C.byref(n)))
+        tris = np.zeros((n.value, 12), np.float32)
+        off = np.zeros(self.info().num_nodes + 1, np.int32)
+        self._check(self._L.rto_download_leaf_triangles(self._h, tris.ctypes.data if n.value else None, n.value, off.ctypes.data, C.byref(n)))
+        return tris, off
 
     def render_triangles_host(self, frame: Frame, shadow: bool = True, stats: bool = False):
         out = np.empty((frame.height, frame.width, 4), np.float32)

@@ -101,6 +101,8 @@ def load():
     L.rtoh_rt_render_scene_compute_with_culling.restype = None
     L.rtoh_rt_build_leaf_triangles.argtypes = [_vp]
     L.rtoh_rt_build_leaf_triangles.restype = None
+    L.rtoh_rt_build_leaf_triangles_on_host.argtypes = [_vp]
+    L.rtoh_rt_build_leaf_triangles_on_host.restype = None
     L.rtoh_rt_render_scene_triangles.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
     L.rtoh_rt_render_scene_triangles.restype = None
     L.rtoh_rt_num_nodes.argtypes = [_vp]
@@ -338,8 +340,12 @@ class RayTracerBVH:
 
     # -- additions ---------------------------------------------------------
     def buildLeafTriangles(self):
-        """Config 5: per-leaf Marching-Cubes triangles of the grid given to setOctree(), uploaded to the GPU."""
+        """Config 5: per-leaf Marching-Cubes triangles of the grid given to setOctree(), built in HBM."""
         load().rtoh_rt_build_leaf_triangles(self._h)
+
+    def buildLeafTrianglesOnHost(self):
+        """The same buffer made by the C++ host builder (localMC per leaf) and uploaded: cross-check of the GPU build."""
+        load().rtoh_rt_build_leaf_triangles_on_host(self._h)
 
     def renderSceneTriangles(self, camera: Camera, width: int, height: int, aspect: float, fovDeg: float, shadow: bool = True):
         load().rtoh_rt_render_scene_triangles(self._h, camera._h, width, height, _f(aspect), _f(fovDeg), 1 if shadow else 0)

@@ -24,6 +24,7 @@ struct HipApi {
     decltype(&rto_update_frustum) update_frustum = nullptr;
     decltype(&rto_render_host) render_host = nullptr;
     decltype(&rto_upload_leaf_triangles) upload_leaf_triangles = nullptr;
+    decltype(&rto_build_leaf_triangles) build_leaf_triangles = nullptr;
     decltype(&rto_render_triangles_host) render_triangles_host = nullptr;
     std::string error;
 
@@ -60,6 +61,7 @@ struct HipApi {
         update_frustum = reinterpret_cast<decltype(update_frustum)>(sym("rto_update_frustum"));
         render_host = reinterpret_cast<decltype(render_host)>(sym("rto_render_host"));
         upload_leaf_triangles = reinterpret_cast<decltype(upload_leaf_triangles)>(sym("rto_upload_leaf_triangles"));
+        build_leaf_triangles = reinterpret_cast<decltype(build_leaf_triangles)>(sym("rto_build_leaf_triangles"));
         render_triangles_host = reinterpret_cast<decltype(render_triangles_host)>(sym("rto_render_triangles_host"));
         if (!ok) { dlclose(handle); handle = nullptr; }
         return ok;
@@ -192,8 +194,25 @@ bool RayTracerBVH::render(const Camera& camera, int width, int height, float asp
     return true;
 }
 
-#ifndef RTO_REFERENCE_HEADERS
 void RayTracerBVH::buildLeafTriangles() {
+    if (!m_computeInited || !m_computeOk) {
+        std::cerr << "[RayTracerBVH] Compute pipeline not initialized or failed.\n";
+        return;
+    }
+    if (m_numNodes <= 0) return;
+    // the triangles MarchingCubesRenderer::render would emit per leaf, built in HBM from the grid given to setOctree()
+    // (after setOctreeFromGrid the voxels are already resident: NULL)
+    static_assert(sizeof(VoxelState) == 1, "VoxelState is a byte upstream (S/OctreeVoxel.h:10-13)");
+    const uint8_t* vox = m_flatNodes.empty() ? nullptr : reinterpret_cast<const uint8_t*>(m_grid.data.data());
+    if (api().build_leaf_triangles(m_ctx, vox, m_grid.dimX, m_grid.dimY, m_grid.dimZ) != RTO_OK) {
+        m_lastError = api().last_error(m_ctx);
+        std::cerr << "[RayTracerBVH] leaf-triangle build failed: " << m_lastError << std::endl;
+    }
+}
+
+#ifndef RTO_REFERENCE_HEADERS
+// The same buffer made by this repo's host builder (localMC per leaf) and uploaded: the cross-check of the GPU build.
+void RayTracerBVH::buildLeafTrianglesOnHost() {
     if (!m_computeInited || !m_computeOk) {
         std::cerr << "[RayTracerBVH] Compute pipeline not initialized or failed.\n";
         return;
@@ -207,6 +226,7 @@ void RayTracerBVH::buildLeafTriangles() {
         std::cerr << "[RayTracerBVH] triangle upload failed: " << m_lastError << std::endl;
     }
 }
+#endif
 
 void RayTracerBVH::renderSceneTriangles(const Camera& camera, int width, int height, float aspect, float fovDeg, bool shadow) {
     if (!m_computeInited || !m_computeOk) {
@@ -228,7 +248,6 @@ void RayTracerBVH::renderSceneTriangles(const Camera& camera, int width, int hei
         m_frame.clear(); m_frameW = m_frameH = 0;
     }
 }
-#endif
 
 void RayTracerBVH::renderSceneCompute(const Camera& camera, int width, int height, float aspect, float fovDeg) {
     if (!m_computeInited || !m_computeOk) {

@@ -63,12 +63,14 @@ public:
     // createOctreeFromVoxelGrid + setOctree in one step ON THE GPU (rto_build_octree): no pointer tree, no host
     // flatten.  The resident array equals what setOctree(createOctreeFromVoxelGrid(grid), grid) uploads.
     void setOctreeFromGrid(const VoxelGrid& grid);
-    // Triangle ray path of BASELINE config 5 (no upstream counterpart): builds the per-leaf Marching-Cubes
-    // triangle buffer from the grid given to setOctree() and uploads it; then renders with Moeller-Trumbore
-    // hits on those triangles and, if `shadow`, one shadow ray per hit.  Same framebuffer() as the other calls.
-#ifndef RTO_REFERENCE_HEADERS   // needs this repo's localMC; the reference-header build keeps to the upstream API
+    // Triangle ray path of BASELINE config 5 (no upstream counterpart): builds, in HBM, the per-leaf Marching-Cubes
+    // triangle buffer (what MarchingCubesRenderer::render emits per leaf) from the grid given to setOctree() /
+    // setOctreeFromGrid(); then renders with Moeller-Trumbore hits on those triangles and, if `shadow`, one shadow ray
+    // per hit.  Same framebuffer() as the other calls.
     void buildLeafTriangles();
     void renderSceneTriangles(const Camera& camera, int width, int height, float aspect, float fovDeg, bool shadow);
+#ifndef RTO_REFERENCE_HEADERS   // needs this repo's localMC: the same buffer made on the host and uploaded (cross-check)
+    void buildLeafTrianglesOnHost();
 #endif
     // BFS numbering of setOctree (RayTracerBVH.cpp:443-490) without touching the GPU.
     static std::vector<GPUNodes> flatten(const OctreeNode* root);

@@ -156,6 +156,7 @@ void rtoh_rt_render_scene_compute_with_culling(RayTracerBVH* rt, const Camera* c
     rt->renderSceneComputeWithCulling(*cam, w, h, aspect, fovDeg, updateFrustum != 0);
 }
 void rtoh_rt_build_leaf_triangles(RayTracerBVH* rt) { rt->buildLeafTriangles(); }
+void rtoh_rt_build_leaf_triangles_on_host(RayTracerBVH* rt) { rt->buildLeafTrianglesOnHost(); }
 void rtoh_rt_render_scene_triangles(RayTracerBVH* rt, const Camera* cam, int w, int h, float aspect, float fovDeg, int shadow) {
     rt->renderSceneTriangles(*cam, w, h, aspect, fovDeg, shadow != 0);
 }

@@ -105,7 +105,10 @@ def test_fuzz_random_scenes_and_cameras(ctx, orc, seed):
             assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"]), what
         if shot == 0:
             tris, off = orc.build_leaf_triangles(s.grid, s.nodes)
-            ctx.upload_leaf_triangles(tris, off)
+            ctx.build_leaf_triangles(g.data)                            # GPU builder == oracle's buffer, then render from it
+            gt, go = ctx.download_leaf_triangles()
+            assert go.tobytes() == np.asarray(off, np.int32).tobytes(), f"seed {seed}: triOffset"
+            assert gt.tobytes() == np.ascontiguousarray(tris, np.float32).reshape(-1, 12).tobytes(), f"seed {seed}: triangles"
         if len(tris):
             wt, wst = orc.render_triangles(s.nodes, tris, off, s.min, s.voxel, view, pos, aspect, fov, W, H, shadow=True)
             for kname, kernel in (("packed", rto.KERNEL_AUTO), ("generic", rto.KERNEL_GENERIC)):
@@ -707,6 +710,55 @@ def test_config5_leaf_triangles_and_shadow_ray(ctx, orc, scenes, scene, W, H, ca
             assert_bit_exact(got2, want, f"{scene} triangles shadow={shadow} {kname} (no counters)")
 
 
+@pytest.mark.parametrize("scene", ["sphere16", "sphere32", "sphere64", "odd", "calgary"])
+def test_gpu_leaf_triangle_build_equals_the_host_builders(ctx, orc, scenes, scene):
+    """rto_build_leaf_triangles: the buffer MarchingCubesRenderer/localMC would emit per leaf, built in HBM -- the same
+    bytes as the oracle's builder (itself pinned by the reference's localMC triangles) and as the product's C++ one;
+    for an uploaded octree + voxels and for rto_build_octree + the voxels it kept."""
+    s = scenes(scene)
+    wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
+    upload(ctx, s)
+    ctx.build_leaf_triangles(s.grid.data)
+    gt, go = ctx.download_leaf_triangles()
+    assert go.tobytes() == np.asarray(wo, np.int32).tobytes(), f"{scene}: triOffset"
+    assert gt.shape == np.asarray(wt).reshape(-1, 12).shape
+    assert gt.tobytes() == np.ascontiguousarray(wt, np.float32).tobytes(), f"{scene}: triangles"
+    k_ms, _ = ctx.last_build_ms()
+    assert 0 < k_ms < 1000
+    # GPU-built octree, voxels already resident
+    ctx.build_octree(s.grid.data, s.min, s.voxel)
+    ctx.build_leaf_triangles(None)
+    gt2, go2 = ctx.download_leaf_triangles()
+    assert go2.tobytes() == go.tobytes() and gt2.tobytes() == gt.tobytes()
+    # and it renders: same frame as with the uploaded buffer
+    c = orc.Camera(0.5, 0.7, 1.8) if scene != "calgary" else orc.Camera(0.6, 0.5, 3500.0)
+    if scene == "odd":
+        c = orc.Camera(0.4, 0.9, 9.0)
+    W, H = 200, 120
+    f = rto.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H)
+    a = ctx.render_triangles_host(f, shadow=True)
+    ctx.upload_leaf_triangles(wt, wo)
+    assert_bit_exact(a, ctx.render_triangles_host(f, shadow=True), f"{scene}: GPU-built vs uploaded triangles")
+    # error paths
+    with pytest.raises(rto.RtoError):
+        rto.Context(0).build_leaf_triangles(s.grid.data)            # no octree
+    upload(ctx, s)
+    with pytest.raises(rto.RtoError):
+        ctx.build_leaf_triangles(None)                              # no voxels kept by an upload
+
+
+def test_gpu_leaf_triangle_build_512(ctx, orc, scenes):
+    s = scenes("sphere512")
+    ctx.build_octree(s.grid.data, s.min, s.voxel)
+    ctx.build_leaf_triangles(None)
+    k_ms, _ = ctx.last_build_ms()
+    gt, go = ctx.download_leaf_triangles()
+    wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
+    assert go.tobytes() == np.asarray(wo, np.int32).tobytes()
+    assert gt.tobytes() == np.ascontiguousarray(wt, np.float32).tobytes()
+    print(f"GPU leaf-triangle build 512^3: {len(gt)} triangles in {k_ms:.3f} ms")
+
+
 def test_config5_shadows_exist_and_partitions_agree(ctx, orc, scenes):
     torch = pytest.importorskip("torch")
     s = scenes("calgary")
@@ -788,8 +840,17 @@ def test_cpp_dropin_class_triangle_path(orc, scenes):
     oc = orc.Camera(0.5, 0.7, 1.8)
     wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
     want, _ = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, oc.get_view(), oc.get_pos(), W / H, 45.0, W, H, shadow=True)
-    assert_bit_exact(rt.framebuffer(), want, "C++ class, triangle path")
+    assert_bit_exact(rt.framebuffer(), want, "C++ class, triangle path (buffer built on the GPU)")
+    rt.buildLeafTrianglesOnHost()
+    rt.renderSceneTriangles(cam, W, H, W / H, 45.0, True)
+    assert_bit_exact(rt.framebuffer(), want, "C++ class, triangle path (buffer built on the host)")
     rto.freeOctree(root)
+    rt2 = rto.RayTracerBVH()                     # everything on the GPU: octree and triangles from the voxels
+    rt2.ensureComputeInitialized()
+    rt2.setOctreeFromGrid(g)
+    rt2.buildLeafTriangles()
+    rt2.renderSceneTriangles(cam, W, H, W / H, 45.0, True)
+    assert_bit_exact(rt2.framebuffer(), want, "C++ class, GPU-built octree + GPU-built triangles")
 
 
 def test_root_screen_rectangle_never_changes_pixels(ctx, orc, scenes):
