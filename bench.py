@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--band-rows", type=int, default=16)
-    ap.add_argument("--kernel", choices=["auto", "packed", "generic"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "packed", "persistent", "generic"], default="auto")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo (+ --share-gpu) rehearses the multi-rank path on one GPU; the gather is staged through host memory")
@@ -146,7 +146,8 @@ def main():
 
     ctx = rto.Context(local_rank)
     ctx.upload_octree(nodes, grid.min, grid.voxelSize)
-    ctx.set_kernel({"auto": rto.KERNEL_AUTO, "packed": rto.KERNEL_PACKED, "generic": rto.KERNEL_GENERIC}[args.kernel])
+    ctx.set_kernel({"auto": rto.KERNEL_AUTO, "packed": rto.KERNEL_PACKED, "persistent": rto.KERNEL_PACKED_PERSISTENT,
+                    "generic": rto.KERNEL_GENERIC}[args.kernel])
     ctx.set_launch_order(1 if args.order == "temporal" else 0, args.order_period)
     info = ctx.info()
     renderer = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows,
@@ -242,7 +243,7 @@ def main():
             roofline = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": ("k_trace_packed3" if args.kernel in ("auto", "packed") else "k_trace_packed") if (info.canonical and args.kernel != "generic") else "k_trace_generic",
+                "kernel": {"auto": "k_trace_packed3", "packed": "k_trace_packed3", "persistent": "k_trace_packed3_persistent"}.get(args.kernel, "k_trace_generic") if (info.canonical and args.kernel != "generic") else "k_trace_generic",
                 "launch_order": f"temporal (tiles sorted by an earlier frame's trip counts; k_sort_scatter after every {args.order_period}-th frame)" if args.order == "temporal" else "centre-out",
                 "kernel_ms_avg": round(k_avg, 5), "kernel_ms_median": round(kms[len(kms) // 2], 5),
                 "event_pair_overhead_ms": round(pair_overhead, 5),

@@ -66,6 +66,8 @@ typedef struct rto_partition {
 #define RTO_KERNEL_GENERIC 1       /* 60-byte nodes, explicit child indices, per-thread stack[128] */
 #define RTO_KERNEL_PACKED  2       /* 8-byte child descriptors, LDS level stack, branch-free O(1)-ascent loop */
 #define RTO_KERNEL_PACKED_V1 3     /* first form of the packed kernel (level-by-level ascent); kept for A/B runs */
+#define RTO_KERNEL_PACKED_PERSISTENT 4  /* the default kernel as persistent threads: a machine-filling grid whose waves
+                                         * take launch slots from a global counter; kept for A/B runs */
 
 typedef struct rto_stats {         /* per-frame counters, same meaning as the oracle's */
     uint64_t rays, pops, hits, capped;

@@ -50,6 +50,7 @@ struct rto_context {
     // temporal launch order (packed kernel): an earlier frame's per-tile cost -> this frame's slot->tile table.
     // The tables are written and read by kernels in stream order, so every launch stream owns a set of its own:
     // frames in flight on different streams of one context never share (or race on) a table.
+    int numCUs = 256;
     int orderPolicy = 1;            // 0 = centre-out only, 1 = temporal (falls back to centre-out without history)
     int orderPeriod = 4;            // rebuild the table every orderPeriod-th frame (cost maps change slowly)
     struct OrderState {
@@ -62,6 +63,8 @@ struct rto_context {
         bool valid = false;
         bool fixed = false;             // debug: the caller supplied the table, do not rebuild it
         int age = 0;                    // frames rendered since the table was built
+        int* d_queue = nullptr;         // persistent-threads variant: two slot counters, used alternately
+        int queuePing = 0;
     };
     std::map<hipStream_t, OrderState> orders;
     hipStream_t lastOrderStream = nullptr;      // what the rto_debug_* order functions refer to
@@ -151,6 +154,7 @@ int rto_create(int device_ordinal, rto_context** out) {
         return fail(nullptr, RTO_E_HIP, std::string("rto_create: ") + hipGetErrorString(e));
     }
     c->deviceName = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
         std::string msg = "rto_create: device is " + c->deviceName + ", this library carries gfx950 code only";
         delete c;
@@ -176,7 +180,7 @@ void rto_destroy(rto_context* c) {
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_rayX);
     (void)hipFree(c->d_rayY);
-    for (auto& kv : c->orders) { (void)hipFree(kv.second.d_tileCost); (void)hipFree(kv.second.d_tileOrder); (void)hipFree(kv.second.d_sortHist); }
+    for (auto& kv : c->orders) { (void)hipFree(kv.second.d_tileCost); (void)hipFree(kv.second.d_tileOrder); (void)hipFree(kv.second.d_sortHist); (void)hipFree(kv.second.d_queue); }
     c->orders.clear();
     (void)hipFree(c->d_mcCases);
     (void)hipFree(c->d_steps);
@@ -514,7 +518,7 @@ int rto_octree_info_get(const rto_context* c, rto_octree_info* out) {
 
 int rto_set_kernel(rto_context* c, int kernel) {
     if (!c) return RTO_E_INVALID;
-    if (kernel < RTO_KERNEL_AUTO || kernel > RTO_KERNEL_PACKED_V1)
+    if (kernel < RTO_KERNEL_AUTO || kernel > RTO_KERNEL_PACKED_PERSISTENT)
         return fail(c, RTO_E_INVALID, "rto_set_kernel: unknown kernel id");
     if (kernel >= RTO_KERNEL_PACKED && c->numNodes > 0 && !c->canonical)
         return fail(c, RTO_E_UNSUPPORTED, "rto_set_kernel: packed kernel needs a canonical BFS octree");
@@ -720,12 +724,13 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             bool recordCost = false;
             const bool useOrder = c->orderPolicy == RTO_ORDER_TEMPORAL && (MODE == kModeColor || MODE == kModeShade || MODE == kModeTimeline) &&
                                   (size_t)((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * sizeof(int) <= 96 * 1024;   // table must fit LDS
-            rto_context::OrderState* o = nullptr;
-            if (useOrder) {
+            rto_context::OrderState* st = nullptr;      // this stream's scheduling state
+            {
                 auto it = c->orders.find(s);
-                if (it != c->orders.end()) o = &it->second;
-                else if (c->orders.size() < rto_context::kMaxOrderStreams) o = &c->orders[s];
+                if (it != c->orders.end()) st = &it->second;
+                else if (c->orders.size() < rto_context::kMaxOrderStreams) st = &c->orders[s];
             }
+            rto_context::OrderState* o = useOrder ? st : nullptr;
             if (o) {
                 c->lastOrderStream = s;
                 if (o->tiles != tiles) {
@@ -747,7 +752,23 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 Q.tileCost = recordCost ? o->d_tileCost : nullptr;
                 Q.tileHist = o->d_sortHist + (size_t)o->histPing * ((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets;
             }
-            hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+            const bool persistent = c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT && st && (MODE == kModeColor || MODE == kModeShade);
+            if (persistent) {
+                if (!st->d_queue) {
+                    RTO_HIP(c, hipMalloc(&st->d_queue, 2 * sizeof(int)));
+                    RTO_HIP(c, hipMemsetAsync(st->d_queue, 0, 2 * sizeof(int), s));
+                    st->queuePing = 0;
+                }
+                // enough workgroups to fill the machine at this kernel's occupancy; the rest of the slots come from the counter
+                const int resident = c->numCUs * RTO_PACKED3_WAVES;
+                int* qCur = st->d_queue + st->queuePing;
+                int* qNext = st->d_queue + (1 - st->queuePing);
+                st->queuePing = 1 - st->queuePing;
+                hipLaunchKernelGGL(k_trace_packed3_persistent<MODE>, dim3(std::min(blocks, resident)), dim3(kBlock), lds, s, Q, c->d_desc, d_out,
+                                   c->d_steps, c->d_counters, qCur, qNext);
+            } else {
+                hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+            }
             RTO_HIP(c, hipEventRecord(evB, s));       // the traversal kernel alone; the order kernel follows
             stopRecorded = true;
             if (o && (MODE == kModeColor || MODE == kModeShade) && !recordCost) o->age++;

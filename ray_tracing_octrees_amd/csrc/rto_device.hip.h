@@ -43,6 +43,9 @@ constexpr int kMaxTraversalSteps = 512;   // S/RT:192
 constexpr int kWave = 64;
 constexpr int kBlock = 256;               // 4 waves, each owns one 8x8 pixel tile
 #ifndef RTO_PACKED3_WAVES
+#ifndef RTO_PERSIST_CHUNK
+#define RTO_PERSIST_CHUNK 8
+#endif
 #define RTO_PACKED3_WAVES 6       // waves per SIMD for the default traversal kernel (8 forces spills and measured 6 % slower)
 #endif
 constexpr int kMaxDepth = 20;             // log2(root size) supported by the packed kernel
@@ -202,6 +205,7 @@ __device__ __forceinline__ float4 shade_hit(const RenderParams& P, const Ray& r,
 constexpr int kModeColor = 0;   // RGBA32F framebuffer
 constexpr int kModeSteps = 1;   // per-pixel +/-steps and frame counters (instrumentation)
 constexpr int kModeTimeline = 2; // per-wave {start, end (100 MHz wall clock), loop iterations, HW_ID} in stepsOut (8 ints / tile)
+constexpr int kPersistChunk = RTO_PERSIST_CHUNK;   // launch slots a persistent wave takes per atomic
 constexpr int kModeShade = 3;    // one float per pixel: the Lambert term of the hit, kShadeMiss for a miss (multi-GPU payload)
 
 struct Counters { unsigned long long pops, hits, capped; };
@@ -539,15 +543,11 @@ __device__ __forceinline__ unsigned child_pass_mask_fast(const RenderParams& P, 
 // that has some") are merged through one packed state word W = pending | internal<<8 | visible<<16 |
 // tailAbove<<24 that comes either from the node's descriptor or from the LDS stack entry.  The LDS read is
 // unconditional (harmless when unused), the only predicated memory operation is the stack write.
+// One tile (= one wave's 64 rays) from launch slot `slot`.
 template <int MODE>
-__global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3(RenderParams P, const uint2* __restrict__ desc,
-                                                           float4* __restrict__ out, int* __restrict__ stepsOut,
-                                                           Counters* __restrict__ counters) {
-    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;
-
+__device__ __forceinline__ void trace_tile_packed3(const RenderParams& P, const uint2* __restrict__ desc, float4* __restrict__ out,
+                                                   int* __restrict__ stepsOut, Counters* __restrict__ counters, uint2* stk,
+                                                   const int lane, const int slot) {
     unsigned long long tl0 = 0;
     int tlIters = 0;
     if (MODE == kModeTimeline) tl0 = wall_clock64();
@@ -555,7 +555,6 @@ __global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3(Ren
     // Launch order.  The frame ends when its deepest waves end, so they must start first.  With temporal order the
     // slot -> tile table lists the tiles by their trip count in the previous frame (a scheduling hint only: every
     // tile is rendered exactly once either way); without history, tiles go centre-out from the projected geometry.
-    const int slot = blockIdx.x * (kBlock / kWave) + wave;
     int tile = slot;
     int tx = 0, ty = P.tilesY;
     if (slot < P.tilesX * P.tilesY) {
@@ -708,6 +707,48 @@ __global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3(Ren
     } else {
         if (inImage) stepsOut[(size_t)py * P.W + px] = hit ? steps : -steps;
         wave_accumulate(counters, steps, hit, inImage);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3(RenderParams P, const uint2* __restrict__ desc,
+                                                           float4* __restrict__ out, int* __restrict__ stepsOut,
+                                                           Counters* __restrict__ counters) {
+    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;
+    trace_tile_packed3<MODE>(P, desc, out, stepsOut, counters, stk, lane, blockIdx.x * (kBlock / kWave) + wave);
+}
+
+// Persistent-threads form of the same kernel (RTO_KERNEL_PACKED_PERSISTENT): the grid only fills the machine, every
+// wave renders its first tile and then keeps taking the next launch slot from a global counter until none is left.
+// queueCur is this frame's counter; queueNext, the next frame's, is zeroed here (the host alternates the two).
+template <int MODE>
+__global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3_persistent(RenderParams P, const uint2* __restrict__ desc,
+                                                           float4* __restrict__ out, int* __restrict__ stepsOut,
+                                                           Counters* __restrict__ counters, int* __restrict__ queueCur,
+                                                           int* __restrict__ queueNext) {
+    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;
+    const int tiles = P.tilesX * P.tilesY;
+    const int firstFree = gridDim.x * (kBlock / kWave);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *queueNext = 0;
+    int slot = blockIdx.x * (kBlock / kWave) + wave;
+    int left = 1;                                              // slots of the current chunk still to render
+    while (slot < tiles) {                                     // wave-uniform
+        trace_tile_packed3<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
+        slot++;
+        if (--left == 0) {
+            // same-address atomics serialise (about 10 ns each): one per tile would cost 0.3 ms per 1080p frame,
+            // so a wave takes kPersistChunk consecutive slots at a time
+            int next = 0;
+            if (lane == 0) next = atomicAdd(queueCur, kPersistChunk);
+            slot = firstFree + __builtin_amdgcn_readfirstlane(next);
+            left = kPersistChunk;
+        }
     }
 }
 

@@ -14,7 +14,7 @@ from . import _build
 
 RTO_OK = 0
 RTO_E_INVALID, RTO_E_NO_OCTREE, RTO_E_HIP, RTO_E_NO_DEVICE, RTO_E_UNSUPPORTED = -1, -2, -3, -4, -5
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED, KERNEL_PACKED_V1 = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED, KERNEL_PACKED_V1, KERNEL_PACKED_PERSISTENT = 0, 1, 2, 3, 4
 
 # struct GPUNodes (453-skeleton/RayTracerBVH.h:21-26)
 NODE_DTYPE = np.dtype(
