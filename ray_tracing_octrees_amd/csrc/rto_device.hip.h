@@ -1102,66 +1102,76 @@ __device__ __forceinline__ PTriHit trace_packed_triangles(const RenderParams& P,
     bool needVisit = true;
     int steps = 1;
     bool alive = true;
+    bool haveLeaf = false;         // a popped triangle leaf waits for its test
+    int leafNode = 0;
+    // "while-while" form: lanes first walk nodes until each holds a triangle leaf (or is done), then all of them run
+    // their triangle loops together -- instead of paying a node visit AND the longest triangle loop in every iteration.
     while (alive) {
-        if (needVisit) {
-            const uint2 d = S.desc[cur];
-            c0 = S.descFirstChild[cur];
-            const int half = 1 << (P.depth - 1 - lvl);
-            unsigned passMask;
-            if (__builtin_amdgcn_ballot_w64(risky) != 0ull) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
-            else passMask = child_pass_mask_fast(P, r, cx, cy, cz, half);
-            const unsigned vm0 = __builtin_amdgcn_ubfe(d.x, 16, 8);
-            const unsigned im0 = __builtin_amdgcn_ubfe(d.x, 8, 8);
-            const unsigned tm0 = d.x >> 24;
-            W = (d.x & 0x00ffff00u) | (((im0 | tm0) & vm0) & passMask) | (tailRun << 24);
-            base = d.y;
-            belowPrev = 0xffu;
-            needVisit = false;
+        while (alive && !haveLeaf) {
+            if (needVisit) {
+                const uint2 d = S.desc[cur];
+                c0 = S.descFirstChild[cur];
+                const int half = 1 << (P.depth - 1 - lvl);
+                unsigned passMask;
+                if (__builtin_amdgcn_ballot_w64(risky) != 0ull) passMask = child_pass_mask<true>(P, r, cx, cy, cz, half);
+                else passMask = child_pass_mask_fast(P, r, cx, cy, cz, half);
+                const unsigned vm0 = __builtin_amdgcn_ubfe(d.x, 16, 8);
+                const unsigned im0 = __builtin_amdgcn_ubfe(d.x, 8, 8);
+                const unsigned tm0 = d.x >> 24;
+                W = (d.x & 0x00ffff00u) | (((im0 | tm0) & vm0) & passMask) | (tailRun << 24);
+                base = d.y;
+                belowPrev = 0xffu;
+                needVisit = false;
+            }
+            if ((W & 0xffu) == 0) {
+                // this level is exhausted: its remaining children only count steps; resume at the deepest level with work
+                steps += __builtin_popcount(((W >> 16) & 0xffu) & belowPrev) + (int)(W >> 24);
+                if (lvlPending == 0 || steps >= kMaxTraversalSteps) { alive = false; break; }
+                const int L = 31 - __builtin_clz(lvlPending);
+                const uint4 e = stk[L * kWave];
+                W = e.x; base = e.y; c0 = (int)e.z;
+                lvlPending &= ~(1u << L);          // its state lives in registers again; a later descent re-files it
+                const int bpos = P.depth - 1 - L;
+                const unsigned childIdx = ((cx >> bpos) & 1) | (((cy >> bpos) & 1) << 1) | (((cz >> bpos) & 1) << 2);
+                belowPrev = (1u << childIdx) - 1u;
+                const int keep = (int)(0xffffffffu << (bpos + 1));
+                cx &= keep; cy &= keep; cz &= keep;
+                lvl = L;
+            }
+            // pop the next interesting child of level lvl
+            const unsigned pending = W & 0xffu, im = (W >> 8) & 0xffu, vm = (W >> 16) & 0xffu, tailAbove = W >> 24;
+            const int j = 31 - __builtin_clz(pending);
+            const unsigned bitj = 1u << j;
+            const int stepsC = steps + __builtin_popcount(vm & belowPrev & ~((bitj << 1) - 1u));
+            if (stepsC >= kMaxTraversalSteps) { steps = kMaxTraversalSteps; alive = false; break; }
+            steps = stepsC + 1;
+            W ^= bitj;
+            belowPrev = bitj - 1u;
+            if (im & bitj) {
+                stk[lvl * kWave] = make_uint4(W, base, (unsigned)c0, 0u);
+                if (W & 0xffu) { lvlPending |= (1u << lvl); tailRun = 0; }
+                else { lvlPending &= ~(1u << lvl); tailRun = tailAbove + (unsigned)__builtin_popcount(vm & (bitj - 1u)); }
+                cur = base + (unsigned)__builtin_popcount(im & (bitj - 1u));
+                const int hl = 1 << (P.depth - 1 - lvl);
+                cx |= (j & 1) ? hl : 0; cy |= (j & 2) ? hl : 0; cz |= (j & 4) ? hl : 0;
+                lvl++;
+                needVisit = true;
+            } else {
+                haveLeaf = true;               // a leaf that owns triangles and passed the slab test
+                leafNode = c0 + j;
+            }
         }
-        if ((W & 0xffu) == 0) {
-            // this level is exhausted: its remaining children only count steps; resume at the deepest level with work
-            steps += __builtin_popcount(((W >> 16) & 0xffu) & belowPrev) + (int)(W >> 24);
-            if (lvlPending == 0 || steps >= kMaxTraversalSteps) { alive = false; break; }
-            const int L = 31 - __builtin_clz(lvlPending);
-            const uint4 e = stk[L * kWave];
-            W = e.x; base = e.y; c0 = (int)e.z;
-            lvlPending &= ~(1u << L);          // its state lives in registers again; a later descent re-files it
-            const int bpos = P.depth - 1 - L;
-            const unsigned childIdx = ((cx >> bpos) & 1) | (((cy >> bpos) & 1) << 1) | (((cz >> bpos) & 1) << 2);
-            belowPrev = (1u << childIdx) - 1u;
-            const int keep = (int)(0xffffffffu << (bpos + 1));
-            cx &= keep; cy &= keep; cz &= keep;
-            lvl = L;
-        }
-        // pop the next interesting child of level lvl
-        const unsigned pending = W & 0xffu, im = (W >> 8) & 0xffu, vm = (W >> 16) & 0xffu, tailAbove = W >> 24;
-        const int j = 31 - __builtin_clz(pending);
-        const unsigned bitj = 1u << j;
-        const int stepsC = steps + __builtin_popcount(vm & belowPrev & ~((bitj << 1) - 1u));
-        if (stepsC >= kMaxTraversalSteps) { steps = kMaxTraversalSteps; alive = false; break; }
-        steps = stepsC + 1;
-        W ^= bitj;
-        belowPrev = bitj - 1u;
-        if (im & bitj) {
-            stk[lvl * kWave] = make_uint4(W, base, (unsigned)c0, 0u);
-            if (W & 0xffu) { lvlPending |= (1u << lvl); tailRun = 0; }
-            else { lvlPending &= ~(1u << lvl); tailRun = tailAbove + (unsigned)__builtin_popcount(vm & (bitj - 1u)); }
-            cur = base + (unsigned)__builtin_popcount(im & (bitj - 1u));
-            const int hl = 1 << (P.depth - 1 - lvl);
-            cx |= (j & 1) ? hl : 0; cy |= (j & 2) ? hl : 0; cz |= (j & 4) ? hl : 0;
-            lvl++;
-            needVisit = true;
-        } else {
-            // a leaf that owns triangles and passed the slab test: nearest t > 0 within the leaf
-            const int node = c0 + j;
+        if (haveLeaf) {
+            // nearest t > 0 within the leaf
             float bestT = 1e30f;
             int best = -1;
-            const int k1 = S.triOffset[node + 1];
-            for (int k = S.triOffset[node]; k < k1; k++) {
+            const int k1 = S.triOffset[leafNode + 1];
+            for (int k = S.triOffset[leafNode]; k < k1; k++) {
                 float t;
                 if (ray_triangle(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, S.tris + (size_t)k * 12, t) && t < bestT) { bestT = t; best = k; }
             }
             if (best >= 0) { h.hit = true; h.t = bestT; h.tri = best; alive = false; }
+            haveLeaf = false;
         }
     }
     if (!h.hit && steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
