@@ -155,6 +155,13 @@ int rto_create(int device_ordinal, rto_context** out) {
     }
     c->deviceName = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {   // keep freed build scratch in the stream-ordered pool (see BuildScratch)
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, device_ordinal) == hipSuccess && pool) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+    }
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
         std::string msg = "rto_create: device is " + c->deviceName + ", this library carries gfx950 code only";
         delete c;
@@ -308,11 +315,16 @@ struct LevelBuf {
     int64_t m = 0;       // nodes at this level
     int64_t k = 0;       // internal nodes at this level
 };
+// Scratch of the build entry points: stream-ordered allocations from the device's default memory pool (its release
+// threshold is raised in rto_create, so a second build reuses the memory of the first instead of calling hipMalloc
+// ~50 times); everything is returned to the pool, in stream order, when the build leaves scope.
 struct BuildScratch {
+    hipStream_t stream;
     std::vector<void*> allocs;
-    ~BuildScratch() { for (void* p : allocs) (void)hipFree(p); }
+    explicit BuildScratch(hipStream_t s) : stream(s) {}
+    ~BuildScratch() { for (void* p : allocs) (void)hipFreeAsync(p, stream); }
     template <class T> hipError_t alloc(T** p, size_t count) {
-        hipError_t e = hipMalloc(p, (count ? count : 1) * sizeof(T));
+        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(T), stream);
         if (e == hipSuccess) allocs.push_back(*p);
         return e;
     }
@@ -336,7 +348,7 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     std::memcpy(c->gridMin, grid_min, sizeof c->gridMin);
     c->voxelSize = voxel_size;
     hipStream_t s = c->stream;
-    BuildScratch scratch;
+    BuildScratch scratch(c->stream);
     hipEvent_t e0, e1, e2;
     RTO_HIP(c, hipEventCreate(&e0)); RTO_HIP(c, hipEventCreate(&e1)); RTO_HIP(c, hipEventCreate(&e2));
     struct EvGuard { hipEvent_t a, b, d; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(d); } } evg{ e0, e1, e2 };
@@ -350,64 +362,83 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     RTO_HIP(c, hipMemcpyAsync(d_vox, voxels, nvox, hipMemcpyHostToDevice, s));
     RTO_HIP(c, hipEventRecord(e1, s));
 
-    // ---- occupancy pyramid, bottom-up
+    // ---- occupancy pyramid, bottom-up; every level also leaves its number of mixed cells = internal nodes
     PyramidView V;
     std::memset(&V, 0, sizeof V);
     V.level[0] = d_vox; V.nx[0] = dimX; V.ny[0] = dimY; V.nz[0] = dimZ;
+    LevelCountView LC;
+    std::memset(&LC, 0, sizeof LC);
     for (int l = 1; l <= R; l++) {
         V.nx[l] = (V.nx[l - 1] + 1) / 2; V.ny[l] = (V.ny[l - 1] + 1) / 2; V.nz[l] = (V.nz[l - 1] + 1) / 2;
         const size_t cells = (size_t)V.nx[l] * V.ny[l] * V.nz[l];
+        const unsigned nbl = (unsigned)((cells + kBlock - 1) / kBlock);
         uint8_t* d = nullptr;
+        int* d_bm = nullptr;
         RTO_HIP(c, scratch.alloc(&d, cells));
+        RTO_HIP(c, scratch.alloc(&d_bm, (size_t)nbl));
         V.level[l] = d;
-        hipLaunchKernelGGL(k_pyramid_level, dim3((unsigned)((cells + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                           V.level[l - 1], V.nx[l - 1], V.ny[l - 1], V.nz[l - 1], d, V.nx[l], V.ny[l], V.nz[l], 1 << l, dimX, dimY, dimZ);
+        LC.blockMixed[l] = d_bm; LC.numBlocks[l] = (int)nbl;
+        hipLaunchKernelGGL(k_pyramid_level, dim3(nbl), dim3(kBlock), 0, s,
+                           V.level[l - 1], V.nx[l - 1], V.ny[l - 1], V.nz[l - 1], d, V.nx[l], V.ny[l], V.nz[l], 1 << l, dimX, dimY, dimZ, d_bm);
     }
     RTO_HIP(c, hipGetLastError());
+    std::vector<long long> mixed((size_t)R + 1, 0);
+    if (R > 0) {
+        long long* d_mixed = nullptr;
+        RTO_HIP(c, scratch.alloc(&d_mixed, (size_t)R + 1));
+        hipLaunchKernelGGL(k_sum_level_counts, dim3((unsigned)R), dim3(1024), 0, s, LC, d_mixed);
+        RTO_HIP(c, hipGetLastError());
+        RTO_HIP(c, hipMemcpyAsync(mixed.data() + 1, d_mixed + 1, (size_t)R * sizeof(long long), hipMemcpyDeviceToHost, s));
+        RTO_HIP(c, hipStreamSynchronize(s));      // the only read-back before the tree is complete
+    }
 
-    // ---- pass 1: level-order node lists, internal flags and ranks
+    // ---- pass 1: level-order node lists, internal flags and ranks.  Tree level L holds the cells of pyramid level
+    //      R - L; its internal nodes are that level's mixed cells, so every size is known up front and the loop
+    //      below runs without touching the host.
     std::vector<LevelBuf> levels;
     {
-        LevelBuf L0; L0.m = 1;
-        RTO_HIP(c, scratch.alloc(&L0.coords, 1));
-        const int4 rootc = make_int4(0, 0, 0, 0);
-        RTO_HIP(c, hipMemcpyAsync(L0.coords, &rootc, sizeof rootc, hipMemcpyHostToDevice, s));
-        levels.push_back(L0);
-    }
-    for (int L = 0; L <= R; L++) {
-        LevelBuf& lb = levels[(size_t)L];
-        const int lv = R - L;
-        const int nb = (int)((lb.m + kBlock - 1) / kBlock);
-        int *d_bc = nullptr, *d_bb = nullptr;
-        RTO_HIP(c, scratch.alloc(&lb.state, (size_t)lb.m)); RTO_HIP(c, scratch.alloc(&lb.flag, (size_t)lb.m));
-        RTO_HIP(c, scratch.alloc(&lb.rank, (size_t)lb.m));
-        RTO_HIP(c, scratch.alloc(&d_bc, (size_t)nb)); RTO_HIP(c, scratch.alloc(&d_bb, (size_t)nb));
-        hipLaunchKernelGGL(k_build_classify, dim3(nb), dim3(kBlock), 0, s, V, lb.coords, lb.m, lv, lb.state, lb.flag, d_bc);
-        hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, s, d_bc, nb, d_bb, c->d_visibleCount);
-        hipLaunchKernelGGL(k_cull_remap, dim3(nb), dim3(kBlock), 0, s, lb.flag, lb.m, d_bb, lb.rank);
-        RTO_HIP(c, hipGetLastError());
-        int64_t k = 0;
-        RTO_HIP(c, hipMemcpyAsync(&k, c->d_visibleCount, sizeof k, hipMemcpyDeviceToHost, s));
-        RTO_HIP(c, hipStreamSynchronize(s));
-        lb.k = k;
-        if (k == 0) break;
-        LevelBuf next; next.m = k * 8;
-        if (next.m > 0x7fffffff) return fail(c, RTO_E_UNSUPPORTED, "rto_build_octree: more than 2^31 nodes on one level");
-        RTO_HIP(c, scratch.alloc(&next.coords, (size_t)next.m));
-        hipLaunchKernelGGL(k_build_children, dim3(nb), dim3(kBlock), 0, s, lb.coords, lb.rank, lb.m, (1 << lv) / 2, next.coords);
-        RTO_HIP(c, hipGetLastError());
-        levels.push_back(next);
+        int64_t m = 1;
+        for (int L = 0; L <= R && m > 0; L++) {
+            LevelBuf lb; lb.m = m;
+            lb.k = (L < R) ? (int64_t)mixed[(size_t)(R - L)] : 0;
+            if (lb.m > 0x7fffffff) return fail(c, RTO_E_UNSUPPORTED, "rto_build_octree: more than 2^31 nodes on one level");
+            levels.push_back(lb);
+            m = lb.k * 8;
+        }
     }
     int64_t total = 0, internal = 0;
     for (const LevelBuf& lb : levels) { total += lb.m; internal += lb.k; }
     if (total > 0x7fffffff) return fail(c, RTO_E_UNSUPPORTED, "rto_build_octree: node indices are int32 (GPUNodes.child)");
-
-    // ---- pass 2: node records + descriptors
+    // every allocation first (the result arrays are real hipMallocs, ~0.1 ms each), then all kernels back to back
     RTO_HIP(c, hipMalloc(&c->d_nodes, (size_t)total * sizeof(rto_node)));
     if (internal > 0) {
         RTO_HIP(c, hipMalloc(&c->d_desc, (size_t)internal * sizeof(uint2)));
         RTO_HIP(c, hipMalloc(&c->d_descFirstChild, (size_t)internal * sizeof(int)));
     }
+    std::vector<int*> d_bc(levels.size(), nullptr), d_bb(levels.size(), nullptr);
+    for (size_t L = 0; L < levels.size(); L++) {
+        LevelBuf& lb = levels[L];
+        const size_t nb = (size_t)((lb.m + kBlock - 1) / kBlock);
+        RTO_HIP(c, scratch.alloc(&lb.coords, (size_t)lb.m));
+        RTO_HIP(c, scratch.alloc(&lb.state, (size_t)lb.m)); RTO_HIP(c, scratch.alloc(&lb.flag, (size_t)lb.m));
+        RTO_HIP(c, scratch.alloc(&lb.rank, (size_t)lb.m));
+        RTO_HIP(c, scratch.alloc(&d_bc[L], nb)); RTO_HIP(c, scratch.alloc(&d_bb[L], nb));
+    }
+    int* d_bbox = nullptr;
+    RTO_HIP(c, scratch.alloc(&d_bbox, 6));
+    RTO_HIP(c, hipMemsetAsync(levels[0].coords, 0, sizeof(int4), s));     // the root: (0, 0, 0)
+    for (size_t L = 0; L < levels.size(); L++) {
+        LevelBuf& lb = levels[L];
+        const int lv = R - (int)L;
+        const int nb = (int)((lb.m + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_build_classify, dim3(nb), dim3(kBlock), 0, s, V, lb.coords, lb.m, lv, lb.state, lb.flag, d_bc[L]);
+        hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, s, d_bc[L], nb, d_bb[L], c->d_visibleCount);
+        hipLaunchKernelGGL(k_build_rank_children, dim3(nb), dim3(kBlock), 0, s, lb.flag, lb.coords, lb.m, d_bb[L], (1 << lv) / 2, lb.rank,
+                           L + 1 < levels.size() ? levels[L + 1].coords : (int4*)nullptr);
+    }
+    RTO_HIP(c, hipGetLastError());
+
+    // ---- pass 2: node records + descriptors
     int64_t levelBase = 0, internalBase = 0;
     for (size_t L = 0; L < levels.size(); L++) {
         const LevelBuf& lb = levels[L];
@@ -420,8 +451,6 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     }
     RTO_HIP(c, hipGetLastError());
     // ---- where the solid geometry is (launch-order heuristic)
-    int* d_bbox = nullptr;
-    RTO_HIP(c, scratch.alloc(&d_bbox, 6));
     const int initBox[6] = { 0x7fffffff, 0x7fffffff, 0x7fffffff, -0x7fffffff, -0x7fffffff, -0x7fffffff };
     RTO_HIP(c, hipMemcpyAsync(d_bbox, initBox, sizeof initBox, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_solid_bbox, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, s, c->d_nodes, total, d_bbox);
@@ -712,8 +741,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     if (c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
     RTO_HIP(c, hipEventRecord(evA, s));
     if (packed) {
-        size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint2);
-        if (const char* pad = std::getenv("RTO_LDS_PAD")) lds += (size_t)std::atoi(pad);   // tuning aid: caps workgroups per CU
+        const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint2);
         if (c->kernelMode == RTO_KERNEL_PACKED_V1)
             hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
         else {
@@ -982,7 +1010,7 @@ int rto_build_leaf_triangles(rto_context* c, const uint8_t* voxels, int dimX, in
     RTO_HIP(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     RTO_HIP(c, hipStreamSynchronize(s));
-    BuildScratch scratch;
+    BuildScratch scratch(c->stream);
     hipEvent_t e0, e1, e2;
     RTO_HIP(c, hipEventCreate(&e0)); RTO_HIP(c, hipEventCreate(&e1)); RTO_HIP(c, hipEventCreate(&e2));
     struct EvGuard { hipEvent_t a, b, d; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(d); } } evg{ e0, e1, e2 };

@@ -1321,24 +1321,44 @@ __device__ __forceinline__ int pyr_state(const PyramidView& V, int lv, int x, in
 }
 
 // one thread per cell of level lv >= 1; children at level lv-1 (voxels for lv == 1)
+// blockMixed[block] = number of mixed cells the block produced.  A mixed cell of pyramid level lv IS an internal node
+// of the tree (its ancestors are mixed too), so these counts give every tree level's size before the tree is walked.
 __global__ __launch_bounds__(kBlock) void k_pyramid_level(const uint8_t* __restrict__ child, int cnx, int cny, int cnz,
                                                            uint8_t* __restrict__ out, int nx, int ny, int nz,
-                                                           int ext, int dimX, int dimY, int dimZ) {
+                                                           int ext, int dimX, int dimY, int dimZ, int* __restrict__ blockMixed) {
     const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const size_t total = (size_t)nx * ny * nz;
-    if (t >= total) return;
-    const int i = (int)(t % nx), j = (int)((t / nx) % ny), k = (int)(t / ((size_t)nx * ny));
-    // the cell sticks out of the grid (its out-of-grid voxels are EMPTY) iff its extent passes a grid dimension
-    bool any0 = (i + 1) * (long)ext > dimX || (j + 1) * (long)ext > dimY || (k + 1) * (long)ext > dimZ;
-    bool any1 = false, mixed = false;
+    bool isMixed = false;
+    if (t < total) {
+        const int i = (int)(t % nx), j = (int)((t / nx) % ny), k = (int)(t / ((size_t)nx * ny));
+        // the cell sticks out of the grid (its out-of-grid voxels are EMPTY) iff its extent passes a grid dimension
+        bool any0 = (i + 1) * (long)ext > dimX || (j + 1) * (long)ext > dimY || (k + 1) * (long)ext > dimZ;
+        bool any1 = false, mixed = false;
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const int ci = 2 * i + (c & 1), cj = 2 * j + ((c >> 1) & 1), ck = 2 * k + (c >> 2);
-        if (ci >= cnx || cj >= cny || ck >= cnz) continue;
-        const uint8_t s = child[(size_t)ci + (size_t)cj * cnx + (size_t)ck * cnx * cny];
-        mixed |= (s == 2); any1 |= (s == 1); any0 |= (s == 0);
+        for (int c = 0; c < 8; c++) {
+            const int ci = 2 * i + (c & 1), cj = 2 * j + ((c >> 1) & 1), ck = 2 * k + (c >> 2);
+            if (ci >= cnx || cj >= cny || ck >= cnz) continue;
+            const uint8_t s = child[(size_t)ci + (size_t)cj * cnx + (size_t)ck * cnx * cny];
+            mixed |= (s == 2); any1 |= (s == 1); any0 |= (s == 0);
+        }
+        isMixed = mixed || (any0 && any1);
+        out[t] = isMixed ? 2 : (any1 ? 1 : 0);
     }
-    out[t] = (mixed || (any0 && any1)) ? 2 : (any1 ? 1 : 0);
+    const int cnt = __syncthreads_count(isMixed ? 1 : 0);
+    if (threadIdx.x == 0) blockMixed[blockIdx.x] = cnt;
+}
+
+// one block per pyramid level: levelMixed[l] = sum of that level's per-block counts
+struct LevelCountView { const int* blockMixed[kMaxDepth + 1]; int numBlocks[kMaxDepth + 1]; };
+__global__ __launch_bounds__(1024) void k_sum_level_counts(LevelCountView V, long long* __restrict__ levelMixed) {
+    __shared__ long long partial[1024 / kWave];
+    const int l = blockIdx.x + 1;
+    long long sum = 0;
+    for (int i = threadIdx.x; i < V.numBlocks[l]; i += 1024) sum += V.blockMixed[l][i];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { long long t = 0; for (int w = 0; w < 1024 / kWave; w++) t += partial[w]; levelMixed[l] = t; }
 }
 
 // classify the nodes of one tree level: internal flag + per-block internal count
@@ -1358,13 +1378,25 @@ __global__ __launch_bounds__(kBlock) void k_build_classify(PyramidView V, const 
     if (threadIdx.x == 0) blockCount[blockIdx.x] = cnt;
 }
 
-// children of the internal nodes of a level, in (node order, child slot) order = the next level's node list
-__global__ __launch_bounds__(kBlock) void k_build_children(const int4* __restrict__ coords, const int* __restrict__ rank, int64_t m,
-                                                            int half, int4* __restrict__ next) {
+// rank of the internal nodes of a level (exclusive count of the flags before them, -1 for leaves) and, in the same
+// pass, the coordinates of their children = the next level's node list
+__global__ __launch_bounds__(kBlock) void k_build_rank_children(const uint8_t* __restrict__ flag, const int4* __restrict__ coords, int64_t m,
+                                                                 const int* __restrict__ blockBase, int half, int* __restrict__ rank,
+                                                                 int4* __restrict__ next) {
+    __shared__ int waveTotal[kBlock / kWave];
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool v = (i < m) && flag[i];
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int before = __builtin_popcountll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) waveTotal[wave] = __builtin_popcountll(b);
+    __syncthreads();
+    int base = blockBase[blockIdx.x];
+    for (int w = 0; w < wave; w++) base += waveTotal[w];
     if (i >= m) return;
-    const int r = rank[i];
-    if (r < 0) return;
+    const int r = v ? base + before : -1;
+    rank[i] = r;
+    if (r < 0 || !next) return;
     const int4 c = coords[i];
 #pragma unroll
     for (int k = 0; k < 8; k++)   // S/OctreeVoxel.cpp:751-754: bit0 -> +x, bit1 -> +y, bit2 -> +z
