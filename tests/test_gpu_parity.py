@@ -173,6 +173,42 @@ def test_config4_calgary(ctx, orc, scenes, camera, golden_meta, cam_name, W, H):
         assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"])
 
 
+def test_config4_resampled_to_512x512x128(ctx, orc, scenes, camera):
+    """BASELINE.json names config 4 as "voxelized at 512x512x128"; that grid cannot be regenerated (its source data is
+    absent upstream).  SURVEY 8d's stand-in: a nearest-neighbour resample of the shipped 425x243x29 grid to
+    512x512x128 -- SYNTHETIC, labelled as such -- at 1920x1080 with the oblique (divergent) camera."""
+    src = scenes("calgary")
+    d = src.grid.data                                   # (dimZ, dimY, dimX)
+    tz, ty, tx = 128, 512, 512
+    iz = ((np.arange(tz) + 0.5) * d.shape[0] / tz).astype(np.int64)
+    iy = ((np.arange(ty) + 0.5) * d.shape[1] / ty).astype(np.int64)
+    ix = ((np.arange(tx) + 0.5) * d.shape[2] / tx).astype(np.int64)
+    data = np.ascontiguousarray(d[iz][:, iy][:, :, ix])
+    g = orc.Grid((tx, ty, tz), src.min, src.voxel, data)
+    s = Scene(g, orc.build_flat_octree(g))
+    assert s.nodes[0]["size"] == 512
+    upload(ctx, s)
+    W, H = 1920, 1080
+    cam = orc.Camera(0.6, 0.5, 4500.0)
+    cam.set_target(*[float(x) for x in (g.min + 0.5 * np.array(g.dims, np.float32) * g.voxel_size)])
+    view, pos = cam.get_view(), cam.get_pos()
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, st = oracle_frame(orc, s, view, pos, W, H)
+    assert st["hits"] > 100_000
+    for kname, kernel in KERNELS:
+        ctx.set_kernel(kernel)
+        assert_bit_exact(ctx.render_host(f), want, f"config 4 resampled {kname}")
+        gs = ctx.frame_stats(f)
+        assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"]), kname
+    ctx.set_kernel(rto.KERNEL_AUTO)
+    ctx.render_host(f); ctx.render_host(f)
+    print(f"config 4 (synthetic 512x512x128 resample, {len(s.nodes)} nodes): {st['hits']} hits, {st['pops'] / (W * H):.1f} pops/ray, "
+          f"{st['capped']} capped, kernel {ctx.last_kernel_ms() * 1e3:.1f} us")
+    # the GPU builder makes the same array from these voxels
+    ctx.build_octree(data, g.min, g.voxel_size)
+    assert ctx.download_nodes().tobytes() == s.nodes.tobytes()
+
+
 def test_config5_primary_rays_512_4k(ctx, orc, scenes, camera):
     """BASELINE config 5, primary rays only (the triangle/shadow extension has no reference): 512^3, 3840x2160."""
     s = scenes("sphere512")
