@@ -53,12 +53,16 @@ class HipBackend:
     """Product backend: torch CUDA(HIP) tensors as device buffers, kernels through the C ABI on torch's
     current stream (so RCCL collectives issued by torch order themselves behind the render)."""
 
-    def __init__(self, ctx: hip.Context):
+    def __init__(self, ctx: hip.Context, triangles: bool = False, shadow: bool = True):
+        """triangles=True renders BASELINE config 5's path (leaf triangles + `shadow` ray; upload or build the triangle
+        buffer on every rank's context first) instead of the solid-leaf octree path."""
         import torch
 
         self.torch = torch
         self.ctx = ctx
         self.device = torch.device("cuda", ctx.device)
+        self.triangles = triangles
+        self.shadow = shadow
 
     def _stream(self) -> int:
         return self.torch.cuda.current_stream(self.device).cuda_stream
@@ -67,7 +71,12 @@ class HipBackend:
         return self.torch.empty(shape, dtype=self.torch.float32, device=self.device)
 
     def render_part(self, frame: hip.Frame, part: hip.Partition | None, out, payload: str = "rgba"):
-        if payload == "shade":
+        if self.triangles:
+            if payload == "shade":
+                self.ctx.render_triangles_shade_device(frame, out.data_ptr(), self.shadow, part, self._stream())
+            else:
+                self.ctx.render_triangles_device(frame, out.data_ptr(), self.shadow, part, self._stream())
+        elif payload == "shade":
             self.ctx.render_shade_device(frame, out.data_ptr(), part, self._stream())
         else:
             self.ctx.render_device(frame, out.data_ptr(), part, self._stream())

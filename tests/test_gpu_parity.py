@@ -830,6 +830,12 @@ def test_config5_shadows_exist_and_partitions_agree(ctx, orc, scenes):
         ctx.synchronize()
         assert_bit_exact(frame.cpu().numpy(), shd, f"triangle path, 3 parts, shade payload, {kname}")
     ctx.set_kernel(rto.KERNEL_AUTO)
+    # the renderer class drives the same path (world size 1 needs no process group)
+    from ray_tracing_octrees_amd import tilesplit
+    r = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx, triangles=True, shadow=True), 0, 1)
+    img = r.render(f)
+    torch.cuda.synchronize()
+    assert_bit_exact(img.cpu().numpy(), shd, "TileSplitRenderer, triangle backend")
     # error paths
     fresh = rto.Context(0)
     fresh.upload_octree(scenes("sphere16").nodes, scenes("sphere16").min, scenes("sphere16").voxel)
