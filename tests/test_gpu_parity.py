@@ -14,6 +14,7 @@ import ray_tracing_octrees_amd as rto
 from ray_tracing_octrees_amd import hip
 from conftest import Scene, assert_bit_exact
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 TOL = 1e-4   # north-star tolerance; never reached: see assert_bit_exact
 
@@ -582,6 +583,21 @@ def test_cpp_dropin_class_end_to_end(orc, scenes, camera):
     rt3.renderSceneCompute(cam, W, H, W / H, 45.0)
     assert rt3.framebuffer() is None
     rto.freeOctree(root)
+
+
+def test_plain_cpp_example_renders_config1(tmp_path):
+    """examples/render_sphere: main.cpp's call sequence in plain C++ on the product's host layer (no Python in the
+    process).  BASELINE config 1 -- 64^3 sphere, 512x512 -- must light the 65,009 pixels SURVEY.md records."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "examples", "render_sphere")
+    assert os.path.exists(exe), "built by __graft_entry__.build()"
+    out = tmp_path / "frame.ppm"
+    env = dict(os.environ, RTO_HIP_LIB=os.path.join(ROOT, "ray_tracing_octrees_amd", "librto_hip.so"))
+    p = subprocess.run([exe, "64", "512", "512", str(out)], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "23561 nodes" in p.stdout and "65009 lit pixels" in p.stdout, p.stdout
+    assert out.stat().st_size == len(b"P6\n512 512\n255\n") + 512 * 512 * 3
 
 
 def test_reference_host_stack_drives_the_hip_path(orc, scenes, camera, tmp_path):
