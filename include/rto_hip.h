@@ -142,6 +142,18 @@ int  rto_render_device(rto_context* ctx, const rto_frame* frame, const rto_parti
 /* Synchronous convenience: whole frame into host memory (the one API addition the
  * reference lacks: its texture is never read back). */
 int  rto_render_host(rto_context* ctx, const rto_frame* frame, float* host_rgba);
+/* The reference renders into a GL texture that stays on the GPU (S/RayTracerBVH.cpp:630-646, 684-688) and never reads
+ * it back.  Same here: rto_render_resident renders the whole frame into the context's own device framebuffer
+ * (asynchronous, on rto_stream(ctx)); mode RTO_RESIDENT_OCTREE = the octree path, RTO_RESIDENT_TRIANGLES /
+ * RTO_RESIDENT_TRIANGLES_SHADOW = the leaf-triangle path of config 5.  rto_resident_frame returns the device pointer
+ * (RGBA32F, width*height*16 bytes; valid until a render of another size or rto_destroy) for display interop or further
+ * device work; rto_download_resident copies it to the host (synchronises). */
+#define RTO_RESIDENT_OCTREE 0
+#define RTO_RESIDENT_TRIANGLES 1
+#define RTO_RESIDENT_TRIANGLES_SHADOW 2
+int  rto_render_resident(rto_context* ctx, const rto_frame* frame, int mode);
+int  rto_resident_frame(rto_context* ctx, void** d_rgba, int* width, int* height);
+int  rto_download_resident(rto_context* ctx, float* host_rgba);
 /* Number of rows part `part` owns. */
 int  rto_partition_rows(const rto_frame* frame, const rto_partition* part);
 /* Reassembles num_parts compact buffers laid end to end (as a gather delivers them;

@@ -51,6 +51,7 @@ struct rto_context {
     // The tables are written and read by kernels in stream order, so every launch stream owns a set of its own:
     // frames in flight on different streams of one context never share (or race on) a table.
     int numCUs = 256;
+    int residentW = 0, residentH = 0;   // size of the frame rto_render_resident left in d_frame
     int orderPolicy = 1;            // 0 = centre-out only, 1 = temporal (falls back to centre-out without history)
     int orderPeriod = 4;            // rebuild the table every orderPeriod-th frame (cost maps change slowly)
     struct OrderState {
@@ -825,6 +826,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
 }
 
 static int ensure_frame(rto_context* c, size_t pixels) {
+    c->residentW = c->residentH = 0;          // whoever asks for the buffer is about to overwrite it
     if (c->frameCap >= pixels) return RTO_OK;
     (void)hipFree(c->d_frame); c->d_frame = nullptr; c->frameCap = 0;
     RTO_HIP(c, hipMalloc(&c->d_frame, pixels * sizeof(float4)));
@@ -1134,6 +1136,46 @@ int rto_render_triangles_device(rto_context* c, const rto_frame* f, const rto_pa
     if (!d_out) return fail(c, RTO_E_INVALID, "rto_render_triangles_device: d_out is NULL");
     RTO_HIP(c, hipSetDevice(c->device));
     return launch_triangles(c, f, p, shadow, (float4*)d_out, (hipStream_t)hip_stream, false);
+}
+
+int rto_render_resident(rto_context* c, const rto_frame* f, int mode) {
+    if (!c) return RTO_E_INVALID;
+    if (!f) return fail(c, RTO_E_INVALID, "rto_render_resident: frame is NULL");
+    if (mode < RTO_RESIDENT_OCTREE || mode > RTO_RESIDENT_TRIANGLES_SHADOW) return fail(c, RTO_E_INVALID, "rto_render_resident: unknown mode");
+    RTO_HIP(c, hipSetDevice(c->device));
+    if (f->width <= 0 || f->height <= 0) return fail(c, RTO_E_INVALID, "rto_render_resident: empty frame");
+    const size_t pixels = (size_t)f->width * f->height;
+    int rc = ensure_frame(c, pixels);
+    if (rc != RTO_OK) return rc;
+    c->residentW = c->residentH = 0;
+    if (mode == RTO_RESIDENT_OCTREE) {
+        RenderParams P;
+        if ((rc = fill_params(c, f, nullptr, P)) != RTO_OK) return rc;
+        if ((rc = launch_trace<kModeColor>(c, P, c->d_frame, c->stream)) != RTO_OK) return rc;
+    } else {
+        if ((rc = launch_triangles(c, f, nullptr, mode == RTO_RESIDENT_TRIANGLES_SHADOW ? 1 : 0, c->d_frame, c->stream, false)) != RTO_OK) return rc;
+    }
+    c->residentW = f->width; c->residentH = f->height;
+    return RTO_OK;
+}
+
+int rto_resident_frame(rto_context* c, void** d_rgba, int* width, int* height) {
+    if (!c) return RTO_E_INVALID;
+    if (c->residentW <= 0) return fail(c, RTO_E_INVALID, "rto_resident_frame: nothing rendered with rto_render_resident yet");
+    if (d_rgba) *d_rgba = c->d_frame;
+    if (width) *width = c->residentW;
+    if (height) *height = c->residentH;
+    return RTO_OK;
+}
+
+int rto_download_resident(rto_context* c, float* host_rgba) {
+    if (!c) return RTO_E_INVALID;
+    if (!host_rgba) return fail(c, RTO_E_INVALID, "rto_download_resident: host_rgba is NULL");
+    if (c->residentW <= 0) return fail(c, RTO_E_INVALID, "rto_download_resident: nothing rendered with rto_render_resident yet");
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipMemcpyAsync(host_rgba, c->d_frame, (size_t)c->residentW * c->residentH * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    return RTO_OK;
 }
 
 int rto_render_triangles_shade_device(rto_context* c, const rto_frame* f, const rto_partition* p, int shadow, void* d_shade, void* hip_stream) {

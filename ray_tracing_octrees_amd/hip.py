@@ -28,7 +28,7 @@ SYMBOLS = (
     "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel", "rto_set_launch_order",
     "rto_update_frustum", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
-    "rto_render_shade_device", "rto_assemble_shade_device",
+    "rto_render_shade_device", "rto_assemble_shade_device", "rto_render_resident", "rto_resident_frame", "rto_download_resident",
     "rto_upload_leaf_triangles", "rto_build_leaf_triangles", "rto_download_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
 )
@@ -102,6 +102,9 @@ def load():
     L.rto_render_host.argtypes = [vp, C.POINTER(Frame), vp]
     L.rto_partition_rows.argtypes = [C.POINTER(Frame), C.POINTER(Partition)]
     L.rto_assemble_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp, vp]
+    L.rto_render_resident.argtypes = [vp, C.POINTER(Frame), C.c_int]
+    L.rto_resident_frame.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.rto_download_resident.argtypes = [vp, vp]
     L.rto_render_shade_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp]
     L.rto_assemble_shade_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp, vp]
     L.rto_render_triangles_shade_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), C.c_int, vp, vp]
@@ -231,6 +234,22 @@ class Context:
     def render_host(self, frame: Frame) -> np.ndarray:
         out = np.empty((frame.height, frame.width, 4), np.float32)
         self._check(self._L.rto_render_host(self._h, C.byref(frame), out.ctypes.data))
+        return out
+
+    def render_resident(self, frame: Frame, mode: int = 0):
+        """Asynchronous render into the context's own device framebuffer (0 octree, 1 triangles, 2 triangles + shadow)."""
+        self._check(self._L.rto_render_resident(self._h, C.byref(frame), mode))
+
+    def resident_frame(self):
+        """(device pointer, width, height) of the frame render_resident left on the GPU."""
+        p, w, h = C.c_void_p(), C.c_int(), C.c_int()
+        self._check(self._L.rto_resident_frame(self._h, C.byref(p), C.byref(w), C.byref(h)))
+        return p.value, w.value, h.value
+
+    def download_resident(self) -> np.ndarray:
+        _, w, h = self.resident_frame()
+        out = np.empty((h, w, 4), np.float32)
+        self._check(self._L.rto_download_resident(self._h, out.ctypes.data))
         return out
 
     def render_device(self, frame: Frame, d_out: int, part: Partition | None = None, stream: int = 0):

@@ -25,6 +25,9 @@ struct HipApi {
     decltype(&rto_render_host) render_host = nullptr;
     decltype(&rto_upload_leaf_triangles) upload_leaf_triangles = nullptr;
     decltype(&rto_build_leaf_triangles) build_leaf_triangles = nullptr;
+    decltype(&rto_render_resident) render_resident = nullptr;
+    decltype(&rto_download_resident) download_resident = nullptr;
+    decltype(&rto_synchronize) synchronize = nullptr;
     decltype(&rto_render_triangles_host) render_triangles_host = nullptr;
     std::string error;
 
@@ -62,6 +65,9 @@ struct HipApi {
         render_host = reinterpret_cast<decltype(render_host)>(sym("rto_render_host"));
         upload_leaf_triangles = reinterpret_cast<decltype(upload_leaf_triangles)>(sym("rto_upload_leaf_triangles"));
         build_leaf_triangles = reinterpret_cast<decltype(build_leaf_triangles)>(sym("rto_build_leaf_triangles"));
+        render_resident = reinterpret_cast<decltype(render_resident)>(sym("rto_render_resident"));
+        download_resident = reinterpret_cast<decltype(download_resident)>(sym("rto_download_resident"));
+        synchronize = reinterpret_cast<decltype(synchronize)>(sym("rto_synchronize"));
         render_triangles_host = reinterpret_cast<decltype(render_triangles_host)>(sym("rto_render_triangles_host"));
         if (!ok) { dlclose(handle); handle = nullptr; }
         return ok;
@@ -184,13 +190,15 @@ bool RayTracerBVH::render(const Camera& camera, int width, int height, float asp
     f.width = width;
     f.height = height;
     if (width <= 0 || height <= 0) return false;
-    m_frame.resize(static_cast<size_t>(width) * height * 4);
-    m_frameW = width; m_frameH = height;
-    if (api().render_host(m_ctx, &f, m_frame.data()) != RTO_OK) {
+    // like the reference's texture, the frame stays on the GPU (asynchronous); framebuffer() fetches it on demand
+    m_frameW = m_frameH = 0; m_frameStale = false;
+    if (api().render_resident(m_ctx, &f, RTO_RESIDENT_OCTREE) != RTO_OK) {
         m_lastError = api().last_error(m_ctx);
         std::cerr << "[RayTracerBVH] render failed: " << m_lastError << std::endl;
+        m_frame.clear();
         return false;
     }
+    m_frameW = width; m_frameH = height; m_frameStale = true;
     return true;
 }
 
@@ -240,13 +248,31 @@ void RayTracerBVH::renderSceneTriangles(const Camera& camera, int width, int hei
     const auto pos = camera.getPos();
     f.cam_pos[0] = pos.x; f.cam_pos[1] = pos.y; f.cam_pos[2] = pos.z;
     f.aspect = aspect; f.fov_deg = fovDeg; f.width = width; f.height = height;
-    m_frame.resize(static_cast<size_t>(width) * height * 4);
-    m_frameW = width; m_frameH = height;
-    if (api().render_triangles_host(m_ctx, &f, shadow ? 1 : 0, m_frame.data(), nullptr) != RTO_OK) {
+    m_frameW = m_frameH = 0; m_frameStale = false;
+    if (api().render_resident(m_ctx, &f, shadow ? RTO_RESIDENT_TRIANGLES_SHADOW : RTO_RESIDENT_TRIANGLES) != RTO_OK) {
         m_lastError = api().last_error(m_ctx);
         std::cerr << "[RayTracerBVH] render failed: " << m_lastError << std::endl;
-        m_frame.clear(); m_frameW = m_frameH = 0;
+        m_frame.clear();
+        return;
     }
+    m_frameW = width; m_frameH = height; m_frameStale = true;
+}
+
+const std::vector<float>& RayTracerBVH::framebuffer() const {
+    if (m_frameStale && m_ctx) {
+        m_frame.resize(static_cast<size_t>(m_frameW) * m_frameH * 4);
+        if (api().download_resident(m_ctx, m_frame.data()) != RTO_OK) {
+            m_lastError = api().last_error(m_ctx);
+            std::cerr << "[RayTracerBVH] frame read-back failed: " << m_lastError << std::endl;
+            m_frame.clear();
+        }
+        m_frameStale = false;
+    }
+    return m_frame;
+}
+
+void RayTracerBVH::finish() const {
+    if (m_ctx) (void)api().synchronize(m_ctx);
 }
 
 void RayTracerBVH::renderSceneCompute(const Camera& camera, int width, int height, float aspect, float fovDeg) {

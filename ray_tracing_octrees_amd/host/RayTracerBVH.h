@@ -76,7 +76,11 @@ public:
     static std::vector<GPUNodes> flatten(const OctreeNode* root);
     const std::vector<GPUNodes>& flatNodes() const { return m_flatNodes; }   // empty after setOctreeFromGrid
     int numNodes() const { return m_numNodes; }
-    const std::vector<float>& framebuffer() const { return m_frame; }   // width*height*4 floats of the last render
+    // The renders are asynchronous and leave the frame on the GPU, as the reference's texture is (its image is never
+    // read back); framebuffer() copies it to the host on first use after a render (width*height*4 floats, row 0 = top)
+    // and finish() just waits for the GPU -- the counterpart of glFinish for timing loops.
+    const std::vector<float>& framebuffer() const;
+    void finish() const;
     int frameWidth() const { return m_frameW; }
     int frameHeight() const { return m_frameH; }
     void setDevice(int ordinal) { m_device = ordinal; }                  // before ensureComputeInitialized()
@@ -96,8 +100,9 @@ private:
     bool m_frustumCullingEnabled;
     int m_device;
     rto_context* m_ctx;
-    std::string m_lastError;
+    mutable std::string m_lastError;
 
-    std::vector<float> m_frame;
+    mutable std::vector<float> m_frame;
+    mutable bool m_frameStale = false;   // the GPU holds a newer frame than m_frame
     int m_frameW, m_frameH;
 };

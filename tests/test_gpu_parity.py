@@ -500,6 +500,39 @@ def test_frames_in_flight_on_several_streams_of_one_context(ctx, orc, scenes):
         ctx.set_launch_order(1, 4)
 
 
+def test_resident_frame_stays_on_the_gpu(ctx, orc, scenes, camera):
+    """rto_render_resident leaves the frame in the context's device buffer (the reference's texture is never read
+    back either); rto_download_resident / the device pointer give the oracle's pixels, for the octree and triangle paths."""
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere32")
+    view, pos = camera("sphere")
+    upload(ctx, s)
+    W, H = 320, 200
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, _ = oracle_frame(orc, s, view, pos, W, H)
+    for _ in range(3):
+        ctx.render_resident(f)
+    assert_bit_exact(ctx.download_resident(), want, "resident octree frame")
+    ptr, w, h = ctx.resident_frame()
+    assert (w, h) == (W, H) and ptr
+    # the device pointer is usable by other device work: re-interleave it as a 1-part "gather"
+    frame = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    ctx.assemble_device(f, hip.Partition(1, 0, 16), ptr, frame.data_ptr(), ctx.stream)
+    ctx.synchronize()
+    assert_bit_exact(frame.cpu().numpy(), want, "resident frame through its device pointer")
+    wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
+    ctx.build_leaf_triangles(s.grid.data)
+    for mode, shadow in ((1, False), (2, True)):
+        wtri, _ = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, view, pos, W / H, 45.0, W, H, shadow=shadow)
+        ctx.render_resident(f, mode)
+        assert_bit_exact(ctx.download_resident(), wtri, f"resident triangle frame, mode {mode}")
+    ctx.render_host(f)                       # any other user of the buffer invalidates the resident frame
+    with pytest.raises(rto.RtoError):
+        ctx.resident_frame()
+    with pytest.raises(rto.RtoError):
+        ctx.render_resident(f, 7)
+
+
 def test_render_device_on_a_caller_stream(ctx, scenes, camera):
     torch = pytest.importorskip("torch")
     s = scenes("sphere32")
