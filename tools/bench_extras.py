@@ -79,5 +79,20 @@ for n in (49, 1 << 20):
         ctx.octree_ray_skip(pos, rd)
     out[f"octree_ray_skip_{n}_rays_ms_incl_copies"] = round((time.perf_counter() - t) / 5 * 1e3, 3)
 
+# ---- frustum update (A7): GPU cull + compaction + visibility masks vs the reference's CPU loop + SSBO re-upload
+for dim, gg in ((256, g256), (512, g)):
+    ctx.build_octree(gg.data, gg.min, gg.voxelSize)
+    cam2 = rto.Camera(0.5, 0.7, 0.9)            # close enough that part of the sphere leaves the frustum
+    view = cam2.getView()
+    ctx.update_frustum(view, 45.0, 16 / 9, enable=True)
+    ts = []
+    for _ in range(10):
+        t = time.perf_counter()
+        ctx.update_frustum(view, 45.0, 16 / 9, enable=True)
+        ts.append(time.perf_counter() - t)
+    out[f"frustum_update_{dim}_ms_wall"] = round(float(np.median(ts)) * 1e3, 3)
+    out[f"frustum_update_{dim}_visible_nodes"] = int(len(ctx.download_visible_nodes()))
+    ctx.update_frustum(view, 45.0, 16 / 9, enable=False)
+
 # ---- config 4: the shipped scene cache is not on the GPU box; calgary fixture lives in tests/golden
 print(json.dumps(out))
