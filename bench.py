@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--payload", choices=["shade", "rgba"], default="shade",
                     help="N>1: what a part ships to rank 0 -- 4-byte Lambert term per pixel (default) or the 16-byte pixel")
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: finish the gather of a frame before rendering the next")
+    ap.add_argument("--pipelines", type=int, default=2,
+                    help="N>1: independent submit/flush pipelines, each on its own HIP stream, that take the frames in turn "
+                         "(a part's kernel is bounded by its deepest rays, not by its pixel count, so one pipeline leaves "
+                         "most of each GPU idle); 1 = a single pipeline")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="N=1 only: render consecutive frames on this many HIP streams (own framebuffers) so that the "
                          "deep-ray tail of one frame overlaps the start of the next; 1 = strictly one frame at a time")
@@ -150,9 +154,12 @@ def main():
                     "generic": rto.KERNEL_GENERIC}[args.kernel])
     ctx.set_launch_order(1 if args.order == "temporal" else 0, args.order_period)
     info = ctx.info()
-    renderer = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows,
-                                           stage_through_host=(args.dist_backend == "gloo"), payload=args.payload)
     pipelined = world > 1 and not args.no_pipeline
+    npipe = max(1, args.pipelines) if pipelined else 1
+    renderers = [tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows,
+                                             stage_through_host=(args.dist_backend == "gloo"), payload=args.payload)
+                 for _ in range(npipe)]
+    renderer = renderers[0]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -166,11 +173,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # a side stream: kernels, events and (for N > 1) the RCCL gather all order themselves on it
-    stream = torch.cuda.Stream()
+    # side streams: kernels, events and (for N > 1) the RCCL gathers order themselves on them; pipeline i owns stream i
+    pstreams = [torch.cuda.Stream() for _ in range(npipe)]
+    stream = pstreams[0]
     torch.cuda.set_stream(stream)
-    for _ in range(args.warmup):
-        renderer.render(frame)
+
+    def run_frames(n):
+        """n frames; with pipelines, frame k goes to pipeline k % npipe (same order on every rank: the collectives match)."""
+        img_ = None
+        for k in range(n):
+            if pipelined:
+                with torch.cuda.stream(pstreams[k % npipe]):
+                    renderers[k % npipe].submit(frame)   # render k, complete this pipeline's previous frame, start gather k
+            else:
+                img_ = renderer.render(frame)
+        if pipelined:
+            for i in range(npipe):                       # every frame is assembled on rank 0 before this returns
+                with torch.cuda.stream(pstreams[i]):
+                    out_ = renderers[i].flush()
+                    img_ = out_ if out_ is not None else img_
+        return img_
+
+    run_frames(args.warmup)
     sync_all()
 
     # ---- timed region: exactly K frames ------------------------------------------------------------
@@ -184,17 +208,13 @@ def main():
     ctx.timing_begin(args.steps)      # HIP event pair around every traversal kernel, on its launch stream, no syncs
     sync_all()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        if fif > 1:
+    if fif > 1:
+        for k in range(args.steps):
             s_ = streams[k % fif]
             ctx.render_device(frame, bufs[k % fif].data_ptr(), None, s_.cuda_stream)
             img = bufs[k % fif]
-        elif pipelined:
-            renderer.submit(frame)        # render k, then complete frame k-1 (its gather ran meanwhile), then start gather k
-        else:
-            img = renderer.render(frame)
-    if pipelined:
-        img = renderer.flush()            # frame K-1: all K frames are assembled on rank 0 before the clock stops
+    else:
+        img = run_frames(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -294,7 +314,8 @@ def main():
                             f"{W}x{H} primary rays, Camera(0.5,0.7,1.8), fov 45",
                 "parallelism": ("1 GPU" if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else f"screen split over {world} GPUs, {args.band_rows}-row bands "
                                                           f"round-robin, 1 RCCL gather per frame ({'4-byte Lambert term' if args.payload == 'shade' else 'RGBA32F'} per pixel"
-                                                          f"{', gather k overlaps render k+1' if pipelined else ''})",
+                                                          f"{', gather k overlaps render k+1' if pipelined else ''}"
+                                                          f"{f', {npipe} such pipelines on {npipe} HIP streams take the frames in turn' if npipe > 1 else ''})",
                 "kernel": args.kernel,
             },
             "hit_rays": stats["hits"], "capped_rays": stats["capped"],

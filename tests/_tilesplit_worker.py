@@ -107,6 +107,26 @@ def main():
                 ok &= got[k + 1] is not None and got[k + 1].tobytes() == want.tobytes()
             else:
                 ok &= got[k + 1] is None
+        # two pipelines taking the frames in turn (what bench.py does for N > 1): their collectives interleave in the
+        # same order on every rank and never touch each other's buffers
+        pair = [tilesplit.TileSplitRenderer(OracleBackend(nodes, g.min, g.voxel_size), rank, world, band_rows=band, payload=payload)
+                for _ in range(2)]
+        cams2 = [orc.Camera(0.3 + 0.5 * k, 0.6, 1.7 + 0.1 * k) for k in range(5)]
+        got2 = {}
+        for k, c in enumerate(cams2):
+            out = pair[k % 2].submit(hip.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H))
+            if k >= 2:
+                got2[k - 2] = None if out is None else out.numpy().copy()
+        for i in range(2):
+            k_last = max(k for k in range(len(cams2)) if k % 2 == i)
+            out = pair[i].flush()
+            got2[k_last] = None if out is None else out.numpy().copy()
+        for k, c in enumerate(cams2):
+            if rank == 0:
+                want, _ = orc.render(nodes, g.min, g.voxel_size, c.get_view(), c.get_pos(), W / H, 45.0, W, H)
+                ok &= got2[k] is not None and got2[k].tobytes() == want.tobytes()
+            else:
+                ok &= got2[k] is None
         try:                    # mixing the two forms with a frame in flight is refused
             r.submit(frame)
             r.render(frame)
