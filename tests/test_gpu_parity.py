@@ -472,6 +472,42 @@ def test_temporal_launch_order_is_only_a_schedule(ctx, orc, scenes, scene, cam0,
         ctx.set_launch_order(1, 4)
 
 
+def test_8k_frame_with_temporal_order(ctx, orc, scenes, camera):
+    """7680x4320 = 518,400 tiles: the launch-order sort runs with 507 blocks (its table still fits LDS); three frames
+    so that the third one is launched through a rebuilt table.  A 16K frame exceeds that and must fall back silently."""
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere64")
+    view, pos = camera("sphere")
+    upload(ctx, s)
+    try:
+        ctx.set_launch_order(1, 1)
+        W, H = 7680, 4320
+        f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+        want, st = oracle_frame(orc, s, view, pos, W, H)
+        buf = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+        for k in range(3):
+            buf.fill_(7.0)
+            ctx.render_device(f, buf.data_ptr())
+            ctx.synchronize()
+            assert_bit_exact(buf.cpu().numpy(), want, f"8K frame {k}")
+        assert len(ctx.debug_tile_cost()) == (W // 8) * (H // 8)
+        del buf
+        W, H = 15360, 8640                                   # 2,073,600 tiles: no table, centre-out order
+        f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+        big = torch.full((H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+        ctx.render_device(f, big.data_ptr())
+        ctx.render_device(f, big.data_ptr())
+        ctx.synchronize()
+        # compare a band through the sphere (the oracle renders rows on request)
+        out = np.zeros((H, W, 4), np.float32)
+        orc.render(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H, nthreads=min(16, orc.max_threads()), rows=(4000, 4640), out=out)
+        got = big[4000:4640].cpu().numpy()
+        assert_bit_exact(got, out[4000:4640], "16K frame, rows 4000..4639")
+        assert float(big.min()) == 0.0 and float(big[..., 3].min()) == 1.0     # every pixel was written
+    finally:
+        ctx.set_launch_order(1, 4)
+
+
 def test_frames_in_flight_on_several_streams_of_one_context(ctx, orc, scenes):
     """Three HIP streams render interleaved frames of one context without any host sync in between; every stream
     owns its launch-order tables (rebuilt after every frame here), so nothing is shared between frames in flight."""
