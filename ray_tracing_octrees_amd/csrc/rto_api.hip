@@ -372,15 +372,19 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     for (int l = 1; l <= R; l++) {
         V.nx[l] = (V.nx[l - 1] + 1) / 2; V.ny[l] = (V.ny[l - 1] + 1) / 2; V.nz[l] = (V.nz[l - 1] + 1) / 2;
         const size_t cells = (size_t)V.nx[l] * V.ny[l] * V.nz[l];
-        const unsigned nbl = (unsigned)((cells + kBlock - 1) / kBlock);
+        const bool wide = l == 1 && dimX % 16 == 0;         // level 1 reads the voxels 16 B at a time when rows stay aligned
+        const unsigned nbl = (unsigned)(((wide ? cells / 8 : cells) + kBlock - 1) / kBlock);
         uint8_t* d = nullptr;
         int* d_bm = nullptr;
         RTO_HIP(c, scratch.alloc(&d, cells));
         RTO_HIP(c, scratch.alloc(&d_bm, (size_t)nbl));
         V.level[l] = d;
         LC.blockMixed[l] = d_bm; LC.numBlocks[l] = (int)nbl;
-        hipLaunchKernelGGL(k_pyramid_level, dim3(nbl), dim3(kBlock), 0, s,
-                           V.level[l - 1], V.nx[l - 1], V.ny[l - 1], V.nz[l - 1], d, V.nx[l], V.ny[l], V.nz[l], 1 << l, dimX, dimY, dimZ, d_bm);
+        if (wide)
+            hipLaunchKernelGGL(k_pyramid_level1_wide, dim3(nbl), dim3(kBlock), 0, s, d_vox, dimX, dimY, dimZ, d, V.nx[l], V.ny[l], V.nz[l], d_bm);
+        else
+            hipLaunchKernelGGL(k_pyramid_level, dim3(nbl), dim3(kBlock), 0, s,
+                               V.level[l - 1], V.nx[l - 1], V.ny[l - 1], V.nz[l - 1], d, V.nx[l], V.ny[l], V.nz[l], 1 << l, dimX, dimY, dimZ, d_bm);
     }
     RTO_HIP(c, hipGetLastError());
     std::vector<long long> mixed((size_t)R + 1, 0);

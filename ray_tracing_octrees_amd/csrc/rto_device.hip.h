@@ -1348,6 +1348,51 @@ __global__ __launch_bounds__(kBlock) void k_pyramid_level(const uint8_t* __restr
     if (threadIdx.x == 0) blockMixed[blockIdx.x] = cnt;
 }
 
+// Level 1 straight from the voxels, 16 B per load: one thread = 8 consecutive cells along x = 16 voxels of each of the
+// four (y, z) rows under them.  Same result as k_pyramid_level; needs dimX % 16 == 0 (rows stay 16-byte aligned).
+__global__ __launch_bounds__(kBlock) void k_pyramid_level1_wide(const uint8_t* __restrict__ vox, int dimX, int dimY, int dimZ,
+                                                                 uint8_t* __restrict__ out, int nx, int ny, int nz,
+                                                                 int* __restrict__ blockMixed) {
+    __shared__ int waveTotal[kBlock / kWave];
+    const int groupsX = nx / 8;
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t total = (size_t)groupsX * ny * nz;
+    int mixedCount = 0;
+    if (t < total) {
+        const int gx = (int)(t % groupsX), j = (int)((t / groupsX) % ny), k = (int)(t / ((size_t)groupsX * ny));
+        const bool overhang = (j + 1) * 2 > dimY || (k + 1) * 2 > dimZ;     // out-of-grid voxels are EMPTY
+        uint4 row[4];
+        bool have[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int y = 2 * j + (r & 1), z = 2 * k + (r >> 1);
+            have[r] = y < dimY && z < dimZ;
+            row[r] = make_uint4(0, 0, 0, 0);
+            if (have[r]) row[r] = *reinterpret_cast<const uint4*>(vox + ((size_t)z * dimY + y) * dimX + (size_t)gx * 16);
+        }
+        unsigned long long packed = 0;
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            bool any0 = overhang, any1 = false, mixed = false;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (!have[r]) continue;
+                const unsigned w = (o >> 1) == 0 ? row[r].x : (o >> 1) == 1 ? row[r].y : (o >> 1) == 2 ? row[r].z : row[r].w;
+                const unsigned a = (w >> ((o & 1) * 16)) & 0xffu, b = (w >> ((o & 1) * 16 + 8)) & 0xffu;
+                mixed |= (a == 2) | (b == 2); any1 |= (a == 1) | (b == 1); any0 |= (a == 0) | (b == 0);
+            }
+            const bool isMixed = mixed || (any0 && any1);
+            mixedCount += isMixed ? 1 : 0;
+            packed |= (unsigned long long)(isMixed ? 2 : (any1 ? 1 : 0)) << (8 * o);
+        }
+        *reinterpret_cast<unsigned long long*>(out + ((size_t)k * ny + j) * nx + (size_t)gx * 8) = packed;
+    }
+    for (int off = 32; off > 0; off >>= 1) mixedCount += __shfl_down(mixedCount, off);
+    if ((threadIdx.x & 63) == 0) waveTotal[threadIdx.x >> 6] = mixedCount;
+    __syncthreads();
+    if (threadIdx.x == 0) { int s = 0; for (int w = 0; w < kBlock / kWave; w++) s += waveTotal[w]; blockMixed[blockIdx.x] = s; }
+}
+
 // one block per pyramid level: levelMixed[l] = sum of that level's per-block counts
 struct LevelCountView { const int* blockMixed[kMaxDepth + 1]; int numBlocks[kMaxDepth + 1]; };
 __global__ __launch_bounds__(1024) void k_sum_level_counts(LevelCountView V, long long* __restrict__ levelMixed) {

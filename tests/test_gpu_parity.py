@@ -782,7 +782,9 @@ def test_gpu_octree_build_equals_reference_arrays(ctx, orc, scenes, camera, gold
 def test_gpu_octree_build_degenerate_and_random_grids(ctx, orc):
     rng = np.random.default_rng(3)
     cases = [((1, 1, 1), 1.0), ((1, 1, 1), 0.0), ((4, 4, 4), 1.0), ((4, 4, 4), 0.0), ((3, 3, 3), 1.0), ((7, 5, 3), 0.5),
-             ((33, 9, 20), 0.9), ((64, 1, 1), 0.5), ((2, 3, 1), 0.0), ((17, 17, 17), 0.02)]
+             ((33, 9, 20), 0.9), ((64, 1, 1), 0.5), ((2, 3, 1), 0.0), ((17, 17, 17), 0.02),
+             # dimX % 16 == 0 takes the 16-byte level-1 pyramid kernel: odd / single rows and slices, all states
+             ((16, 5, 7), 0.5), ((32, 33, 2), 0.9), ((48, 1, 1), 0.5), ((16, 16, 16), 1.0), ((16, 2, 3), 0.0), ((80, 37, 11), 0.03)]
     for dims, p in cases:
         data = (rng.random((dims[2], dims[1], dims[0])) < p).astype(np.uint8)
         mn = np.array([0.5, -2.0, 3.0], np.float32)
