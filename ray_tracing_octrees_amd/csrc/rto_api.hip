@@ -458,7 +458,7 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     // ---- where the solid geometry is (launch-order heuristic)
     const int initBox[6] = { 0x7fffffff, 0x7fffffff, 0x7fffffff, -0x7fffffff, -0x7fffffff, -0x7fffffff };
     RTO_HIP(c, hipMemcpyAsync(d_bbox, initBox, sizeof initBox, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_solid_bbox, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, s, c->d_nodes, total, d_bbox);
+    hipLaunchKernelGGL(k_solid_bbox, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 512)), dim3(kBlock), 0, s, c->d_nodes, total, d_bbox);
     RTO_HIP(c, hipGetLastError());
     RTO_HIP(c, hipEventRecord(e2, s));
     int box[6];
@@ -1051,18 +1051,29 @@ int rto_build_leaf_triangles(rto_context* c, const uint8_t* voxels, int dimX, in
     LeafTriParams P{ c->d_nodes, n, d_vox, dimX, dimY, dimZ, c->gridMin[0], c->gridMin[1], c->gridMin[2], c->voxelSize, c->d_mcCases };
     int *d_count = nullptr, *d_big = nullptr, *d_bigCount = nullptr, *d_bs = nullptr, *d_bb = nullptr;
     int64_t* d_total = nullptr;
-    RTO_HIP(c, scratch.alloc(&d_count, (size_t)n)); RTO_HIP(c, scratch.alloc(&d_big, (size_t)n)); RTO_HIP(c, scratch.alloc(&d_bigCount, 1));
+    RTO_HIP(c, scratch.alloc(&d_count, (size_t)n)); RTO_HIP(c, scratch.alloc(&d_big, (size_t)n)); RTO_HIP(c, scratch.alloc(&d_bigCount, 3));
     RTO_HIP(c, scratch.alloc(&d_bs, (size_t)nb)); RTO_HIP(c, scratch.alloc(&d_bb, (size_t)nb)); RTO_HIP(c, scratch.alloc(&d_total, 1));
     RTO_HIP(c, hipMalloc(&c->d_triOffset, (size_t)(n + 1) * sizeof(int)));
-    RTO_HIP(c, hipMemsetAsync(d_bigCount, 0, sizeof(int), s));
+    RTO_HIP(c, hipMemsetAsync(d_bigCount, 0, 3 * sizeof(int), s));        // [0] big leaves, [1] their chunks, [2] chunk cursor
     // pass 1: counts
     hipLaunchKernelGGL(k_leaftri_small<false>, dim3(nb), dim3(kBlock), 0, s, P, d_count, (const int*)nullptr, d_big, d_bigCount, (float*)nullptr);
     RTO_HIP(c, hipGetLastError());
-    int bigCount = 0;
-    RTO_HIP(c, hipMemcpyAsync(&bigCount, d_bigCount, sizeof bigCount, hipMemcpyDeviceToHost, s));
+    int big[2] = { 0, 0 };
+    RTO_HIP(c, hipMemcpyAsync(big, d_bigCount, sizeof big, hipMemcpyDeviceToHost, s));
     RTO_HIP(c, hipStreamSynchronize(s));
-    const int nbBig = (bigCount + (kBlock / kWave) - 1) / (kBlock / kWave);
-    if (bigCount > 0) hipLaunchKernelGGL(k_leaftri_big<false>, dim3(nbBig), dim3(kBlock), 0, s, P, d_big, bigCount, d_count, (const int*)nullptr, (float*)nullptr);
+    const int bigCount = big[0], numChunks = big[1];
+    const int nbBig = (bigCount + kBlock - 1) / kBlock;
+    const int nbChunk = (numChunks + (kBlock / kWave) - 1) / (kBlock / kWave);
+    int *d_bigFirst = nullptr, *d_chunkCount = nullptr, *d_chunkOff = nullptr;
+    int2* d_chunks = nullptr;
+    if (bigCount > 0) {
+        RTO_HIP(c, scratch.alloc(&d_bigFirst, (size_t)bigCount)); RTO_HIP(c, scratch.alloc(&d_chunks, (size_t)numChunks));
+        RTO_HIP(c, scratch.alloc(&d_chunkCount, (size_t)numChunks)); RTO_HIP(c, scratch.alloc(&d_chunkOff, (size_t)numChunks));
+        hipLaunchKernelGGL(k_leaftri_plan, dim3(nbBig), dim3(kBlock), 0, s, P, d_big, bigCount, d_bigCount + 2, d_bigFirst, d_chunks);
+        hipLaunchKernelGGL(k_leaftri_big<false>, dim3(nbChunk), dim3(kBlock), 0, s, P, d_big, d_chunks, numChunks, d_chunkCount, (const int*)nullptr,
+                           (const int*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(k_leaftri_bigsum, dim3(nbBig), dim3(kBlock), 0, s, P, d_big, bigCount, d_bigFirst, d_chunkCount, d_chunkOff, d_count);
+    }
     // scan -> triOffset
     hipLaunchKernelGGL(k_block_sums, dim3(nb), dim3(kBlock), 0, s, d_count, n, d_bs);
     hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, s, d_bs, nb, d_bb, d_total);
@@ -1075,7 +1086,7 @@ int rto_build_leaf_triangles(rto_context* c, const uint8_t* voxels, int dimX, in
     RTO_HIP(c, hipMalloc(&c->d_tris, (size_t)(total ? total : 1) * 12 * sizeof(float)));
     // pass 2: triangles
     hipLaunchKernelGGL(k_leaftri_small<true>, dim3(nb), dim3(kBlock), 0, s, P, d_count, c->d_triOffset, d_big, d_bigCount, c->d_tris);
-    if (bigCount > 0) hipLaunchKernelGGL(k_leaftri_big<true>, dim3(nbBig), dim3(kBlock), 0, s, P, d_big, bigCount, d_count, c->d_triOffset, c->d_tris);
+    if (bigCount > 0) hipLaunchKernelGGL(k_leaftri_big<true>, dim3(nbChunk), dim3(kBlock), 0, s, P, d_big, d_chunks, numChunks, d_chunkCount, d_chunkOff, c->d_triOffset, c->d_tris);
     RTO_HIP(c, hipGetLastError());
     c->numTris = total;
     if (c->canonical && c->numInternal > 0) {

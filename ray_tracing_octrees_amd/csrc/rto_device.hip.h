@@ -1487,10 +1487,11 @@ __global__ __launch_bounds__(kBlock) void k_build_emit(const int4* __restrict__ 
     nodes[levelBase + i] = nd;
 }
 
-// bounding box of the solid leaves (voxel units) for the launch-order heuristic.  Grid-stride over the nodes, one
-// wave reduction at the end and at most 6 atomics per wave that saw a solid leaf (same-address atomics serialise:
-// one set per 64 nodes cost 1 ms at 1.5 M nodes).
+// bounding box of the solid leaves (voxel units) for the launch-order heuristic.  Grid-stride over the nodes with a
+// small grid, wave + block reduction, then at most 6 atomics per BLOCK: same-address atomics serialise at ~10 ns
+// each (one set per 64 nodes cost 1 ms at 1.5 M nodes, one set per wave of a 1024-block grid still 0.29 ms).
 __global__ __launch_bounds__(kBlock) void k_solid_bbox(const rto_node* __restrict__ nodes, int64_t n, int* __restrict__ bbox /* lo[3], hi[3] */) {
+    __shared__ int part[kBlock / kWave][6];
     int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const rto_node* nd = nodes + i;
@@ -1507,9 +1508,17 @@ __global__ __launch_bounds__(kBlock) void k_solid_bbox(const rto_node* __restric
             hi[a] = max(hi[a], __shfl_down(hi[a], off));
         }
     }
-    if ((threadIdx.x & 63) == 0 && lo[0] != 0x7fffffff) {
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; a++) { atomicMin(&bbox[a], lo[a]); atomicMax(&bbox[3 + a], hi[a]); }
+        for (int a = 0; a < 3; a++) { part[threadIdx.x >> 6][a] = lo[a]; part[threadIdx.x >> 6][3 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        int v = part[0][a];
+        for (int w = 1; w < kBlock / kWave; w++) v = a < 3 ? min(v, part[w][a]) : max(v, part[w][a]);
+        if (a < 3) { if (v != 0x7fffffff) atomicMin(&bbox[a], v); }
+        else if (v != -0x7fffffff) atomicMax(&bbox[a], v);
     }
 }
 
@@ -1608,18 +1617,26 @@ __device__ __forceinline__ void emit_cell_triangles(const LeafTriParams& P, int 
 
 __device__ __forceinline__ bool is_leaf_node(const rto_node& nd) { return nd.isLeaf == 1; }
 
-// pass 1 (EMIT = false): triCount[node]; leaves with more candidates than a thread should walk go to bigList.
+constexpr int kLeafChunk = 2048;     // candidates one wave walks for a big leaf (32 steps); big leaves are cut into such chunks
+
+// pass 1 (EMIT = false): triCount[node]; leaves with more candidates than a thread should walk go to bigList (and
+//                        their chunk count to *chunkTotal).
 // pass 2 (EMIT = true) : the same walk writing the triangles.
 template <bool EMIT>
 __global__ __launch_bounds__(kBlock) void k_leaftri_small(LeafTriParams P, int* __restrict__ triCount, const int* __restrict__ triOffset,
-                                                           int* __restrict__ bigList, int* __restrict__ bigCount, float* __restrict__ tris) {
+                                                           int* __restrict__ bigList, int* __restrict__ bigCount /* [0] leaves, [1] chunks */,
+                                                           float* __restrict__ tris) {
     const int64_t node = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (node >= P.n) return;
     const rto_node nd = P.nodes[node];
     if (!is_leaf_node(nd)) { if (!EMIT) triCount[node] = 0; return; }
     const LeafCells L = leaf_cells(P, nd);
     if (L.total > kLeafSerialCandidates) {
-        if (!EMIT) { triCount[node] = 0; bigList[atomicAdd(bigCount, 1)] = (int)node; }
+        if (!EMIT) {
+            triCount[node] = 0;
+            bigList[atomicAdd(&bigCount[0], 1)] = (int)node;
+            atomicAdd(&bigCount[1], (L.total + kLeafChunk - 1) / kLeafChunk);
+        }
         return;
     }
     int run = EMIT ? triOffset[node] : 0;
@@ -1633,21 +1650,37 @@ __global__ __launch_bounds__(kBlock) void k_leaftri_small(LeafTriParams P, int* 
     if (!EMIT) triCount[node] = run;
 }
 
+// one thread per big leaf: claim its chunk range and list (leaf slot, chunk number) per chunk
+__global__ __launch_bounds__(kBlock) void k_leaftri_plan(LeafTriParams P, const int* __restrict__ bigList, int bigCount, int* __restrict__ cursor,
+                                                          int* __restrict__ bigFirstChunk, int2* __restrict__ chunks) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= bigCount) return;
+    const LeafCells L = leaf_cells(P, P.nodes[bigList[b]]);
+    const int nch = (L.total + kLeafChunk - 1) / kLeafChunk;
+    const int first = atomicAdd(cursor, nch);
+    bigFirstChunk[b] = first;
+    for (int q = 0; q < nch; q++) chunks[first + q] = make_int2(b, q);
+}
+
+// one wave per chunk.  EMIT = false: chunkCount[chunk]; EMIT = true: triangles at triOffset[node] + chunkOff[chunk] + running
 template <bool EMIT>
-__global__ __launch_bounds__(kBlock) void k_leaftri_big(LeafTriParams P, const int* __restrict__ bigList, int bigCount, int* __restrict__ triCount,
+__global__ __launch_bounds__(kBlock) void k_leaftri_big(LeafTriParams P, const int* __restrict__ bigList, const int2* __restrict__ chunks, int numChunks,
+                                                         int* __restrict__ chunkCount, const int* __restrict__ chunkOff,
                                                          const int* __restrict__ triOffset, float* __restrict__ tris) {
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    if (slot >= bigCount) return;                              // wave-uniform
-    const int node = bigList[slot];
+    const int ch = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (ch >= numChunks) return;                               // wave-uniform
+    const int2 cq = chunks[ch];
+    const int node = bigList[cq.x];
     const rto_node nd = P.nodes[node];
     const LeafCells L = leaf_cells(P, nd);
-    int run = EMIT ? triOffset[node] : 0;
-    for (int c0 = 0; c0 < L.total; c0 += kWave) {
+    const int cBegin = cq.y * kLeafChunk, cEnd = min(L.total, cBegin + kLeafChunk);
+    int run = EMIT ? triOffset[node] + chunkOff[ch] : 0;
+    for (int c0 = cBegin; c0 < cEnd; c0 += kWave) {
         const int c = c0 + lane;
         unsigned long long cs = 0;
         int i = 0, j = 0, k = 0;
-        if (c < L.total) {
+        if (c < cEnd) {
             leaf_candidate(L, c, i, j, k);
             cs = P.cases[cell_case(P, L.x0 + i, L.y0 + j, L.z0 + k)];
         }
@@ -1660,7 +1693,22 @@ __global__ __launch_bounds__(kBlock) void k_leaftri_big(LeafTriParams P, const i
         if (EMIT && nt) emit_cell_triangles(P, L.x0 + i, L.y0 + j, L.z0 + k, cs, tris + (size_t)(run + incl - nt) * 12);
         run += __shfl(incl, kWave - 1);
     }
-    if (!EMIT && lane == 0) triCount[node] = run;
+    if (!EMIT && lane == 0) chunkCount[ch] = run;
+}
+
+// one thread per big leaf: exclusive prefix of its chunks' counts (chunk order = candidate order), total -> triCount
+__global__ __launch_bounds__(kBlock) void k_leaftri_bigsum(LeafTriParams P, const int* __restrict__ bigList, int bigCount,
+                                                            const int* __restrict__ bigFirstChunk, const int* __restrict__ chunkCount,
+                                                            int* __restrict__ chunkOff, int* __restrict__ triCount) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= bigCount) return;
+    const int node = bigList[b];
+    const LeafCells L = leaf_cells(P, P.nodes[node]);
+    const int nch = (L.total + kLeafChunk - 1) / kLeafChunk;
+    const int first = bigFirstChunk[b];
+    int run = 0;
+    for (int q = 0; q < nch; q++) { chunkOff[first + q] = run; run += chunkCount[first + q]; }
+    triCount[node] = run;
 }
 
 // block sums of an int array (for the exclusive scan that turns triCount into triOffset)

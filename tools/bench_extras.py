@@ -32,17 +32,24 @@ t = time.perf_counter()
 ctx.build_octree(g.data, g.min, g.voxelSize)
 nodes = ctx.download_nodes()
 info = ctx.info()
-t = time.perf_counter()
-tris, off = rto.buildLeafTriangles(g, nodes)
-t_tris = time.perf_counter() - t
-ctx.upload_leaf_triangles(tris, off)
+ctx.build_leaf_triangles(None)                      # GPU builder, voxels still resident from build_octree
+ctx.build_leaf_triangles(None)
+t_tris_gpu_ms = ctx.last_build_ms()[0]
+tris, off = ctx.download_leaf_triangles()
+t_tris = None
+if os.environ.get("RTO_EXTRAS_HOST_TRIS"):           # the C++ host builder (localMC per leaf), for comparison: ~4.5 s
+    t = time.perf_counter()
+    rto.buildLeafTriangles(g, nodes)
+    t_tris = time.perf_counter() - t
 cam = rto.Camera(0.5, 0.7, 1.8)
 W, H = 3840, 2160
 f = rto.make_frame(cam.getView(), cam.getPos(), W / H, 45.0, W, H)
 import torch
 
 buf = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
-c5 = {"nodes": int(info.num_nodes), "triangles": int(len(tris)), "leaf_triangle_build_host_s": round(t_tris, 3)}
+c5 = {"nodes": int(info.num_nodes), "triangles": int(len(tris)), "leaf_triangle_build_gpu_ms": round(t_tris_gpu_ms, 3)}
+if t_tris is not None:
+    c5["leaf_triangle_build_host_s"] = round(t_tris, 3)
 for kname, kernel in (("packed", rto.KERNEL_AUTO), ("generic", rto.KERNEL_GENERIC)):
     ctx.set_kernel(kernel)
     for shadow in (True, False):
