@@ -1224,22 +1224,25 @@ int rto_octree_ray_skip(rto_context* c, const float ro[3], const float* rd, int6
     if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_octree_ray_skip: no octree uploaded");
     if (n == 0) return RTO_OK;
     RTO_HIP(c, hipSetDevice(c->device));
+    BuildScratch scratch(c->stream);                 // stream-ordered pool: no hipMalloc / hipFree per call
     float *d_rd = nullptr, *d_out = nullptr;
-    RTO_HIP(c, hipMalloc(&d_rd, (size_t)n * 3 * sizeof(float)));
-    if (hipMalloc(&d_out, (size_t)n * sizeof(float)) != hipSuccess) { (void)hipFree(d_rd); return fail(c, RTO_E_HIP, "rto_octree_ray_skip: hipMalloc"); }
-    hipError_t e = hipMemcpyAsync(d_rd, rd, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        const uint8_t* vis = (use_visibility && c->culling) ? c->d_vis : nullptr;
-        const int blocks = (int)((n + kBlock - 1) / kBlock);
+    RTO_HIP(c, scratch.alloc(&d_rd, (size_t)n * 3));
+    RTO_HIP(c, scratch.alloc(&d_out, (size_t)n));
+    RTO_HIP(c, hipMemcpyAsync(d_rd, rd, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const uint8_t* vis = (use_visibility && c->culling) ? c->d_vis : nullptr;
+    const int blocks = (int)((n + kBlock - 1) / kBlock);
+    // canonical trees: the descriptor form (latency of a ray = one 8-byte load per visited internal node);
+    // anything else, or RTO_KERNEL_GENERIC: the 60-byte node form
+    if (c->canonical && c->numInternal > 0 && c->kernelMode != RTO_KERNEL_GENERIC)
+        hipLaunchKernelGGL(k_octree_ray_skip_packed, dim3(blocks), dim3(kBlock), 0, c->stream, c->d_desc, vis, vis ? 1 : 0, c->rootSize, c->depth,
+                           c->gridMin[0], c->gridMin[1], c->gridMin[2], c->voxelSize, ro[0], ro[1], ro[2], d_rd, n, t_min, t_max, d_out);
+    else
         hipLaunchKernelGGL(k_octree_ray_skip, dim3(blocks), dim3(kBlock), 0, c->stream, c->d_nodes, vis,
                            c->gridMin[0], c->gridMin[1], c->gridMin[2], c->voxelSize, ro[0], ro[1], ro[2],
                            d_rd, n, t_min, t_max, d_out);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(out_t, d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_rd); (void)hipFree(d_out);
-    if (e != hipSuccess) return fail(c, RTO_E_HIP, std::string("rto_octree_ray_skip: ") + hipGetErrorString(e));
+    RTO_HIP(c, hipGetLastError());
+    RTO_HIP(c, hipMemcpyAsync(out_t, d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
     return RTO_OK;
 }
 

@@ -707,13 +707,17 @@ def test_octree_ray_skip_matches_oracle(ctx, orc, scenes, camera):
         axis = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, -0.6, -0.8], [1e-12, -1, 0]], np.float32)
         rd = np.concatenate([rd, axis])
         want = np.array([orc.octree_ray_skip(s.nodes, s.min, s.voxel, ro, d) for d in rd], np.float32)
-        got = ctx.octree_ray_skip(ro, rd)
-        assert got.tobytes() == want.tobytes(), name
         assert (want < 1e30).sum() > 20
         # narrower [tMin, tMax] window
         want2 = np.array([orc.octree_ray_skip(s.nodes, s.min, s.voxel, ro, d, 0.5, float(np.median(want[want < 1e30]))) for d in rd], np.float32)
-        got2 = ctx.octree_ray_skip(ro, rd, 0.5, float(np.median(want[want < 1e30])))
-        assert got2.tobytes() == want2.tobytes(), name
+        # AUTO = the descriptor form (canonical trees), GENERIC = the 60-byte node form
+        for kname, kernel in (("descriptors", rto.KERNEL_AUTO), ("nodes", rto.KERNEL_GENERIC)):
+            ctx.set_kernel(kernel)
+            got = ctx.octree_ray_skip(ro, rd)
+            assert got.tobytes() == want.tobytes(), (name, kname)
+            got2 = ctx.octree_ray_skip(ro, rd, 0.5, float(np.median(want[want < 1e30])))
+            assert got2.tobytes() == want2.tobytes(), (name, kname)
+        ctx.set_kernel(rto.KERNEL_AUTO)
     # the probe pattern of drawRaycast (S/VR:1602-1647): 7x7 NDC samples within +-0.2, unprojected with inverse(P), inverse(V)
     s = scenes("calgary")
     upload(ctx, s)
@@ -739,6 +743,9 @@ def test_octree_ray_skip_matches_oracle(ctx, orc, scenes, camera):
     assert ctx.octree_ray_skip(pos, dirs, use_visibility=False).tobytes() == want.tobytes()
     got_v = ctx.octree_ray_skip(pos, dirs, use_visibility=True)
     assert (got_v >= want).all()
+    ctx.set_kernel(rto.KERNEL_GENERIC)                      # both forms apply the same visibility map
+    assert ctx.octree_ray_skip(pos, dirs, use_visibility=True).tobytes() == got_v.tobytes()
+    ctx.set_kernel(rto.KERNEL_AUTO)
     ctx.update_frustum(view, 45.0, 16 / 9, enable=False)
 
 
