@@ -565,13 +565,18 @@ int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, floa
     if (!c) return RTO_E_INVALID;
     if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_update_frustum: no octree uploaded");
     RTO_HIP(c, hipSetDevice(c->device));
+    // the visibility masks live in the descriptors every traversal kernel reads: frames still in flight on caller
+    // streams must be done before they change, and the change must be complete before this returns
+    RTO_HIP(c, hipDeviceSynchronize());
     const int64_t n = c->numNodes;
     const int nb = (int)((n + kBlock - 1) / kBlock);
     const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
     if (!enable) {
-        if (c->culling && c->canonical && nbInt > 0)
+        if (c->culling && c->canonical && nbInt > 0) {
             hipLaunchKernelGGL(k_desc_visall, dim3(nbInt), dim3(kBlock), 0, c->stream, c->numInternal, c->d_desc);
-        RTO_HIP(c, hipGetLastError());
+            RTO_HIP(c, hipGetLastError());
+            RTO_HIP(c, hipStreamSynchronize(c->stream));
+        }
         c->culling = false; c->rootVisible = 1; c->visibleNodes = n;
         return RTO_OK;
     }
@@ -973,7 +978,7 @@ int rto_upload_leaf_triangles(rto_context* c, const float* tris, int64_t num_tri
     for (int64_t i = 0; i < c->numNodes; i++)
         if (tri_offset[i + 1] < tri_offset[i]) return fail(c, RTO_E_INVALID, "rto_upload_leaf_triangles: tri_offset must be non-decreasing");
     RTO_HIP(c, hipSetDevice(c->device));
-    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    RTO_HIP(c, hipDeviceSynchronize());          // frames in flight on any stream still read the old buffers / descriptors
     (void)hipFree(c->d_tris); c->d_tris = nullptr;
     (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
     RTO_HIP(c, hipMalloc(&c->d_tris, (size_t)(num_tris ? num_tris : 1) * 12 * sizeof(float)));
@@ -1015,7 +1020,7 @@ int rto_build_leaf_triangles(rto_context* c, const uint8_t* voxels, int dimX, in
     if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_build_leaf_triangles: upload or build the octree first");
     RTO_HIP(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    RTO_HIP(c, hipStreamSynchronize(s));
+    RTO_HIP(c, hipDeviceSynchronize());          // frames in flight on any stream still read the old buffers / descriptors
     BuildScratch scratch(c->stream);
     hipEvent_t e0, e1, e2;
     RTO_HIP(c, hipEventCreate(&e0)); RTO_HIP(c, hipEventCreate(&e1)); RTO_HIP(c, hipEventCreate(&e2));
