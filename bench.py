@@ -133,10 +133,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+
+        # a rank that dies must not leave the others waiting for ten minutes in a collective
+        tmo = datetime.timedelta(seconds=180)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
 
     # ---- scene: the product's own host layer (C++), not the oracle --------------------------------
     W, H = args.width, args.height
@@ -337,4 +341,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:           # one JSON line or a loud failure, never a hang: take the whole job down
+        import traceback
+
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
