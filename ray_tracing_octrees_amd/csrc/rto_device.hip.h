@@ -43,10 +43,10 @@ constexpr int kMaxTraversalSteps = 512;   // S/RT:192
 constexpr int kWave = 64;
 constexpr int kBlock = 256;               // 4 waves, each owns one 8x8 pixel tile
 #ifndef RTO_PACKED3_WAVES
-#ifndef RTO_PERSIST_CHUNK
-#define RTO_PERSIST_CHUNK 8
-#endif
 #define RTO_PACKED3_WAVES 6       // waves per SIMD for the default traversal kernel (8 forces spills and measured 6 % slower)
+#endif
+#ifndef RTO_PERSIST_CHUNK
+#define RTO_PERSIST_CHUNK 8       // launch slots a persistent wave takes per atomic (A/B builds: -DRTO_PERSIST_CHUNK=n)
 #endif
 constexpr int kMaxDepth = 20;             // log2(root size) supported by the packed kernel
 // temporal launch order: tiles are bucketed by their trip count; 1024 tiles per sort block
