@@ -41,7 +41,10 @@ namespace rto {
 
 constexpr int kMaxTraversalSteps = 512;   // S/RT:192
 constexpr int kWave = 64;
-constexpr int kBlock = 256;               // 4 waves, each owns one 8x8 pixel tile
+#ifndef RTO_BLOCK
+#define RTO_BLOCK 256             // A/B builds (-DRTO_BLOCK=n), traversal kernel at config 2: 64 -> 67.4 us, 128 -> 69.0, 256 -> 66.3, 512 -> 71.3
+#endif
+constexpr int kBlock = RTO_BLOCK;         // 4 waves, each owns one 8x8 pixel tile
 #ifndef RTO_PACKED3_WAVES
 #define RTO_PACKED3_WAVES 6       // waves per SIMD for the default traversal kernel (8 forces spills and measured 6 % slower)
 #endif
