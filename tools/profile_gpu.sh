@@ -7,7 +7,7 @@
 # (tools/summarize_profile.py).  Copy what should be judged into profiles/.
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${*:---steps 100 --warmup 10 --cpu-frames 0}
+ARGS=${*:---cpu-frames 0}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
