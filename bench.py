@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--verify", action="store_true", help="rank 0 compares the assembled frame with the CPU oracle (outside the timed region)")
     ap.add_argument("--order", choices=["temporal", "centre-out"], default="temporal",
                     help="tile launch order of the packed kernel (scheduling only; pixels are identical)")
-    ap.add_argument("--order-period", type=int, default=4, help="temporal order: rebuild the table every n-th frame")
+    ap.add_argument("--order-period", type=int, default=8, help="temporal order: rebuild the table every n-th frame")
     ap.add_argument("--payload", choices=["shade", "rgba"], default="shade",
                     help="N>1: what a part ships to rank 0 -- 4-byte Lambert term per pixel (default) or the 16-byte pixel")
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: finish the gather of a frame before rendering the next")

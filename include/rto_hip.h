@@ -114,7 +114,7 @@ int  rto_set_kernel(rto_context* ctx, int kernel /* RTO_KERNEL_* */);
  * The frame ends when its deepest rays end, so the waves that will run longest should start first.
  * CENTRE_OUT: outwards from the projection of the solid geometry's centre.  TEMPORAL (default): by the per-tile
  * trip counts an earlier frame of the same size recorded (CENTRE_OUT until one exists); the table is rebuilt
- * every refresh_period-th frame (default 4; 0 keeps the current period) by one small kernel after that frame. */
+ * every refresh_period-th frame (default 8; 0 keeps the current period) by one small kernel after that frame. */
 #define RTO_ORDER_CENTRE_OUT 0
 #define RTO_ORDER_TEMPORAL   1
 int  rto_set_launch_order(rto_context* ctx, int policy, int refresh_period);

@@ -53,7 +53,8 @@ struct rto_context {
     int numCUs = 256;
     int residentW = 0, residentH = 0;   // size of the frame rto_render_resident left in d_frame
     int orderPolicy = 1;            // 0 = centre-out only, 1 = temporal (falls back to centre-out without history)
-    int orderPeriod = 4;            // rebuild the table every orderPeriod-th frame (cost maps change slowly)
+    int orderPeriod = 8;            // rebuild the table every orderPeriod-th frame: cost maps change slowly (tools/order_period.py:
+                                    // 8 or 16 beat 4 for a static, an orbiting and a fast-moving camera alike)
     struct OrderState {
         int* d_tileCost = nullptr;
         int* d_tileOrder = nullptr;

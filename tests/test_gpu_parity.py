@@ -469,7 +469,7 @@ def test_temporal_launch_order_is_only_a_schedule(ctx, orc, scenes, scene, cam0,
         assert_bit_exact(ctx.render_host(f), want, f"{scene} centre-out")
     finally:
         ctx.debug_set_tile_order(None)
-        ctx.set_launch_order(1, 4)
+        ctx.set_launch_order(1, 8)
 
 
 def test_8k_frame_with_temporal_order(ctx, orc, scenes, camera):
@@ -505,7 +505,7 @@ def test_8k_frame_with_temporal_order(ctx, orc, scenes, camera):
         assert_bit_exact(got, out[4000:4640], "16K frame, rows 4000..4639")
         assert float(big.min()) == 0.0 and float(big[..., 3].min()) == 1.0     # every pixel was written
     finally:
-        ctx.set_launch_order(1, 4)
+        ctx.set_launch_order(1, 8)
 
 
 def test_frames_in_flight_on_several_streams_of_one_context(ctx, orc, scenes):
@@ -533,7 +533,7 @@ def test_frames_in_flight_on_several_streams_of_one_context(ctx, orc, scenes):
             for i in range(3):
                 assert_bit_exact(bufs[i].cpu().numpy(), wants[i], f"stream {i}, period {period}")
     finally:
-        ctx.set_launch_order(1, 4)
+        ctx.set_launch_order(1, 8)
 
 
 def test_resident_frame_stays_on_the_gpu(ctx, orc, scenes, camera):
