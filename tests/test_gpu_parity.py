@@ -210,6 +210,44 @@ def test_config4_resampled_to_512x512x128(ctx, orc, scenes, camera):
     assert ctx.download_nodes().tobytes() == s.nodes.tobytes()
 
 
+def test_depth10_grid_1024(ctx, orc):
+    """A 1024^3 grid (1 GiB of voxels, root edge 1024, depth 10 -- one level beyond every BASELINE config): the GPU
+    builder reproduces the oracle's array and every kernel its pixels, steps and counters."""
+    N = 1024
+    d = np.zeros((N, N, N), np.uint8)
+    for (cx, cy, cz, r) in ((300, 400, 500, 120), (700, 650, 300, 90), (512, 512, 800, 60)):
+        z, y, x = np.ogrid[cz - r:cz + r + 1, cy - r:cy + r + 1, cx - r:cx + r + 1]
+        d[cz - r:cz + r + 1, cy - r:cy + r + 1, cx - r:cx + r + 1] |= ((x - cx) ** 2 + (y - cy) ** 2 + (z - cz) ** 2 <= r * r).astype(np.uint8)
+    mn = np.array([-0.5, -0.5, -0.5], np.float32)
+    vs = np.float32(1.0 / N)
+    s = Scene(orc.Grid((N, N, N), mn, vs, d), None)
+    s.nodes = orc.build_flat_octree(s.grid)
+    assert s.nodes[0]["size"] == N
+    ctx.build_octree(d, mn, vs)
+    assert ctx.info().num_nodes == len(s.nodes)
+    assert ctx.download_nodes().tobytes() == s.nodes.tobytes()
+    cam = orc.Camera(0.4, 0.8, 1.6)
+    view, pos = cam.get_view(), cam.get_pos()
+    W, H = 1280, 720
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, st = oracle_frame(orc, s, view, pos, W, H)
+    steps = orc.render_steps(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H)
+    assert st["hits"] > 10_000
+    for kname, kernel in KERNELS:
+        ctx.set_kernel(kernel)
+        assert_bit_exact(ctx.render_host(f), want, f"1024^3 {kname}")
+        np.testing.assert_array_equal(ctx.render_steps(f), steps, err_msg=kname)
+        gs = ctx.frame_stats(f)
+        assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"]), kname
+    ctx.set_kernel(rto.KERNEL_AUTO)
+    ctx.build_leaf_triangles(None)
+    wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
+    gt, go = ctx.download_leaf_triangles()
+    assert go.tobytes() == np.asarray(wo, np.int32).tobytes() and gt.tobytes() == np.ascontiguousarray(wt, np.float32).tobytes()
+    wtri, _ = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, view, pos, W / H, 45.0, W, H, shadow=True, nthreads=min(16, orc.max_threads()))
+    assert_bit_exact(ctx.render_triangles_host(f, shadow=True), wtri, "1024^3 triangles + shadow")
+
+
 def test_config5_primary_rays_512_4k(ctx, orc, scenes, camera):
     """BASELINE config 5, primary rays only (the triangle/shadow extension has no reference): 512^3, 3840x2160."""
     s = scenes("sphere512")
