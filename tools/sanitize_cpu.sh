@@ -1,0 +1,18 @@
+#!/bin/bash
+# tools/sanitize_cpu.sh -- AddressSanitizer + UBSan over the CPU-side code (the C++ host layer and the C oracle): the
+# GPU pool offers no device sanitizers, so this is where memory errors in the host path would show.  Works on a scratch
+# copy of the repo; prints pytest's summary and the number of UBSan reports (expected: 0).
+set -eu
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+W=$(mktemp -d)
+cp -r "$ROOT" "$W/repo"
+cd "$W/repo"
+SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -fPIC -shared"
+g++ $SAN -std=c++17 -I include ray_tracing_octrees_amd/host/*.cpp -o ray_tracing_octrees_amd/librto_host.so -ldl
+gcc $SAN -fopenmp oracle/rto_oracle.c -o oracle/liborc.so -lm
+touch ray_tracing_octrees_amd/librto_host.so oracle/liborc.so ray_tracing_octrees_amd/librto_hip.so
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 \
+  python -m pytest tests/test_oracle_golden.py tests/test_abi_and_host.py -q -p no:cacheprovider > "$W/log" 2>&1 || true
+tail -3 "$W/log"
+echo "UBSan reports: $(grep -c 'runtime error' "$W/log" || true)"
+rm -rf "$W"
