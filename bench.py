@@ -59,6 +59,10 @@ def parse_args():
                     help="N>1: independent submit/flush pipelines, each on its own HIP stream, that take the frames in turn "
                          "(a part's kernel is bounded by its deepest rays, not by its pixel count, so one pipeline leaves "
                          "most of each GPU idle); 1 = a single pipeline")
+    ap.add_argument("--graph-frames", type=int, default=50,
+                    help="N=1: capture this many consecutive frames (one kernel each, strictly one after the other) in a HIP "
+                         "graph and replay it: the ~9 us the runtime needs between dependent plain launches shrink to ~1 us; "
+                         "0 = plain stream launches with a HIP event pair around every kernel")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="N=1 only: render consecutive frames on this many HIP streams (own framebuffers) so that the "
                          "deep-ray tail of one frame overlaps the start of the next; 1 = strictly one frame at a time")
@@ -213,10 +217,35 @@ def main():
         for i in range(fif):
             ctx.render_device(frame, bufs[i].data_ptr(), None, streams[i].cuda_stream)
         sync_all()
-    ctx.timing_begin(args.steps)      # HIP event pair around every traversal kernel, on its launch stream, no syncs
+    use_graph = world == 1 and fif == 1 and args.graph_frames > 0
+    graph = None
+    gframes = 0
+    if use_graph:
+        # after the warm-up frames rto_render_device allocates nothing and never synchronises: it can be stream-captured
+        gframes = min(args.graph_frames, args.steps)
+        buf0 = renderer.render(frame)
+        ctx.timing_begin(0)
+        sync_all()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            for _ in range(gframes):
+                ctx.render_device(frame, buf0.data_ptr(), None, stream.cuda_stream)
+        graph.replay()                                  # untimed: first replay of a fresh graph
+        sync_all()
+        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    else:
+        ctx.timing_begin(args.steps)  # HIP event pair around every traversal kernel, on its launch stream, no syncs
     sync_all()
     t0 = time.perf_counter()
-    if fif > 1:
+    if use_graph:
+        ev_a.record(stream)
+        for _ in range(args.steps // gframes):
+            graph.replay()
+        for _ in range(args.steps % gframes):           # exactly K frames: the remainder as plain launches
+            ctx.render_device(frame, buf0.data_ptr(), None, stream.cuda_stream)
+        ev_b.record(stream)
+        img = buf0
+    elif fif > 1:
         for k in range(args.steps):
             s_ = streams[k % fif]
             ctx.render_device(frame, bufs[k % fif].data_ptr(), None, s_.cuda_stream)
@@ -237,9 +266,15 @@ def main():
         bytes_per_ray = pops_per_ray * NODE_BYTES + PIXEL_BYTES
         roofline = None
         if world == 1:
-            kms = sorted(float(x) for x in ctx.timing_read())
-            assert len(kms) == args.steps
-            k_avg = sum(kms) / len(kms)
+            if use_graph:
+                # one HIP event pair around the whole timed region, on the launch stream: GPU time per frame = the
+                # traversal kernel + the ~1 us between graph nodes (an upper bound of the kernel's own duration)
+                k_avg = ev_a.elapsed_time(ev_b) / args.steps
+                kms = [k_avg]
+            else:
+                kms = sorted(float(x) for x in ctx.timing_read())
+                assert len(kms) == args.steps
+                k_avg = sum(kms) / len(kms)
             # cost of an event pair with nothing between (reported, not subtracted): rocprofv3's kernel
             # duration is ~ k_avg minus this
             cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
@@ -272,8 +307,13 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": {"auto": "k_trace_packed3", "packed": "k_trace_packed3", "persistent": "k_trace_packed3_persistent"}.get(args.kernel, "k_trace_generic") if (info.canonical and args.kernel != "generic") else "k_trace_generic",
-                "launch_order": f"temporal (tiles sorted by an earlier frame's trip counts; k_sort_scatter after every {args.order_period}-th frame)" if args.order == "temporal" else "centre-out",
+                "launch_order": ("centre-out" if args.order != "temporal" else
+                                 "temporal (tiles sorted by an earlier frame's trip counts; table built during the warm-up, frozen while the frames are replayed from the graph)" if use_graph else
+                                 f"temporal (tiles sorted by an earlier frame's trip counts; k_sort_scatter after every {args.order_period}-th frame)"),
                 "kernel_ms_avg": round(k_avg, 5), "kernel_ms_median": round(kms[len(kms) // 2], 5),
+                "kernel_ms_how": (f"one HIP event pair around the {args.steps} timed frames / {args.steps} (graph replay: events inside a captured graph "
+                                  f"cannot be timed): an upper bound of the kernel's duration, it includes the ~1 us between graph nodes") if use_graph
+                                 else "HIP event pair around every traversal kernel launch of the timed region",
                 "event_pair_overhead_ms": round(pair_overhead, 5),
                 "algorithmic_bytes_per_ray": round(bytes_per_ray, 2), "pops_per_ray": round(pops_per_ray, 4),
                 "algorithmic_bytes_per_launch": int(round(rays * bytes_per_ray)),
@@ -320,7 +360,7 @@ def main():
             "config": {
                 "workload": f"{args.dim}^3 test-sphere voxel grid, octree to min-leaf 1 ({info.num_nodes} nodes), "
                             f"{W}x{H} primary rays, Camera(0.5,0.7,1.8), fov 45",
-                "parallelism": ("1 GPU" if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else f"screen split over {world} GPUs, {args.band_rows}-row bands "
+                "parallelism": (("1 GPU" + (f", frames replayed from a HIP graph of {gframes} consecutive frames" if use_graph else "")) if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else f"screen split over {world} GPUs, {args.band_rows}-row bands "
                                                           f"round-robin, 1 RCCL gather per frame ({'4-byte Lambert term' if args.payload == 'shade' else 'RGBA32F'} per pixel"
                                                           f"{', gather k overlaps render k+1' if pipelined else ''}"
                                                           f"{f', {npipe} such pipelines on {npipe} HIP streams take the frames in turn' if npipe > 1 else ''})",

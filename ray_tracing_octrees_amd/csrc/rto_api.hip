@@ -786,8 +786,13 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 }
                 if (std::memcmp(key, o->key, sizeof key) != 0) { o->valid = false; o->fixed = false; std::memcpy(o->key, key, sizeof key); }
                 Q.tileOrder = o->valid ? o->d_tileOrder : nullptr;
+                // A stream that is being captured into a HIP graph gets a frozen schedule: a rebuild mutates device state
+                // (cost table, histograms, the table itself) that a replayed graph would not find as it was at capture.
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing(s, &cap);
+                const bool capturing = cap == hipStreamCaptureStatusActive;
                 // costs are recorded only by the frame whose epilogue is followed by a rebuild
-                recordCost = (MODE == kModeColor || MODE == kModeShade) && !o->fixed && (!o->valid || o->age + 1 >= c->orderPeriod);
+                recordCost = (MODE == kModeColor || MODE == kModeShade) && !o->fixed && !capturing && (!o->valid || o->age + 1 >= c->orderPeriod);
                 Q.tileCost = recordCost ? o->d_tileCost : nullptr;
                 Q.tileHist = o->d_sortHist + (size_t)o->histPing * ((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets;
             }

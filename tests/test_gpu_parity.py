@@ -607,6 +607,46 @@ def test_resident_frame_stays_on_the_gpu(ctx, orc, scenes, camera):
         ctx.render_resident(f, 7)
 
 
+def test_frames_captured_in_a_hip_graph_replay_exactly(ctx, orc, scenes):
+    """rto_render_device is stream-capturable after a warm-up frame (no allocation, no synchronisation): 24 frames of 6
+    cameras captured once (more frames than a launch-order period, an odd number of would-be rebuilds) and replayed
+    three times give the oracle's pixels every time.  While capturing, the launch-order table is frozen, so a replay
+    finds the device state it was captured with."""
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere64")
+    upload(ctx, s)
+    W, H = 640, 360
+    cams = [orc.Camera(0.5 + 0.25 * i, 0.7 + 0.05 * i, 1.8) for i in range(6)]
+    frames = [rto.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H) for c in cams]
+    wants = [oracle_frame(orc, s, c.get_view(), c.get_pos(), W, H)[0] for c in cams]
+    bufs = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
+    stream = torch.cuda.Stream()
+    try:
+        ctx.set_launch_order(1, 3)
+        for _ in range(7):                                   # warm-up on the capture stream: tables, a valid order
+            ctx.render_device(frames[0], bufs[0].data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            with torch.cuda.graph(g, stream=stream):
+                for k in range(24):
+                    ctx.render_device(frames[k % 6], bufs[k % 6].data_ptr(), None, stream.cuda_stream)
+            for rep in range(3):
+                for b in bufs:
+                    b.fill_(7.0)
+                g.replay()
+                torch.cuda.synchronize()
+                for i in range(6):
+                    assert_bit_exact(bufs[i].cpu().numpy(), wants[i], f"graph replay {rep}, camera {i}")
+        # plain launches afterwards still work and rebuild their table
+        for _ in range(5):
+            ctx.render_device(frames[1], bufs[1].data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert_bit_exact(bufs[1].cpu().numpy(), wants[1], "plain launches after the graph")
+    finally:
+        ctx.set_launch_order(1, 8)
+
+
 def test_render_device_on_a_caller_stream(ctx, scenes, camera):
     torch = pytest.importorskip("torch")
     s = scenes("sphere32")
