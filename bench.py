@@ -226,14 +226,25 @@ def main():
         buf0 = renderer.render(frame)
         ctx.timing_begin(0)
         sync_all()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream):
-            for _ in range(gframes):
-                ctx.render_device(frame, buf0.data_ptr(), None, stream.cuda_stream)
-        graph.replay()                                  # untimed: first replay of a fresh graph
-        sync_all()
-        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    else:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for _ in range(gframes):
+                    ctx.render_device(frame, buf0.data_ptr(), None, stream.cuda_stream)
+            graph.replay()                              # untimed: first replay of a fresh graph
+            sync_all()
+            ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        except Exception as e:                          # a runtime that cannot capture: plain launches, said so in the line
+            print(f"bench: HIP graph capture failed ({type(e).__name__}: {e}); falling back to plain launches", file=sys.stderr, flush=True)
+            use_graph, graph, gframes = False, None, 0
+            torch.cuda.synchronize()
+            stream = torch.cuda.Stream()
+            torch.cuda.set_stream(stream)
+            pstreams[0] = stream
+            for _ in range(3):
+                renderer.render(frame)
+            sync_all()
+    if not use_graph:
         ctx.timing_begin(args.steps)  # HIP event pair around every traversal kernel, on its launch stream, no syncs
     sync_all()
     t0 = time.perf_counter()
