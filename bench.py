@@ -5,12 +5,16 @@ Metric   : Mrays/s of primary rays (and ms/frame) at 1920x1080.
 Workload : BASELINE config 2 -- 256^3 shell-sphere voxel grid (main.cpp:337-372 rules), octree to
            min-leaf 1 (374,921 nodes), Camera(theta 0.5, phi 0.7, r 1.8), fov 45, aspect W/H.
 Step     : one frame = one pass of the hot path over 2,073,600 rays, octree and framebuffer resident in HBM.
-N = 1    : one kernel launch per frame into a device framebuffer.
+N = 1    : one kernel launch per frame into a device framebuffer, one frame strictly after the other; the timed frames
+           are replayed from a HIP graph of 50 consecutive frames (--graph-frames; 0 = plain stream launches with a
+           HIP event pair around every kernel): the runtime needs ~9 us between dependent plain launches, ~1 us
+           between graph nodes.
 N > 1    : launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; every rank
            holds the octree, renders its round-robin bands and ONE torch.distributed.gather (RCCL over
            xGMI) per frame lands the image on rank 0, which re-interleaves it (strong scaling).  The payload
            is 4 bytes per pixel (the Lambert term; rank 0 finishes the colour, bit-identical) and the gather
-           of frame k overlaps the render of frame k+1; all K frames are complete inside the timed region.
+           of frame k overlaps the render of frame k+1; two such pipelines on two HIP streams take the frames in turn;
+           all K frames are complete inside the timed region.
 
 Prints ONE JSON line on rank 0.  `cpu_baseline` is this repo's own C restatement of the reference's GLSL
 kernel (the reference has no CPU path and publishes no numbers), timed here on the box's host cores.
