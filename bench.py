@@ -13,7 +13,7 @@ N > 1    : launched by `python -m torch.distributed.run --nproc-per-node N ... b
            holds the octree, renders its round-robin bands and ONE torch.distributed.gather (RCCL over
            xGMI) per frame lands the image on rank 0, which re-interleaves it (strong scaling).  The payload
            is 4 bytes per pixel (the Lambert term; rank 0 finishes the colour, bit-identical) and the gather
-           of frame k overlaps the render of frame k+1; two such pipelines on two HIP streams take the frames in turn;
+           of frame k overlaps the render of frame k+1; three such pipelines on three HIP streams take the frames in turn;
            all K frames are complete inside the timed region.
 
 Prints ONE JSON line on rank 0.  `cpu_baseline` is this repo's own C restatement of the reference's GLSL
@@ -59,7 +59,7 @@ def parse_args():
     ap.add_argument("--payload", choices=["shade", "rgba"], default="shade",
                     help="N>1: what a part ships to rank 0 -- 4-byte Lambert term per pixel (default) or the 16-byte pixel")
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: finish the gather of a frame before rendering the next")
-    ap.add_argument("--pipelines", type=int, default=2,
+    ap.add_argument("--pipelines", type=int, default=3,
                     help="N>1: independent submit/flush pipelines, each on its own HIP stream, that take the frames in turn "
                          "(a part's kernel is bounded by its deepest rays, not by its pixel count, so one pipeline leaves "
                          "most of each GPU idle); 1 = a single pipeline")
