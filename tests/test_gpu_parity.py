@@ -74,7 +74,8 @@ def _random_grid(orc, rng):
     return orc.Grid(dims, gmin, voxel, data)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RTO_FUZZ_SEEDS", "12"))))     # a larger sweep: RTO_FUZZ_SEEDS=400
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTO_FUZZ_START", "0")),          # a larger sweep: RTO_FUZZ_SEEDS=400 [RTO_FUZZ_START=2500]
+                                        int(os.environ.get("RTO_FUZZ_START", "0")) + int(os.environ.get("RTO_FUZZ_SEEDS", "12"))))
 def test_fuzz_random_scenes_and_cameras(ctx, orc, seed):
     """Seeded fuzz: random grids, cameras outside / inside / grazing, random image sizes, fov and aspect; every
     kernel must reproduce the oracle's pixel bits, per-pixel step counts and frame counters; the triangle path too."""
