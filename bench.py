@@ -13,7 +13,8 @@ N > 1    : launched by `python -m torch.distributed.run --nproc-per-node N ... b
            holds the octree, renders its round-robin bands and ONE torch.distributed.gather (RCCL over
            xGMI) per frame lands the image on rank 0, which re-interleaves it (strong scaling).  The payload
            is 4 bytes per pixel (the Lambert term; rank 0 finishes the colour, bit-identical) and the gather
-           of frame k overlaps the render of frame k+1; three such pipelines on three HIP streams take the frames in turn;
+           of batch k overlaps the renders of batch k+1 (8 consecutive frames travel in one gather: fewer, larger
+           collectives); three such pipelines on three HIP streams take the batches in turn;
            all K frames are complete inside the timed region.
 
 Prints ONE JSON line on rank 0.  `cpu_baseline` is this repo's own C restatement of the reference's GLSL
@@ -65,6 +66,9 @@ def parse_args():
                     help="N>1: independent submit/flush pipelines, each on its own HIP stream, that take the frames in turn "
                          "(a part's kernel is bounded by its deepest rays, not by its pixel count, so one pipeline leaves "
                          "most of each GPU idle); 1 = a single pipeline")
+    ap.add_argument("--frames-per-gather", type=int, default=8,
+                    help="N>1: consecutive frames whose parts travel in ONE gather (fewer, larger collectives: a "
+                         "torch.distributed call costs the host tens of microseconds, as much as a whole frame); 1 = one gather per frame")
     ap.add_argument("--graph-frames", type=int, default=50,
                     help="N=1: capture this many consecutive frames (one kernel each, strictly one after the other) in a HIP "
                          "graph and replay it: the ~9 us the runtime needs between dependent plain launches shrink to ~1 us; "
@@ -196,20 +200,28 @@ def main():
     stream = pstreams[0]
     torch.cuda.set_stream(stream)
 
+    fpg = max(1, args.frames_per_gather) if pipelined else 1
+
     def run_frames(n):
-        """n frames; with pipelines, frame k goes to pipeline k % npipe (same order on every rank: the collectives match)."""
+        """n frames.  With pipelines, batch j (fpg consecutive frames, one gather) goes to pipeline j % npipe -- the same
+        order on every rank, so the collectives match; every frame is assembled on rank 0 before this returns."""
         img_ = None
-        for k in range(n):
-            if pipelined:
-                with torch.cuda.stream(pstreams[k % npipe]):
-                    renderers[k % npipe].submit(frame)   # render k, complete this pipeline's previous frame, start gather k
-            else:
+        if not pipelined:
+            for _ in range(n):
                 img_ = renderer.render(frame)
-        if pipelined:
-            for i in range(npipe):                       # every frame is assembled on rank 0 before this returns
-                with torch.cuda.stream(pstreams[i]):
-                    out_ = renderers[i].flush()
-                    img_ = out_ if out_ is not None else img_
+            return img_
+        full, rest = divmod(n, fpg)
+        for j in range(full):
+            with torch.cuda.stream(pstreams[j % npipe]):
+                renderers[j % npipe].submit_batch([frame] * fpg)   # render, complete this pipeline's previous batch, start the gather
+        for i in range(npipe):
+            with torch.cuda.stream(pstreams[i]):
+                out_ = renderers[i].flush_batch()
+                img_ = out_[-1] if out_ is not None else img_
+        if rest:                                                   # exactly n frames: the remainder as one smaller batch
+            with torch.cuda.stream(pstreams[0]):
+                out_ = renderers[0].render_batch([frame] * rest)
+                img_ = out_[-1] if out_ is not None else img_
         return img_
 
     run_frames(args.warmup)
@@ -378,9 +390,10 @@ def main():
                 "workload": f"{args.dim}^3 test-sphere voxel grid, octree to min-leaf 1 ({info.num_nodes} nodes), "
                             f"{W}x{H} primary rays, Camera(0.5,0.7,1.8), fov 45",
                 "parallelism": (("1 GPU" + (f", frames replayed from a HIP graph of {gframes} consecutive frames" if use_graph else "")) if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else f"screen split over {world} GPUs, {args.band_rows}-row bands "
-                                                          f"round-robin, 1 RCCL gather per frame ({'4-byte Lambert term' if args.payload == 'shade' else 'RGBA32F'} per pixel"
+                                                          f"round-robin, 1 RCCL gather per {'frame' if fpg == 1 else f'{fpg} frames'} ({'4-byte Lambert term' if args.payload == 'shade' else 'RGBA32F'} per pixel"
                                                           f"{', gather k overlaps render k+1' if pipelined else ''}"
-                                                          f"{f', {npipe} such pipelines on {npipe} HIP streams take the frames in turn' if npipe > 1 else ''})",
+                                                          f"{f', {fpg} consecutive frames per gather' if fpg > 1 else ''}"
+                                                          f"{f', {npipe} such pipelines on {npipe} HIP streams take the batches in turn' if npipe > 1 else ''})",
                 "kernel": args.kernel,
             },
             "hit_rays": stats["hits"], "capped_rays": stats["capped"],

@@ -174,6 +174,10 @@ int  rto_render_shade_device(rto_context* ctx, const rto_frame* frame, const rto
                              void* d_shade, void* hip_stream);
 int  rto_assemble_shade_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part,
                                const void* d_gathered_shade, void* d_frame, void* hip_stream);
+/* Fewer, larger collectives: when every rank ships `batch` consecutive frames of its part in ONE gather
+ * ([rank][batch][part-0 rows][width], either payload), this rebuilds frame `index` of the batch. */
+int  rto_assemble_batch_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part, const void* d_gathered,
+                               int batch, int index, int shade_payload, void* d_frame, void* hip_stream);
 
 /* ---- N2: leaf triangles + shadow ray (BASELINE config 5) -------------------------
  * No upstream counterpart: the reference has no ray/triangle code (its MC triangles are rasterised).  The

@@ -740,6 +740,13 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     return RTO_OK;
 }
 
+// Is `s` being captured into a HIP graph?  Then the launch must stay free of anything a replay could not repeat:
+// no timing events (events recorded inside a capture cannot be timed), no launch-order rebuild (see launch_trace).
+static bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
+}
+
 template <int MODE>
 static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hipStream_t s) {
     const int tiles = P.tilesX * P.tilesY;
@@ -750,7 +757,8 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     bool stopRecorded = false;
     hipEvent_t evA = c->ev0, evB = c->ev1;
     if (c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
-    RTO_HIP(c, hipEventRecord(evA, s));
+    const bool capturing = stream_is_capturing(s);
+    if (!capturing) RTO_HIP(c, hipEventRecord(evA, s));
     if (packed) {
         const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint2);
         if (c->kernelMode == RTO_KERNEL_PACKED_V1)
@@ -788,9 +796,6 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 Q.tileOrder = o->valid ? o->d_tileOrder : nullptr;
                 // A stream that is being captured into a HIP graph gets a frozen schedule: a rebuild mutates device state
                 // (cost table, histograms, the table itself) that a replayed graph would not find as it was at capture.
-                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-                (void)hipStreamIsCapturing(s, &cap);
-                const bool capturing = cap == hipStreamCaptureStatusActive;
                 // costs are recorded only by the frame whose epilogue is followed by a rebuild
                 recordCost = (MODE == kModeColor || MODE == kModeShade) && !o->fixed && !capturing && (!o->valid || o->age + 1 >= c->orderPeriod);
                 Q.tileCost = recordCost ? o->d_tileCost : nullptr;
@@ -813,7 +818,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             } else {
                 hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             }
-            RTO_HIP(c, hipEventRecord(evB, s));       // the traversal kernel alone; the order kernel follows
+            if (!capturing) RTO_HIP(c, hipEventRecord(evB, s));       // the traversal kernel alone; the order kernel follows
             stopRecorded = true;
             if (o && (MODE == kModeColor || MODE == kModeShade) && !recordCost) o->age++;
             if (o && recordCost) {
@@ -834,9 +839,9 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
         hipLaunchKernelGGL(k_trace_generic<MODE>, dim3(blocks), dim3(kBlock), 0, s, Q, nodes, d_out, c->d_steps, c->d_counters);
     }
     RTO_HIP(c, hipGetLastError());
-    if (!stopRecorded) RTO_HIP(c, hipEventRecord(evB, s));
+    if (!stopRecorded && !capturing) RTO_HIP(c, hipEventRecord(evB, s));
     if (evA != c->ev0) { c->lastA = evA; c->lastB = evB; } else { c->lastA = c->ev0; c->lastB = c->ev1; }
-    c->timed = true;
+    c->timed = !capturing;
     return RTO_OK;
 }
 
@@ -894,31 +899,37 @@ int rto_render_host(rto_context* c, const rto_frame* f, float* host_rgba) {
     return RTO_OK;
 }
 
-int rto_assemble_device(rto_context* c, const rto_frame* f, const rto_partition* p, const void* d_gathered,
-                        void* d_frame, void* hip_stream) {
-    if (!c || !f || !p || !d_gathered || !d_frame) return c ? fail(c, RTO_E_INVALID, "rto_assemble_device: NULL argument") : RTO_E_INVALID;
-    if (p->num_parts < 1 || p->band_rows <= 0) return fail(c, RTO_E_INVALID, "rto_assemble_device: bad partition");
+static int assemble_common(rto_context* c, const rto_frame* f, const rto_partition* p, const void* d_gathered, int batch, int index,
+                           void* d_frame, void* hip_stream, bool shade, const char* who) {
+    if (!c || !f || !p || !d_gathered || !d_frame) return c ? fail(c, RTO_E_INVALID, std::string(who) + ": NULL argument") : RTO_E_INVALID;
+    if (p->num_parts < 1 || p->band_rows <= 0) return fail(c, RTO_E_INVALID, std::string(who) + ": bad partition");
+    if (batch < 1 || index < 0 || index >= batch) return fail(c, RTO_E_INVALID, std::string(who) + ": index must lie in [0, batch)");
     RTO_HIP(c, hipSetDevice(c->device));
     rto_partition p0 = *p; p0.part = 0;
-    const int partRows = rto_partition_rows(f, &p0);
-    hipStream_t s = (hipStream_t)hip_stream;
-    hipLaunchKernelGGL(k_assemble, dim3(2048), dim3(256), 0, s, (const float4*)d_gathered, (float4*)d_frame,
-                       f->width, f->height, p->num_parts, p->num_parts > 1 ? p->band_rows : f->height, partRows);
+    const size_t partPixels = (size_t)rto_partition_rows(f, &p0) * (size_t)f->width;
+    const size_t stride = partPixels * (size_t)batch, base = partPixels * (size_t)index;
+    const int bandRows = p->num_parts > 1 ? p->band_rows : f->height;
+    if (shade)
+        hipLaunchKernelGGL(k_assemble_shade, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, (const float*)d_gathered + base, (float4*)d_frame,
+                           f->width, f->height, p->num_parts, bandRows, stride);
+    else
+        hipLaunchKernelGGL(k_assemble, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, (const float4*)d_gathered + base, (float4*)d_frame,
+                           f->width, f->height, p->num_parts, bandRows, stride);
     RTO_HIP(c, hipGetLastError());
     return RTO_OK;
 }
 
-int rto_assemble_shade_device(rto_context* c, const rto_frame* f, const rto_partition* p, const void* d_gathered,
-                              void* d_frame, void* hip_stream) {
-    if (!c || !f || !p || !d_gathered || !d_frame) return c ? fail(c, RTO_E_INVALID, "rto_assemble_shade_device: NULL argument") : RTO_E_INVALID;
-    if (p->num_parts < 1 || p->band_rows <= 0) return fail(c, RTO_E_INVALID, "rto_assemble_shade_device: bad partition");
-    RTO_HIP(c, hipSetDevice(c->device));
-    rto_partition p0 = *p; p0.part = 0;
-    const int partRows = rto_partition_rows(f, &p0);
-    hipLaunchKernelGGL(k_assemble_shade, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, (const float*)d_gathered, (float4*)d_frame,
-                       f->width, f->height, p->num_parts, p->num_parts > 1 ? p->band_rows : f->height, partRows);
-    RTO_HIP(c, hipGetLastError());
-    return RTO_OK;
+int rto_assemble_device(rto_context* c, const rto_frame* f, const rto_partition* p, const void* d_gathered, void* d_frame, void* hip_stream) {
+    return assemble_common(c, f, p, d_gathered, 1, 0, d_frame, hip_stream, false, "rto_assemble_device");
+}
+
+int rto_assemble_shade_device(rto_context* c, const rto_frame* f, const rto_partition* p, const void* d_gathered, void* d_frame, void* hip_stream) {
+    return assemble_common(c, f, p, d_gathered, 1, 0, d_frame, hip_stream, true, "rto_assemble_shade_device");
+}
+
+int rto_assemble_batch_device(rto_context* c, const rto_frame* f, const rto_partition* p, const void* d_gathered, int batch, int index,
+                              int shade_payload, void* d_frame, void* hip_stream) {
+    return assemble_common(c, f, p, d_gathered, batch, index, d_frame, hip_stream, shade_payload != 0, "rto_assemble_batch_device");
 }
 
 static int run_steps(rto_context* c, const rto_frame* f, rto_stats* st, int32_t* host_steps) {
@@ -1138,7 +1149,8 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
     if (tiles <= 0) return RTO_OK;
     const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
     const bool packed = c->canonical && c->numInternal > 0 && c->kernelMode != RTO_KERNEL_GENERIC;
-    RTO_HIP(c, hipEventRecord(c->ev0, s));
+    const bool capturing = stream_is_capturing(s);
+    if (!capturing) RTO_HIP(c, hipEventRecord(c->ev0, s));
     if (packed) {
         PackedTriScene S{ c->d_desc, c->d_descFirstChild, c->d_tris, c->d_triOffset };
         const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint4);
@@ -1152,8 +1164,8 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
         else hipLaunchKernelGGL((k_trace_triangles<kModeColor, false>), dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
     }
     RTO_HIP(c, hipGetLastError());
-    RTO_HIP(c, hipEventRecord(c->ev1, s));
-    c->timed = true;
+    if (!capturing) RTO_HIP(c, hipEventRecord(c->ev1, s));
+    c->timed = !capturing;
     return RTO_OK;
 }
 

@@ -1846,28 +1846,30 @@ __global__ __launch_bounds__(kBlock) void k_block_exclusive_scan(const int* __re
 }
 
 // ================================================================ multi-GPU reassembly
-// d_gathered: numParts compact buffers, each padded to partRows rows of W pixels.
+// d_gathered: numParts compact buffers, each padded to partRows rows of W pixels; part p starts partStride pixels after
+// part p-1 (partRows * W when one frame was gathered; batch * partRows * W when the ranks shipped `batch` frames in
+// one collective, the caller then passes the pointer to its frame inside part 0).
 __global__ void k_assemble(const float4* __restrict__ gathered, float4* __restrict__ frame,
-                           int W, int H, int numParts, int bandRows, int partRows) {
+                           int W, int H, int numParts, int bandRows, size_t partStride) {
     const size_t n = (size_t)W * H;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         int y = (int)(i / W), x = (int)(i - (size_t)y * W);
         int gband = y / bandRows, r = y - gband * bandRows;
         int part = gband % numParts, band = gband / numParts;
-        size_t src = ((size_t)part * partRows + (size_t)band * bandRows + r) * W + x;
+        size_t src = (size_t)part * partStride + ((size_t)band * bandRows + r) * W + x;
         frame[i] = gathered[src];
     }
 }
 
 // Same re-interleave for the 4-byte shade payload, finishing the colour expression (shade_color) on the way.
 __global__ void k_assemble_shade(const float* __restrict__ gathered, float4* __restrict__ frame,
-                                 int W, int H, int numParts, int bandRows, int partRows) {
+                                 int W, int H, int numParts, int bandRows, size_t partStride) {
     const size_t n = (size_t)W * H;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         int y = (int)(i / W), x = (int)(i - (size_t)y * W);
         int gband = y / bandRows, r = y - gband * bandRows;
         int part = gband % numParts, band = gband / numParts;
-        size_t src = ((size_t)part * partRows + (size_t)band * bandRows + r) * W + x;
+        size_t src = (size_t)part * partStride + ((size_t)band * bandRows + r) * W + x;
         frame[i] = shade_color(gathered[src]);
     }
 }

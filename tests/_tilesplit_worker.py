@@ -66,10 +66,10 @@ class OracleBackend:
         mine = full[rows]
         out[: len(rows)] = torch.from_numpy(encode_shade(mine) if payload == "shade" else mine)
 
-    def assemble(self, frame, part0, gathered, out, payload="rgba"):
+    def assemble(self, frame, part0, gathered, out, payload="rgba", batch=1, index=0):
         for p in range(part0.num_parts):
             rows = tilesplit.partition_row_map(frame.height, part0.num_parts, p, part0.band_rows)
-            g = gathered[p][: len(rows)]
+            g = gathered[p][index][: len(rows)]
             out[torch.from_numpy(rows)] = torch.from_numpy(decode_shade(g.numpy())) if payload == "shade" else g
 
 
@@ -127,6 +127,29 @@ def main():
                 ok &= got2[k] is not None and got2[k].tobytes() == want.tobytes()
             else:
                 ok &= got2[k] is None
+        # several frames per collective: batches of 3 cameras, pipelined (submit_batch hands back the previous batch)
+        rb = tilesplit.TileSplitRenderer(OracleBackend(nodes, g.min, g.voxel_size), rank, world, band_rows=band, payload=payload)
+        cams3 = [orc.Camera(0.2 + 0.3 * k, 0.65 + 0.02 * k, 1.75) for k in range(9)]
+        frames3 = [hip.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H) for c in cams3]
+        outs = []
+        for bi in range(3):
+            o = rb.submit_batch(frames3[3 * bi: 3 * bi + 3])
+            outs.append(None if o is None else [t.numpy().copy() for t in o])
+        o = rb.flush_batch()
+        outs.append(None if o is None else [t.numpy().copy() for t in o])
+        ok &= outs[0] is None and rb.flush_batch() is None
+        for bi in range(3):
+            for f in range(3):
+                c = cams3[3 * bi + f]
+                if rank == 0:
+                    want, _ = orc.render(nodes, g.min, g.voxel_size, c.get_view(), c.get_pos(), W / H, 45.0, W, H)
+                    ok &= outs[bi + 1] is not None and outs[bi + 1][f].tobytes() == want.tobytes()
+                else:
+                    ok &= outs[bi + 1] is None
+        one = rb.render_batch(frames3[:3])                       # unpipelined batch
+        if rank == 0:
+            want, _ = orc.render(nodes, g.min, g.voxel_size, cams3[2].get_view(), cams3[2].get_pos(), W / H, 45.0, W, H)
+            ok &= one is not None and len(one) == 3 and one[2].numpy().tobytes() == want.tobytes()
         try:                    # mixing the two forms with a frame in flight is refused
             r.submit(frame)
             r.render(frame)

@@ -648,6 +648,40 @@ def test_frames_captured_in_a_hip_graph_replay_exactly(ctx, orc, scenes):
         ctx.set_launch_order(1, 8)
 
 
+def test_batched_gather_layout_assembles_every_frame(ctx, orc, scenes):
+    """Several frames per collective: every part renders `batch` frames into [batch][rows][width], the gather delivers
+    [rank][batch][rows][width], rto_assemble_batch_device rebuilds frame `index` -- both payloads, 3 parts, 4 cameras;
+    and through TileSplitRenderer.render_batch at world size 1."""
+    torch = pytest.importorskip("torch")
+    from ray_tracing_octrees_amd import tilesplit
+
+    s = scenes("sphere64")
+    upload(ctx, s)
+    W, H, nparts, band, batch = 417, 250, 3, 16, 4
+    cams = [orc.Camera(0.5 + 0.3 * i, 0.7 - 0.1 * i, 1.8) for i in range(batch)]
+    frames = [rto.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H) for c in cams]
+    wants = [oracle_frame(orc, s, c.get_view(), c.get_pos(), W, H)[0] for c in cams]
+    rows0 = ctx.partition_rows(frames[0], hip.Partition(nparts, 0, band))
+    for shade in (True, False):
+        shape = (nparts, batch, rows0, W) if shade else (nparts, batch, rows0, W, 4)
+        gathered = torch.full(shape, 7.0, dtype=torch.float32, device="cuda")
+        for p in range(nparts):
+            for f in range(batch):
+                (ctx.render_shade_device if shade else ctx.render_device)(frames[f], gathered[p, f].data_ptr(), hip.Partition(nparts, p, band))
+        out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+        for f in range(batch):
+            ctx.assemble_batch_device(frames[f], hip.Partition(nparts, 0, band), gathered.data_ptr(), batch, f, shade, out.data_ptr())
+            ctx.synchronize()
+            assert_bit_exact(out.cpu().numpy(), wants[f], f"batched gather, frame {f}, shade={shade}")
+    with pytest.raises(rto.RtoError):
+        ctx.assemble_batch_device(frames[0], hip.Partition(nparts, 0, band), gathered.data_ptr(), batch, batch, False, out.data_ptr())
+    r = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), 0, 1)
+    imgs = r.render_batch(frames)
+    torch.cuda.synchronize()
+    for f in range(batch):
+        assert_bit_exact(imgs[f].cpu().numpy(), wants[f], f"render_batch, world 1, frame {f}")
+
+
 def test_render_device_on_a_caller_stream(ctx, scenes, camera):
     torch = pytest.importorskip("torch")
     s = scenes("sphere32")
