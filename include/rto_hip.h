@@ -178,6 +178,13 @@ int  rto_assemble_shade_device(rto_context* ctx, const rto_frame* frame, const r
  * ([rank][batch][part-0 rows][width], either payload), this rebuilds frame `index` of the batch. */
 int  rto_assemble_batch_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part, const void* d_gathered,
                                int batch, int index, int shade_payload, void* d_frame, void* hip_stream);
+/* The whole batch with one call each (a caller in an interpreted language pays per call): this part of frames[0..n-1]
+ * (same width/height) into d_out + i*frame_stride_bytes, either payload; and all `batch` frames of a gather into
+ * d_frames + i*frame_stride_bytes. */
+int  rto_render_batch_device(rto_context* ctx, const rto_frame* frames, int n, const rto_partition* part, int shade_payload,
+                             void* d_out, size_t frame_stride_bytes, void* hip_stream);
+int  rto_assemble_batch_all_device(rto_context* ctx, const rto_frame* frames, int batch, const rto_partition* part,
+                                   const void* d_gathered, int shade_payload, void* d_frames, size_t frame_stride_bytes, void* hip_stream);
 
 /* ---- N2: leaf triangles + shadow ray (BASELINE config 5) -------------------------
  * No upstream counterpart: the reference has no ray/triangle code (its MC triangles are rasterised).  The

@@ -932,6 +932,36 @@ int rto_assemble_batch_device(rto_context* c, const rto_frame* f, const rto_part
     return assemble_common(c, f, p, d_gathered, batch, index, d_frame, hip_stream, shade_payload != 0, "rto_assemble_batch_device");
 }
 
+int rto_render_batch_device(rto_context* c, const rto_frame* frames, int n, const rto_partition* p, int shade_payload, void* d_out,
+                            size_t frame_stride_bytes, void* hip_stream) {
+    if (!c) return RTO_E_INVALID;
+    if (!frames || n < 1 || !d_out) return fail(c, RTO_E_INVALID, "rto_render_batch_device: NULL argument / empty batch");
+    RTO_HIP(c, hipSetDevice(c->device));
+    for (int i = 0; i < n; i++) {
+        if (frames[i].width != frames[0].width || frames[i].height != frames[0].height)
+            return fail(c, RTO_E_INVALID, "rto_render_batch_device: the frames of a batch share width and height");
+        RenderParams P;
+        int rc = fill_params(c, &frames[i], p, P);
+        if (rc != RTO_OK) return rc;
+        float4* out = reinterpret_cast<float4*>(static_cast<char*>(d_out) + (size_t)i * frame_stride_bytes);
+        rc = shade_payload ? launch_trace<kModeShade>(c, P, out, (hipStream_t)hip_stream) : launch_trace<kModeColor>(c, P, out, (hipStream_t)hip_stream);
+        if (rc != RTO_OK) return rc;
+    }
+    return RTO_OK;
+}
+
+int rto_assemble_batch_all_device(rto_context* c, const rto_frame* frames, int batch, const rto_partition* p, const void* d_gathered,
+                                  int shade_payload, void* d_frames, size_t frame_stride_bytes, void* hip_stream) {
+    if (!c) return RTO_E_INVALID;
+    if (!frames || batch < 1 || !d_frames) return fail(c, RTO_E_INVALID, "rto_assemble_batch_all_device: NULL argument / empty batch");
+    for (int i = 0; i < batch; i++) {
+        const int rc = assemble_common(c, &frames[i], p, d_gathered, batch, i, static_cast<char*>(d_frames) + (size_t)i * frame_stride_bytes,
+                                       hip_stream, shade_payload != 0, "rto_assemble_batch_all_device");
+        if (rc != RTO_OK) return rc;
+    }
+    return RTO_OK;
+}
+
 static int run_steps(rto_context* c, const rto_frame* f, rto_stats* st, int32_t* host_steps) {
     RTO_HIP(c, hipSetDevice(c->device));
     RenderParams P;

@@ -28,7 +28,7 @@ SYMBOLS = (
     "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel", "rto_set_launch_order",
     "rto_update_frustum", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
-    "rto_render_shade_device", "rto_assemble_shade_device", "rto_assemble_batch_device", "rto_render_resident", "rto_resident_frame", "rto_download_resident",
+    "rto_render_shade_device", "rto_assemble_shade_device", "rto_assemble_batch_device", "rto_render_batch_device", "rto_assemble_batch_all_device", "rto_render_resident", "rto_resident_frame", "rto_download_resident",
     "rto_upload_leaf_triangles", "rto_build_leaf_triangles", "rto_download_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
 )
@@ -108,6 +108,8 @@ def load():
     L.rto_render_shade_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp]
     L.rto_assemble_shade_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp, vp]
     L.rto_assemble_batch_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.rto_render_batch_device.argtypes = [vp, C.POINTER(Frame), C.c_int, C.POINTER(Partition), C.c_int, vp, C.c_size_t, vp]
+    L.rto_assemble_batch_all_device.argtypes = [vp, C.POINTER(Frame), C.c_int, C.POINTER(Partition), vp, C.c_int, vp, C.c_size_t, vp]
     L.rto_render_triangles_shade_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), C.c_int, vp, vp]
     L.rto_frame_stats.argtypes = [vp, C.POINTER(Frame), C.POINTER(Stats)]
     L.rto_upload_leaf_triangles.argtypes = [vp, vp, C.c_int64, vp]
@@ -275,6 +277,21 @@ class Context:
         """Frame `index` of a gather that carried `batch` frames per rank ([rank][batch][rows][width])."""
         self._check(self._L.rto_assemble_batch_device(self._h, C.byref(frame), C.byref(part), C.c_void_p(d_gathered), batch, index,
                                                       1 if shade else 0, C.c_void_p(d_frame), C.c_void_p(stream) if stream else None))
+
+    @staticmethod
+    def frame_array(frames):
+        """ctypes array of rto_frame for the batch entry points (build once per batch)."""
+        return (Frame * len(frames))(*frames)
+
+    def render_batch_device(self, frames_arr, d_out: int, frame_stride_bytes: int, part: Partition | None, shade: bool, stream: int = 0):
+        self._check(self._L.rto_render_batch_device(self._h, frames_arr, len(frames_arr), C.byref(part) if part else None, 1 if shade else 0,
+                                                    C.c_void_p(d_out), frame_stride_bytes, C.c_void_p(stream) if stream else None))
+
+    def assemble_batch_all_device(self, frames_arr, part: Partition, d_gathered: int, shade: bool, d_frames: int, frame_stride_bytes: int,
+                                  stream: int = 0):
+        self._check(self._L.rto_assemble_batch_all_device(self._h, frames_arr, len(frames_arr), C.byref(part), C.c_void_p(d_gathered),
+                                                          1 if shade else 0, C.c_void_p(d_frames), frame_stride_bytes,
+                                                          C.c_void_p(stream) if stream else None))
 
     def partition_rows(self, frame: Frame, part: Partition | None) -> int:
         return self._L.rto_partition_rows(C.byref(frame), C.byref(part) if part else None)

@@ -86,6 +86,20 @@ class HipBackend:
         else:
             self.ctx.render_device(frame, out.data_ptr(), part, self._stream())
 
+    def render_parts(self, frames, part: hip.Partition, local, payload: str):
+        """All frames of a batch with one call through the C ABI (octree path): local is [batch][rows][width(,4)]."""
+        if self.triangles:
+            for f, frame in enumerate(frames):
+                self.render_part(frame, part, local[f], payload)
+            return
+        arr = hip.Context.frame_array(frames)
+        self.ctx.render_batch_device(arr, local.data_ptr(), local.stride(0) * 4, part, payload == "shade", self._stream())
+
+    def assemble_all(self, frames, part0: hip.Partition, gathered, out_frames, payload: str):
+        arr = hip.Context.frame_array(frames)
+        self.ctx.assemble_batch_all_device(arr, part0, gathered.data_ptr(), payload == "shade", out_frames.data_ptr(),
+                                           out_frames.stride(0) * 4, self._stream())
+
     def assemble(self, frame: hip.Frame, part0: hip.Partition, gathered, out, payload: str = "rgba", batch: int = 1, index: int = 0):
         """Frame `index` of a gather that carried `batch` frames per rank: gathered is [rank][batch][rows][width(,4)]."""
         self.ctx.assemble_batch_device(frame, part0, gathered.data_ptr(), batch, index, payload == "shade", out.data_ptr(), self._stream())
@@ -187,8 +201,11 @@ class TileSplitRenderer:
             for i, p in enumerate(fl.keep[1]):
                 b.gathered[i].copy_(p)
         n = len(fl.frames)
-        for f, frame in enumerate(fl.frames):
-            self.backend.assemble(frame, self._part0, b.gathered, b.frames[f], self.payload, batch=b.key[2], index=f)
+        if hasattr(self.backend, "assemble_all"):
+            self.backend.assemble_all(fl.frames, self._part0, b.gathered, b.frames, self.payload)
+        else:
+            for f, frame in enumerate(fl.frames):
+                self.backend.assemble(frame, self._part0, b.gathered, b.frames[f], self.payload, batch=b.key[2], index=f)
         return [b.frames[f] for f in range(n)]
 
     # ---- public: batches ----------------------------------------------------------------------------
@@ -209,8 +226,11 @@ class TileSplitRenderer:
             return [b.frames[f] for f in range(len(frames))]
         local = b.local[self._seq % 2]
         self._seq += 1
-        for f, frame in enumerate(frames):                      # overlaps the gather in flight
-            self.backend.render_part(frame, self._part, local[f], self.payload)
+        if hasattr(self.backend, "render_parts"):               # overlaps the gather in flight
+            self.backend.render_parts(frames, self._part, local, self.payload)
+        else:
+            for f, frame in enumerate(frames):
+                self.backend.render_part(frame, self._part, local[f], self.payload)
         done = None
         if self._inflight is not None:
             done = self._complete(b, self._inflight)            # ... and only now waits for it
