@@ -182,6 +182,8 @@ def main():
                                              stage_through_host=(args.dist_backend == "gloo"), payload=args.payload)
                  for _ in range(npipe)]
     renderer = renderers[0]
+    rest_renderer = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows,
+                                                stage_through_host=(args.dist_backend == "gloo"), payload=args.payload)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -219,8 +221,8 @@ def main():
                 out_ = renderers[i].flush_batch()
                 img_ = out_[-1] if out_ is not None else img_
         if rest:                                                   # exactly n frames: the remainder as one smaller batch
-            with torch.cuda.stream(pstreams[0]):
-                out_ = renderers[0].render_batch([frame] * rest)
+            with torch.cuda.stream(pstreams[0]):                   # (own renderer: the pipelines keep their full-size buffers)
+                out_ = rest_renderer.render_batch([frame] * rest)
                 img_ = out_[-1] if out_ is not None else img_
         return img_
 
