@@ -682,6 +682,18 @@ def test_batched_gather_layout_assembles_every_frame(ctx, orc, scenes):
         assert_bit_exact(imgs[f].cpu().numpy(), wants[f], f"render_batch, world 1, frame {f}")
 
 
+def test_tile_split_over_rccl_with_one_rank():
+    """The device-to-device multi-rank path (nccl backend = RCCL, async gathers, batches, three pipelines) with a one-rank
+    group on this GPU, in its own process."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29598")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_one_rank_worker.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "nccl one-rank worker: ok" in p.stdout
+
+
 def test_render_device_on_a_caller_stream(ctx, scenes, camera):
     torch = pytest.importorskip("torch")
     s = scenes("sphere32")
