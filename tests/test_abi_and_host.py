@@ -236,3 +236,23 @@ def test_host_leaf_triangle_buffer_matches_oracle(orc, scenes):
         assert off.tobytes() == wo.tobytes() and tris.tobytes() == wt.tobytes(), name
         assert len(tris) > 0 and off[-1] == len(tris)
         assert (np.diff(off)[s.nodes["isLeaf"] == 0] == 0).all()      # only leaves own triangles
+
+
+def test_plain_cpp_example_fails_loudly_without_a_gpu():
+    """examples/render_sphere (plain C++ on the host layer): in a container without a GPU the HIP library refuses to
+    create a context, the class says so, and the program exits non-zero -- there is no CPU fallback to fall into."""
+    import subprocess
+
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is visible: the loud failure cannot be observed here")
+    except ImportError:
+        pass
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "render_sphere")
+    assert os.path.exists(exe), "built by __graft_entry__.build()"
+    env = dict(os.environ, RTO_HIP_LIB=os.path.join(root, "ray_tracing_octrees_amd", "librto_hip.so"))
+    p = subprocess.run([exe, "16", "32", "32"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert "no MI355X path" in p.stderr and "lit pixels" not in p.stdout
