@@ -1,30 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- the headline benchmark of BASELINE.json on this repo's HIP path.
 
-Metric   : Mrays/s of primary rays (and ms/frame) at 1920x1080.
-Workload : BASELINE config 2 -- 256^3 shell-sphere voxel grid (main.cpp:337-372 rules), octree to
-           min-leaf 1 (374,921 nodes), Camera(theta 0.5, phi 0.7, r 1.8), fov 45, aspect W/H.
-Step     : one frame = one pass of the hot path over 2,073,600 rays, octree and framebuffer resident in HBM.
+Metric   : Mrays/s of primary rays (and ms/frame).
+Workload : --config 2 (default) BASELINE config 2 -- 256^3 shell-sphere voxel grid (main.cpp:337-372 rules), octree to
+                      min-leaf 1 (374,921 nodes), Camera(theta 0.5, phi 0.7, r 1.8), fov 45, 1920x1080.
+           --config 4           the shipped sceneCache.bin grid (425x243x29, root 512; tests/golden/ref_scene_cache.npz),
+                      oblique Camera(0.6, 0.5, 3500): the irregular / divergent case, 1920x1080.
+           --config 4synthetic  that grid resampled nearest-neighbour to the 512x512x128 BASELINE.json names (SYNTHETIC: the
+                      real one cannot be regenerated), Camera(0.6, 0.5, 4500) on the grid centre, 1920x1080.
+           --config 5           512^3 sphere, 3840x2160, Marching-Cubes leaf triangles + 1 shadow ray per hit.
+Step     : one frame = one pass of the hot path over W x H primary rays, octree and framebuffer resident in HBM.
 N = 1    : one kernel launch per frame into a device framebuffer, one frame strictly after the other; the timed frames
-           are replayed from a HIP graph of 50 consecutive frames (--graph-frames; 0 = plain stream launches with a
-           HIP event pair around every kernel): the runtime needs ~9 us between dependent plain launches, ~1 us
-           between graph nodes.
-N > 1    : launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; every rank
-           holds the octree, renders its round-robin bands and ONE torch.distributed.gather (RCCL over
-           xGMI) per frame lands the image on rank 0, which re-interleaves it (strong scaling).  The payload
-           is 4 bytes per pixel (the Lambert term; rank 0 finishes the colour, bit-identical) and the gather
-           of batch k overlaps the renders of batch k+1 (8 consecutive frames travel in one gather: fewer, larger
-           collectives); three such pipelines on three HIP streams take the batches in turn;
-           all K frames are complete inside the timed region.
+           are replayed from a HIP graph of --graph-frames consecutive frames (0 = plain stream launches with a HIP
+           event pair around every kernel).
+N > 1    : `python3 bench.py --gpus N` starts N fresh ranks itself (python -m torch.distributed.run, one per GPU; the
+           parent process never touches a GPU) and relays rank 0's line; launched under torch.distributed.run it is a
+           rank.  Every rank holds the octree, renders its round-robin bands, ONE gather per batch of frames lands the
+           image on rank 0, which re-interleaves it (strong scaling: one frame split N ways).
 
-Prints ONE JSON line on rank 0.  `cpu_baseline` is this repo's own C restatement of the reference's GLSL
+Prints ONE JSON line on rank 0.  `roofline` prices the traversal kernel against the bound that holds -- VALU issue
+(wave-level VALU instructions from the committed PMC pass x 2 cycles on 1,024 SIMD-32 at 2.4 GHz) -- and keeps SURVEY
+8d's HBM-algorithmic figure beside it.  `cpu_baseline` is this repo's own C restatement of the reference's GLSL
 kernel (the reference has no CPU path and publishes no numbers), timed here on the box's host cores.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,28 +40,39 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 NODE_BYTES = 60                # struct GPUNodes, the reference's node record (constant even if repacked)
 PIXEL_BYTES = 16               # RGBA32F
-VALU_MIX_CYCLES = 2.85          # measured issue cost of the traversal loop's instruction mix
 SIMDS, CLOCK_GHZ, VALU_CYCLES_PER_WAVE_INST = 1024, 2.4, 2   # 256 CUs x 4 SIMD-32: a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
+VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INST   # 1228.8 G wave-instructions/s
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_counters.json")
+
+CONFIGS = {
+    "2": dict(width=1920, height=1080, mode="octree"),
+    "4": dict(width=1920, height=1080, mode="octree"),
+    "4synthetic": dict(width=1920, height=1080, mode="octree"),
+    "5": dict(width=3840, height=2160, mode="triangles"),
+}
+KERNEL_NAMES = {"auto": "k_trace_lean", "packed": "k_trace_lean", "persistent": "k_trace_lean_persistent", "packed_v3": "k_trace_packed3",
+                "packed_v1": "k_trace_packed", "generic": "k_trace_generic"}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000, help="timed frames (2000 frames = 0.15 s at N=1: past the clock ramp of a cold GPU)")
+    ap.add_argument("--steps", type=int, default=2000, help="timed frames (2000 frames = 0.1 s at N=1, config 2)")
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--dim", type=int, default=256, help="test-sphere grid edge (config 2: 256)")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="2", help="BASELINE.json configuration (see the module docstring)")
+    ap.add_argument("--dim", type=int, default=None, help="config 2 / 5: test-sphere grid edge (default 256 / 512)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--band-rows", type=int, default=16)
-    ap.add_argument("--kernel", choices=["auto", "packed", "persistent", "generic"], default="auto")
-    ap.add_argument("--cpu-frames", type=int, default=40,
-                    help="frames of the CPU baseline sample (0 = skip); 40 frames on 16 cores = about 12 core-seconds")
+    ap.add_argument("--kernel", choices=sorted(KERNEL_NAMES), default="auto")
+    ap.add_argument("--cpu-frames", type=int, default=None,
+                    help="frames of the CPU baseline sample (0 = skip); default: about 10-30 core-seconds for the configuration")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo (+ --share-gpu) rehearses the multi-rank path on one GPU; the gather is staged through host memory")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
     ap.add_argument("--verify", action="store_true", help="(kept for old command lines: the comparison below is always made)")
     ap.add_argument("--no-verify", action="store_true",
-                    help="N>1: skip rank 0's comparison of the assembled frame with the CPU oracle (one 20 ms oracle frame, outside the timed region)")
+                    help="skip rank 0's comparison of the timed frame with the CPU oracle (one oracle frame, outside the timed region)")
     ap.add_argument("--order", choices=["temporal", "centre-out"], default="temporal",
                     help="tile launch order of the packed kernel (scheduling only; pixels are identical)")
     ap.add_argument("--order-period", type=int, default=8, help="temporal order: rebuild the table every n-th frame")
@@ -63,22 +80,59 @@ def parse_args():
                     help="N>1: what a part ships to rank 0 -- 4-byte Lambert term per pixel (default) or the 16-byte pixel")
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: finish the gather of a frame before rendering the next")
     ap.add_argument("--pipelines", type=int, default=3,
-                    help="N>1: independent submit/flush pipelines, each on its own HIP stream, that take the frames in turn "
-                         "(a part's kernel is bounded by its deepest rays, not by its pixel count, so one pipeline leaves "
-                         "most of each GPU idle); 1 = a single pipeline")
+                    help="N>1: independent submit/flush pipelines, each on its own HIP stream, that take the batches in turn; 1 = a single pipeline")
     ap.add_argument("--frames-per-gather", type=int, default=8,
-                    help="N>1: consecutive frames whose parts travel in ONE gather (fewer, larger collectives: a "
-                         "torch.distributed call costs the host tens of microseconds, as much as a whole frame); 1 = one gather per frame")
+                    help="N>1: consecutive frames whose parts travel in ONE gather (fewer, larger collectives); 1 = one gather per frame")
     ap.add_argument("--graph-frames", type=int, default=50,
                     help="N=1: capture this many consecutive frames (one kernel each, strictly one after the other) in a HIP "
-                         "graph and replay it: the ~9 us the runtime needs between dependent plain launches shrink to ~1 us; "
-                         "0 = plain stream launches with a HIP event pair around every kernel")
+                         "graph and replay it; 0 = plain stream launches with a HIP event pair around every kernel")
     ap.add_argument("--frames-in-flight", type=int, default=1,
-                    help="N=1 only: render consecutive frames on this many HIP streams (own framebuffers) so that the "
-                         "deep-ray tail of one frame overlaps the start of the next; 1 = strictly one frame at a time")
-    return ap.parse_args()
+                    help="N=1 only: render consecutive frames on this many HIP streams (own framebuffers); 1 = strictly one frame at a time")
+    ap.add_argument("--ramp-ms", type=float, default=300.0,
+                    help="N=1: untimed frames of the same workload rendered for this long before the W warm-up frames, so that a cold "
+                         "GPU has reached its working clock (disclosed in the line as `clock_ramp`); 0 = none")
+    ap.add_argument("--orbit-frames", type=int, default=None,
+                    help="N=1, octree configs: extra figure with the camera orbiting 0.01 rad per frame, plain launches, launch-order "
+                         "table rebuilt every --order-period-th frame (default 240; 0 = skip)")
+    ap.add_argument("--launcher-dry-run", action="store_true", help="--gpus N without WORLD_SIZE: print the child command line and exit")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------ N > 1: self-launch
+def child_command(args, argv, port: int) -> list[str]:
+    """The N fresh ranks `python3 bench.py --gpus N ...` starts: one process per GPU over RCCL, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv) -> int:
+    """Parent of an N>1 run: touches no GPU, starts the ranks as CHILD processes (never an exec of this process),
+    relays rank 0's single JSON line and returns the children's status -- non-zero, loudly, on any failure."""
+    cmd = child_command(args, argv, free_port())
+    if args.launcher_dry_run:
+        print(json.dumps({"launcher": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    if p.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(p.stderr[-8000:])
+        sys.stderr.write(p.stdout[-4000:])
+        sys.stderr.write(f"\nbench: the {args.gpus}-rank job failed (exit status {p.returncode}, {len(lines)} result lines)\n")
+        return p.returncode if p.returncode != 0 else 1
+    print(lines[0], flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ helpers
 def host_cores() -> int:
     """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0))
@@ -91,49 +145,117 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(args, grid, nodes, view, pos, gpu_pops):
-    """Oracle (own restatement of the reference GLSL) on the host cores: all cores + one thread."""
+def device_source_hash() -> str:
+    """Identifies the device code a PMC entry was measured on (the counters are per binary)."""
+    h = hashlib.sha256()
+    for rel in ("ray_tracing_octrees_amd/csrc/rto_device.hip.h", "ray_tracing_octrees_amd/csrc/rto_api.hip"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_scene(args):
+    """The product's own host layer (C++) builds the grid; returns everything both the GPU path and the checker need."""
+    import numpy as np
+
+    import ray_tracing_octrees_amd as rto
+
+    cfg = args.config
+    if cfg in ("2", "5"):
+        dim = args.dim or (256 if cfg == "2" else 512)
+        grid = rto.VoxelGrid.test_sphere(dim)                       # main.cpp:337-372, 1052-1070 + recenterFilledVoxels
+        cam = rto.Camera(0.5, 0.7, 1.8)
+        what = f"{dim}^3 test-sphere voxel grid"
+        camtxt = "Camera(0.5,0.7,1.8)"
+    else:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "ref_scene_cache.npz"))     # sceneCache.bin via the reference's loadVoxelGrid
+        dims = tuple(int(x) for x in z["dims"])
+        data = np.unpackbits(z["packed"])[: dims[0] * dims[1] * dims[2]].reshape(dims[2], dims[1], dims[0])
+        gmin, voxel = z["min"].astype(np.float32), np.float32(z["voxel"])
+        if cfg == "4synthetic":
+            tz, ty, tx = 128, 512, 512
+            iz = ((np.arange(tz) + 0.5) * data.shape[0] / tz).astype(np.int64)
+            iy = ((np.arange(ty) + 0.5) * data.shape[1] / ty).astype(np.int64)
+            ix = ((np.arange(tx) + 0.5) * data.shape[2] / tx).astype(np.int64)
+            data = np.ascontiguousarray(data[iz][:, iy][:, :, ix])
+            grid = rto.VoxelGrid.from_array(data, gmin, voxel)
+            cam = rto.Camera(0.6, 0.5, 4500.0)
+            centre = gmin + 0.5 * np.array([tx, ty, tz], np.float32) * voxel
+            cam.setTarget(float(centre[0]), float(centre[1]), float(centre[2]))
+            what = "sceneCache.bin resampled nearest-neighbour to 512x512x128 (SYNTHETIC stand-in for the grid BASELINE.json names)"
+            camtxt = "Camera(0.6,0.5,4500) on the grid centre"
+        else:
+            grid = rto.VoxelGrid.from_array(data, gmin, voxel)
+            cam = rto.Camera(0.6, 0.5, 3500.0)
+            what = "sceneCache.bin as shipped (425x243x29 voxels, octree root 512)"
+            camtxt = "oblique Camera(0.6,0.5,3500)"
+    return grid, cam, what, camtxt
+
+
+def cpu_baseline(args, scene, frames_default):
+    """Oracle (own restatement of the reference GLSL) on the host cores: all cores + one thread; returns the oracle's frame."""
     import numpy as np
 
     from oracle import orc   # cpu_baseline leg only
 
-    W, H = args.width, args.height
+    W, H = scene["W"], scene["H"]
     cores = host_cores()
-    out = np.zeros((H, W, 4), np.float32)
-    gmin, voxel = grid.min, grid.voxelSize
-    _, st = orc.render(nodes, gmin, voxel, view, pos, W / H, 45.0, W, H, nthreads=cores, out=out)   # warm-up + stats
-    assert st["pops"] == gpu_pops, "GPU and oracle disagree on the pop count"
+    nodes, gmin, voxel, view, pos = scene["nodes"], scene["gmin"], scene["voxel"], scene["view"], scene["pos"]
+    n = frames_default if args.cpu_frames is None else args.cpu_frames
+    if scene["mode"] == "triangles":
+        tris, off = scene["tris"], scene["tri_offset"]
+
+        def run(threads):
+            return orc.render_triangles(nodes, tris, off, gmin, voxel, view, pos, W / H, 45.0, W, H, shadow=True, nthreads=threads)
+    else:
+        out = np.zeros((H, W, 4), np.float32)
+
+        def run(threads):
+            return orc.render(nodes, gmin, voxel, view, pos, W / H, 45.0, W, H, nthreads=threads, out=out)
+    want, st = run(cores)                                             # warm-up + stats + the checker's frame
+    want = np.array(want, copy=True)
+    if n <= 0:
+        return None, want, st
     ts = []
-    for _ in range(args.cpu_frames):
+    for _ in range(n):
         t = time.perf_counter()
-        orc.render(nodes, gmin, voxel, view, pos, W / H, 45.0, W, H, nthreads=cores, out=out)
+        run(cores)
         ts.append(time.perf_counter() - t)
     ts.sort()
     med = ts[len(ts) // 2]
-    t1s = []
-    for _ in range(3):
-        t = time.perf_counter()
-        orc.render(nodes, gmin, voxel, view, pos, W / H, 45.0, W, H, nthreads=1, out=out)
-        t1s.append(time.perf_counter() - t)
-    t1 = sorted(t1s)[1]
+    t = time.perf_counter()
+    run(1)
+    t1 = time.perf_counter() - t
     return {
         "value": round(W * H / med / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "sample": f"{args.cpu_frames} full {W}x{H} frames of the same scene/camera, median, OpenMP dynamic over rows; "
-                  f"plus 3 frames on 1 thread (median)",
+        "sample": f"{n} full {W}x{H} frames of the same scene/camera, median, OpenMP dynamic over rows; plus 1 frame on 1 thread",
         "single_thread_value": round(W * H / t1 / 1e6, 3),
         "note": "own restatement of reference GLSL; reference has no CPU path and publishes no numbers",
-    }, out
+    }, want, st
 
 
-def main():
-    args = parse_args()
+def pmc_entry(config: str, kernel_name: str, order: str):
+    """Counters of the committed rocprofv3 --pmc passes for this (config, kernel, launch order), or None."""
+    if not os.path.exists(PMC_FILE):
+        return None
+    with open(PMC_FILE) as f:
+        table = json.load(f)
+    for e in table.get("entries", []):
+        if e.get("config") == config and e.get("kernel") == kernel_name and e.get("order") == order:
+            return e
+    return None
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(self_launch(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}`")
-        args.gpus = world
+    world = int(world_env or "1")
+    args.gpus = world
 
     import numpy as np
     import torch
@@ -160,30 +282,41 @@ def main():
         else:
             dist.init_process_group("gloo", timeout=tmo)
 
-    # ---- scene: the product's own host layer (C++), not the oracle --------------------------------
-    W, H = args.width, args.height
-    grid = rto.VoxelGrid.test_sphere(args.dim)
-    root = rto.createOctreeFromVoxelGrid(grid)
-    nodes = root.flatten()
-    rto.freeOctree(root)
-    cam = rto.Camera(0.5, 0.7, 1.8)
+    # ---- scene ------------------------------------------------------------------------------------
+    cfg = CONFIGS[args.config]
+    W, H = args.width or cfg["width"], args.height or cfg["height"]
+    triangles = cfg["mode"] == "triangles"
+    grid, cam, what, camtxt = build_scene(args)
     view, pos = cam.getView(), cam.getPos()
     frame = rto.make_frame(view, pos, W / H, 45.0, W, H)
 
     ctx = rto.Context(local_rank)
-    ctx.upload_octree(nodes, grid.min, grid.voxelSize)
+    vox = grid.data
+    ctx.build_octree(vox, grid.min, grid.voxelSize)                 # createOctreeFromVoxelGrid + setOctree on the GPU (row N4)
+    if triangles:
+        ctx.build_leaf_triangles(None)                              # MarchingCubesRenderer per leaf, on the GPU (row N2)
     ctx.set_kernel({"auto": rto.KERNEL_AUTO, "packed": rto.KERNEL_PACKED, "persistent": rto.KERNEL_PACKED_PERSISTENT,
-                    "generic": rto.KERNEL_GENERIC}[args.kernel])
+                    "packed_v3": rto.KERNEL_PACKED_V3, "packed_v1": rto.KERNEL_PACKED_V1, "generic": rto.KERNEL_GENERIC}[args.kernel])
     ctx.set_launch_order(1 if args.order == "temporal" else 0, args.order_period)
     info = ctx.info()
     pipelined = world > 1 and not args.no_pipeline
     npipe = max(1, args.pipelines) if pipelined else 1
-    renderers = [tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows,
+
+    def backend():
+        return tilesplit.HipBackend(ctx, triangles=triangles, shadow=True)
+
+    renderers = [tilesplit.TileSplitRenderer(backend(), rank, world, band_rows=args.band_rows,
                                              stage_through_host=(args.dist_backend == "gloo"), payload=args.payload)
                  for _ in range(npipe)]
     renderer = renderers[0]
-    rest_renderer = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), rank, world, band_rows=args.band_rows,
+    rest_renderer = tilesplit.TileSplitRenderer(backend(), rank, world, band_rows=args.band_rows,
                                                 stage_through_host=(args.dist_backend == "gloo"), payload=args.payload)
+
+    def render_to(buf_ptr, stream_handle, fr=None):
+        if triangles:
+            ctx.render_triangles_device(fr or frame, buf_ptr, True, None, stream_handle)
+        else:
+            ctx.render_device(fr or frame, buf_ptr, None, stream_handle)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -226,6 +359,15 @@ def main():
                 img_ = out_[-1] if out_ is not None else img_
         return img_
 
+    # ---- untimed: clock ramp (disclosed), then the W warm-up frames ------------------------------------
+    ramp_frames = 0
+    if world == 1 and args.ramp_ms > 0:
+        t_end = time.perf_counter() + args.ramp_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                renderer.render(frame)
+            torch.cuda.synchronize()
+            ramp_frames += 20
     run_frames(args.warmup)
     sync_all()
 
@@ -235,13 +377,13 @@ def main():
         streams = [torch.cuda.Stream() for _ in range(fif)]
         bufs = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(fif)]
         for i in range(fif):
-            ctx.render_device(frame, bufs[i].data_ptr(), None, streams[i].cuda_stream)
+            render_to(bufs[i].data_ptr(), streams[i].cuda_stream)
         sync_all()
     use_graph = world == 1 and fif == 1 and args.graph_frames > 0
     graph = None
     gframes = 0
     if use_graph:
-        # after the warm-up frames rto_render_device allocates nothing and never synchronises: it can be stream-captured
+        # after the warm-up frames the render entry points allocate nothing and never synchronise: they can be stream-captured
         gframes = min(args.graph_frames, args.steps)
         buf0 = renderer.render(frame)
         ctx.timing_begin(0)
@@ -250,7 +392,7 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
                 for _ in range(gframes):
-                    ctx.render_device(frame, buf0.data_ptr(), None, stream.cuda_stream)
+                    render_to(buf0.data_ptr(), stream.cuda_stream)
             graph.replay()                              # untimed: first replay of a fresh graph
             sync_all()
             ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -265,7 +407,7 @@ def main():
                 renderer.render(frame)
             sync_all()
     if not use_graph:
-        ctx.timing_begin(args.steps)  # HIP event pair around every traversal kernel, on its launch stream, no syncs
+        ctx.timing_begin(args.steps if not triangles else 0)  # HIP event pair around every traversal kernel, on its launch stream, no syncs
     sync_all()
     t0 = time.perf_counter()
     if use_graph:
@@ -273,16 +415,21 @@ def main():
         for _ in range(args.steps // gframes):
             graph.replay()
         for _ in range(args.steps % gframes):           # exactly K frames: the remainder as plain launches
-            ctx.render_device(frame, buf0.data_ptr(), None, stream.cuda_stream)
+            render_to(buf0.data_ptr(), stream.cuda_stream)
         ev_b.record(stream)
         img = buf0
     elif fif > 1:
         for k in range(args.steps):
             s_ = streams[k % fif]
-            ctx.render_device(frame, bufs[k % fif].data_ptr(), None, s_.cuda_stream)
+            render_to(bufs[k % fif].data_ptr(), s_.cuda_stream)
             img = bufs[k % fif]
     else:
+        if world == 1 and triangles:
+            ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev_a.record(stream)
         img = run_frames(args.steps)
+        if world == 1 and triangles:
+            ev_b.record(stream)
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -292,70 +439,110 @@ def main():
     rays = W * H
     result = None
     if rank == 0:
-        stats = ctx.frame_stats(frame)                       # exact pop count of this frame (instrumented kernel)
-        pops_per_ray = stats["pops"] / stats["rays"]
+        kernel_name = KERNEL_NAMES[args.kernel] if info.canonical else "k_trace_generic"
+        if triangles:
+            kernel_name = "k_trace_packed_triangles" if (info.canonical and args.kernel != "generic") else "k_trace_triangles"
+            _, tstats = ctx.render_triangles_host(frame, shadow=True, stats=True)     # primary + shadow pops (instrumented kernel)
+            stats = {"rays": rays, "pops": tstats["pops"], "hits": tstats["hits"], "capped": None}
+        else:
+            stats = ctx.frame_stats(frame)                       # exact pop count of this frame (instrumented kernel)
+        pops_per_ray = stats["pops"] / rays
         bytes_per_ray = pops_per_ray * NODE_BYTES + PIXEL_BYTES
+        tri_note = ""
+        if triangles:
+            # SURVEY 8d leaves config 5's triangle / shadow terms to the build: every pop of either traversal prices one
+            # 60 B node, every triangle tested 48 B (v0, v1, v2, normal); the latter is not counted by the instrumented
+            # kernel, so the figure below is a lower bound of the algorithmic bytes.
+            tri_note = " (config 5: pops of the primary AND the shadow traversal; triangle bytes not included)"
         roofline = None
         if world == 1:
-            if use_graph:
+            if use_graph or triangles:
                 # one HIP event pair around the whole timed region, on the launch stream: GPU time per frame = the
-                # traversal kernel + the ~1 us between graph nodes (an upper bound of the kernel's own duration)
+                # traversal kernel + the gap between consecutive launches (an upper bound of the kernel's own duration)
                 k_avg = ev_a.elapsed_time(ev_b) / args.steps
                 kms = [k_avg]
             else:
                 kms = sorted(float(x) for x in ctx.timing_read())
                 assert len(kms) == args.steps
                 k_avg = sum(kms) / len(kms)
-            # cost of an event pair with nothing between (reported, not subtracted): rocprofv3's kernel
-            # duration is ~ k_avg minus this
             cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
             for a, b in cal:
                 a.record(stream); b.record(stream)
             torch.cuda.synchronize()
             pair_overhead = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
-            achieved = rays * bytes_per_ray / (k_avg * 1e-3) / 1e9
-            traffic = None
-            valu = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("dim") == args.dim and tj.get("width") == W and tj.get("height") == H:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    if tj.get("SQ_INSTS_VALU"):
-                        # the bound that actually holds (informational): wave-level VALU instructions (PMC) against the
-                        # chip's issue rate -- 1024 SIMDs x 2.4 GHz, 2 cycles per wave64 instruction (v_pk_* count once here but do two lanes' worth)
-                        insts = float(tj["SQ_INSTS_VALU"])
-                        floor_ms = insts * VALU_CYCLES_PER_WAVE_INST / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
-                        mix_ms = insts * VALU_MIX_CYCLES / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
-                        valu = {"wave_insts_per_launch": int(insts), "lane_utilisation": round(tj["SQ_THREAD_CYCLES_VALU"] / (64.0 * insts), 3),
-                                "issue_floor_ms": round(floor_ms, 5), "frac_of_issue_peak": round(floor_ms / k_avg, 3),
-                                "mix_weighted_floor_ms": round(mix_ms, 5), "frac_of_mix_weighted_peak": round(mix_ms / k_avg, 3),
-                                "model": f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz; issue floor at {VALU_CYCLES_PER_WAVE_INST} cycles per wave64 VALU instruction; "
-                                         f"mix-weighted at {VALU_MIX_CYCLES} (loop body: 27 v_pk_*, 16 v_max3/min3, 4 v_bcnt at ~4.3-4.5 cycles, "
-                                         f"~158 single-rate ops at ~2.4; tools/ubench/valu_rate.hip)"}
+            hbm_alg = rays * bytes_per_ray / (k_avg * 1e-3) / 1e9
+            order_key = "centre-out" if (args.order != "temporal" or triangles) else "temporal"
+            pmc = pmc_entry(args.config, kernel_name, order_key)
             roofline = {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": {"auto": "k_trace_packed3", "packed": "k_trace_packed3", "persistent": "k_trace_packed3_persistent"}.get(args.kernel, "k_trace_generic") if (info.canonical and args.kernel != "generic") else "k_trace_generic",
-                "launch_order": ("centre-out" if args.order != "temporal" else
+                "bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s", "frac": None,
+                "traffic": None, "traffic_source": None,
+                "kernel": kernel_name,
+                "model": f"{SIMDS} SIMD-32 x {CLOCK_GHZ} GHz / {VALU_CYCLES_PER_WAVE_INST} cycles per wave64 VALU instruction (MI355X_MICROARCH.md); "
+                         "achieved = SQ_INSTS_VALU per launch (PMC pass, traffic_source) / the kernel's average duration measured in this run",
+                "launch_order": ("centre-out" if order_key == "centre-out" else
                                  "temporal (tiles sorted by an earlier frame's trip counts; table built during the warm-up, frozen while the frames are replayed from the graph)" if use_graph else
                                  f"temporal (tiles sorted by an earlier frame's trip counts; k_sort_scatter after every {args.order_period}-th frame)"),
                 "kernel_ms_avg": round(k_avg, 5), "kernel_ms_median": round(kms[len(kms) // 2], 5),
-                "kernel_ms_how": (f"one HIP event pair around the {args.steps} timed frames / {args.steps} (graph replay: events inside a captured graph "
-                                  f"cannot be timed): an upper bound of the kernel's duration, it includes the ~1 us between graph nodes") if use_graph
-                                 else "HIP event pair around every traversal kernel launch of the timed region",
+                "kernel_ms_how": (f"one HIP event pair on the launch stream around the {args.steps} timed frames / {args.steps} (events inside a captured "
+                                  f"graph cannot be timed): an upper bound of the kernel's duration, it includes the gap between consecutive launches") if (use_graph or triangles)
+                                 else "HIP event pair around every traversal kernel launch of the timed region, on its launch stream",
                 "event_pair_overhead_ms": round(pair_overhead, 5),
-                "algorithmic_bytes_per_ray": round(bytes_per_ray, 2), "pops_per_ray": round(pops_per_ray, 4),
-                "algorithmic_bytes_per_launch": int(round(rays * bytes_per_ray)),
-                "note": "algorithmic bytes = pops x 60 B reference node + 16 B pixel (SURVEY 8d); the packed kernel "
-                        "reads 8-byte descriptors of internal nodes only, so frac may exceed 1: the real bound is VALU",
+                "hbm_algorithmic": {
+                    "achieved": round(hbm_alg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "ratio": round(hbm_alg / HBM_PEAK_GBS, 4),
+                    "bytes_per_ray": round(bytes_per_ray, 2), "pops_per_ray": round(pops_per_ray, 4),
+                    "bytes_per_launch": int(round(rays * bytes_per_ray)),
+                    "note": "SURVEY 8d: pops x 60 B reference node + 16 B pixel" + tri_note + ". The packed kernels read 8-byte descriptors of "
+                            "internal nodes only (L1/L2 resident), so this ratio exceeds 1: it prices the reference's layout, not this kernel's traffic",
+                },
             }
-            if valu is not None:
-                roofline["valu"] = valu
+            if pmc is not None:
+                insts = float(pmc["SQ_INSTS_VALU"])
+                achieved = insts / (k_avg * 1e-3) / 1e9
+                roofline["achieved"] = round(achieved, 1)
+                roofline["frac"] = round(achieved / VALU_PEAK_GINST, 4)
+                roofline["valu_insts_per_launch"] = int(insts)
+                if pmc.get("SQ_THREAD_CYCLES_VALU"):
+                    roofline["lane_utilisation"] = round(float(pmc["SQ_THREAD_CYCLES_VALU"]) / (64.0 * insts), 3)
+                roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
+                roofline["traffic_source"] = {"file": "profiles/pmc_counters.json", "summary": pmc.get("source"), "commit": pmc.get("commit"),
+                                              "device_source_hash": pmc.get("device_source_hash"),
+                                              "matches_this_build": pmc.get("device_source_hash") == device_source_hash(),
+                                              "how": "rocprofv3 --pmc, separate passes (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE, SQ_*), counters only"}
+            else:
+                roofline["note"] = (f"no PMC entry for config {args.config} / {kernel_name} / {order_key} in profiles/pmc_counters.json: "
+                                    "achieved and frac cannot be stated for this combination")
+        orbit = None
+        if world == 1 and not triangles and fif == 1:
+            n_orbit = 240 if args.orbit_frames is None else args.orbit_frames
+            if n_orbit > 0:
+                # a camera that moves: theta advances 0.01 rad per frame, plain stream launches (no graph), the launch-order
+                # table is rebuilt after every --order-period-th frame from that frame's costs
+                th0, ph0, r0 = cam.theta, cam.phi, cam.radius
+                oframes = []
+                for i in range(n_orbit):
+                    c2 = rto.Camera(th0 + 0.01 * i, ph0, r0)
+                    c2.setTarget(*cam.target)
+                    oframes.append(rto.make_frame(c2.getView(), c2.getPos(), W / H, 45.0, W, H))
+                obuf = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+                ctx.timing_begin(0)
+                for fr in oframes[:16]:
+                    render_to(obuf.data_ptr(), stream.cuda_stream, fr)
+                torch.cuda.synchronize()
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t_o = time.perf_counter()
+                ea.record(stream)
+                for fr in oframes:
+                    render_to(obuf.data_ptr(), stream.cuda_stream, fr)
+                eb.record(stream)
+                torch.cuda.synchronize()
+                wall = time.perf_counter() - t_o
+                orbit = {"frames": n_orbit, "rad_per_frame": 0.01, "launches": "plain stream launches, launch-order table rebuilt every "
+                         f"{args.order_period}-th frame (k_sort_scatter inside the timed region)",
+                         "ms_per_frame": round(wall / n_orbit * 1e3, 5), "gpu_ms_per_frame": round(ea.elapsed_time(eb) / n_orbit, 5),
+                         "Mrays_per_s": round(rays * n_orbit / wall / 1e6, 1)}
         pcie = None
-        if world == 1:
-            # the C ABI's host-buffer entry point (kernel + 33 MB D2H over PCIe): informational, never `value`
+        if world == 1 and not triangles:
+            # the C ABI's host-buffer entry point (kernel + D2H over PCIe): informational, never `value`
             ts = []
             for _ in range(5):
                 t = time.perf_counter()
@@ -365,18 +552,25 @@ def main():
             pcie = {"ms_per_frame": round(ts[2] * 1e3, 4), "Mrays_per_s": round(rays / ts[2] / 1e6, 1),
                     "what": "rto_render_host: kernel + device-to-host copy of the RGBA32F frame into pageable memory"}
         cpu = None
-        if world == 1 and args.cpu_frames > 0:
-            cpu, want = cpu_baseline(args, grid, nodes, view, pos, stats["pops"])
-            got = img.cpu().numpy()
-            if got.tobytes() != want.tobytes():
-                sys.exit("bench: the timed frame differs from the oracle's -- result void")
-        elif not args.no_verify:
-            from oracle import orc   # the checker, outside the timed region
+        verified = False
+        skip_cpu = args.cpu_frames == 0
+        if not (skip_cpu and args.no_verify):
+            scene = {"W": W, "H": H, "mode": cfg["mode"], "nodes": ctx.download_nodes(), "gmin": grid.min, "voxel": grid.voxelSize,
+                     "view": view, "pos": pos}
+            if triangles:
+                from oracle import orc   # the checker builds its own triangle buffer from the voxels
 
-            want = np.zeros((H, W, 4), np.float32)
-            orc.render(nodes, grid.min, grid.voxelSize, view, pos, W / H, 45.0, W, H, nthreads=host_cores(), out=want)
-            if img.cpu().numpy().tobytes() != want.tobytes():
-                sys.exit("bench: the assembled frame differs from the oracle's -- result void")
+                og = orc.Grid(grid.dims, grid.min, grid.voxelSize, vox)
+                scene["tris"], scene["tri_offset"] = orc.build_leaf_triangles(og, scene["nodes"])
+            default_frames = {"2": 40, "4": 12, "4synthetic": 10, "5": 4}[args.config]
+            if world > 1 or skip_cpu:
+                args.cpu_frames = 0
+            cpu, want, ost = cpu_baseline(args, scene, default_frames)
+            if ost["pops"] != stats["pops"] or ost["hits"] != stats["hits"]:
+                sys.exit("bench: GPU and oracle disagree on the pop / hit counts -- result void")
+            if img.cpu().numpy().tobytes() != np.ascontiguousarray(want, np.float32).tobytes():
+                sys.exit("bench: the timed frame differs from the oracle's -- result void")
+            verified = True
         result = {
             "metric": "Mrays/s (primary rays), 1920x1080" if (W, H) == (1920, 1080) else f"Mrays/s (primary rays), {W}x{H}",
             "value": round(rays * args.steps / elapsed / 1e6, 2),
@@ -389,21 +583,25 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.dim}^3 test-sphere voxel grid, octree to min-leaf 1 ({info.num_nodes} nodes), "
-                            f"{W}x{H} primary rays, Camera(0.5,0.7,1.8), fov 45",
-                "parallelism": (("1 GPU" + (f", frames replayed from a HIP graph of {gframes} consecutive frames" if use_graph else "")) if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else f"screen split over {world} GPUs, {args.band_rows}-row bands "
+                "workload": f"BASELINE config {args.config}: {what}, octree to min-leaf 1 ({info.num_nodes} nodes), "
+                            f"{W}x{H} primary rays{', Marching-Cubes leaf triangles + 1 shadow ray per hit' if triangles else ''}, {camtxt}, fov 45",
+                "parallelism": (("1 GPU" + (f", frames replayed from a HIP graph of {gframes} consecutive frames" if use_graph else ", plain stream launches")) if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else f"screen split over {world} GPUs, {args.band_rows}-row bands "
                                                           f"round-robin, 1 RCCL gather per {'frame' if fpg == 1 else f'{fpg} frames'} ({'4-byte Lambert term' if args.payload == 'shade' else 'RGBA32F'} per pixel"
                                                           f"{', gather k overlaps render k+1' if pipelined else ''}"
                                                           f"{f', {fpg} consecutive frames per gather' if fpg > 1 else ''}"
                                                           f"{f', {npipe} such pipelines on {npipe} HIP streams take the batches in turn' if npipe > 1 else ''})",
                 "kernel": args.kernel,
+                "clock_ramp": (f"{ramp_frames} untimed frames of the same workload ({args.ramp_ms:.0f} ms) before the {args.warmup} warm-up frames, "
+                               "so that a cold GPU has reached its working clock") if ramp_frames else "none",
             },
             "hit_rays": stats["hits"], "capped_rays": stats["capped"],
-            "verified_against_oracle": bool((world == 1 and args.cpu_frames > 0) or (not (world == 1 and args.cpu_frames > 0) and not args.no_verify)),
+            "verified_against_oracle": verified,
             "device": ctx.device_name,
         }
         if roofline is not None:
             result["roofline"] = roofline
+        if orbit is not None:
+            result["orbit"] = orbit
         if pcie is not None:
             result["pcie_inclusive"] = pcie
         if cpu is not None:

@@ -64,10 +64,12 @@ typedef struct rto_partition {
  * canonical BFS octree (what setOctree produces), else GENERIC. */
 #define RTO_KERNEL_AUTO    0
 #define RTO_KERNEL_GENERIC 1       /* 60-byte nodes, explicit child indices, per-thread stack[128] */
-#define RTO_KERNEL_PACKED  2       /* 8-byte child descriptors, LDS level stack, branch-free O(1)-ascent loop */
+#define RTO_KERNEL_PACKED  2       /* 8-byte child descriptors, LDS level stack, branch-free O(1)-ascent loop with the pop
+                                    * count rebuilt once per ray after the loop (k_trace_lean) */
 #define RTO_KERNEL_PACKED_V1 3     /* first form of the packed kernel (level-by-level ascent); kept for A/B runs */
 #define RTO_KERNEL_PACKED_PERSISTENT 4  /* the default kernel as persistent threads: a machine-filling grid whose waves
                                          * take launch slots from a global counter; kept for A/B runs */
+#define RTO_KERNEL_PACKED_V3 5     /* round-1 default (k_trace_packed3: pops counted inside the loop); kept for A/B runs */
 
 typedef struct rto_stats {         /* per-frame counters, same meaning as the oracle's */
     uint64_t rays, pops, hits, capped;
@@ -118,6 +120,10 @@ int  rto_set_kernel(rto_context* ctx, int kernel /* RTO_KERNEL_* */);
 #define RTO_ORDER_CENTRE_OUT 0
 #define RTO_ORDER_TEMPORAL   1
 int  rto_set_launch_order(rto_context* ctx, int policy, int refresh_period);
+/* The launch-order tables belong to the launch stream (hipStream_t as void*).  A context keeps them for the 16 most
+ * recently used streams; call this before destroying a stream so that a later stream that happens to get the same
+ * handle does not inherit its table (harmless to pixels, a stale schedule).  Synchronises the device. */
+int  rto_forget_stream(rto_context* ctx, void* hip_stream);
 
 /* ---- frustum culling ------------------------------------------------------
  * replaces: the CPU loop + compaction + SSBO re-upload of
@@ -125,6 +131,10 @@ int  rto_set_launch_order(rto_context* ctx, int policy, int refresh_period);
  * The test runs on the GPU over the resident array; rendering afterwards behaves as
  * if the compacted array had been uploaded.  enable=0 restores the full array. */
 int  rto_update_frustum(rto_context* ctx, const float view[16], float fov_deg, float aspect, int enable);
+/* Developer aid: the same update with caller-supplied planes (LEFT, RIGHT, TOP, BOTTOM, NEAR, FAR as nx, ny, nz, d;
+ * normalised) and margin instead of the ones S/RT:731-755 derives -- lets a test build situations real cameras cannot,
+ * e.g. a culled root with surviving descendants (S/RT:765-812 then starts at whatever lands at compacted index 0). */
+int  rto_debug_update_frustum_planes(rto_context* ctx, const float planes[24], float margin);
 /* Copies the compacted array (== m_visibleNodes, S/RayTracerBVH.cpp:775-802) to the host for parity
  * checks.  out may be NULL to query the count only. */
 int  rto_download_visible_nodes(rto_context* ctx, rto_node* out, int64_t capacity, int64_t* count);
@@ -141,7 +151,8 @@ int  rto_render_device(rto_context* ctx, const rto_frame* frame, const rto_parti
                        void* d_out, void* hip_stream);
 /* HIP graphs: once a frame of the same width/height/aspect/fov has been rendered on a stream, rto_render_device (and the
  * _shade / _triangles variants) allocate nothing and never synchronise on it, so a sequence of frames may be captured
- * with hipStreamBeginCapture and replayed (the runtime needs ~9 us between dependent plain launches but ~1 us between
+ * with hipStreamBeginCapture and replayed; a captured launch that WOULD have to allocate or synchronise (first frame of
+ * a new size on that stream) fails with RTO_E_UNSUPPORTED instead of invalidating the capture (the runtime needs ~9 us between dependent plain launches but ~1 us between
  * graph nodes: 70 -> 61 us per frame at BASELINE config 2).  While a stream is being captured its launch-order table is
  * frozen (no cost recording, no rebuild): a replay finds the device state it was captured with. */
 /* Synchronous convenience: whole frame into host memory (the one API addition the
@@ -233,6 +244,8 @@ int  rto_debug_timeline(rto_context* ctx, const rto_frame* frame, int32_t* host_
  * slot -> tile table (NULL restores the automatic one). */
 int  rto_debug_tile_cost(rto_context* ctx, int32_t* host_cost, int64_t capacity, int64_t* count);
 int  rto_debug_set_tile_order(rto_context* ctx, const int32_t* host_order, int64_t n);
+/* Writes the launch-order sort refused because they fell outside the table (must be 0; synchronises). */
+int  rto_debug_sort_violations(rto_context* ctx, int* count);
 /* Device time in ms of the most recent traversal kernel launched by this context
  * (hipEvent pair on the launch stream; synchronises on that event). */
 int  rto_last_kernel_ms(rto_context* ctx, float* ms);

@@ -16,7 +16,7 @@ The HIP library is mandatory: nothing in this package computes pixels on the CPU
 from __future__ import annotations
 
 from . import hip, host
-from .hip import (KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED, KERNEL_PACKED_PERSISTENT, KERNEL_PACKED_V1, NODE_DTYPE, Context, Frame, Partition,
+from .hip import (KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED, KERNEL_PACKED_PERSISTENT, KERNEL_PACKED_V1, KERNEL_PACKED_V3, NODE_DTYPE, Context, Frame, Partition,
                   RtoError, make_frame)
 from .host import (Camera, MarchingCubesRenderer, OctreeNode, RayTracerBVH, VoxelGrid, buildLeafTriangles,
                    createOctreeFromVoxelGrid,
@@ -26,5 +26,5 @@ __all__ = [
     "RayTracerBVH", "VoxelGrid", "OctreeNode", "Camera", "createOctreeFromVoxelGrid", "freeOctree",
     "getVoxelSafe", "loadVoxelGrid", "loadVoxelGridPartial", "saveVoxelGrid", "localMC", "MarchingCubesRenderer", "buildLeafTriangles",
     "Context", "Frame", "Partition", "RtoError", "make_frame", "NODE_DTYPE",
-    "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_PACKED", "KERNEL_PACKED_PERSISTENT", "KERNEL_PACKED_V1", "hip", "host",
+    "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_PACKED", "KERNEL_PACKED_PERSISTENT", "KERNEL_PACKED_V1", "KERNEL_PACKED_V3", "hip", "host",
 ]

@@ -65,12 +65,14 @@ struct rto_context {
         bool valid = false;
         bool fixed = false;             // debug: the caller supplied the table, do not rebuild it
         int age = 0;                    // frames rendered since the table was built
-        int* d_queue = nullptr;         // persistent-threads variant: two slot counters, used alternately
-        int queuePing = 0;
+        int* d_queue = nullptr;         // persistent-threads variant: the slot counter (zeroed in front of every launch)
+        unsigned long lastUse = 0;      // orderClock value of the last launch on this stream (eviction order)
     };
     std::map<hipStream_t, OrderState> orders;
     hipStream_t lastOrderStream = nullptr;      // what the rto_debug_* order functions refer to
-    static constexpr size_t kMaxOrderStreams = 16;   // further streams render centre-out
+    static constexpr size_t kMaxOrderStreams = 16;   // a 17th stream evicts the least recently used entry
+    unsigned long orderClock = 0;
+    int* d_sortViolations = nullptr;            // k_sort_scatter: out-of-range writes refused (must stay 0; rto_debug_sort_violations)
 
     // voxels retained by rto_build_octree (so that rto_build_leaf_triangles can run without a second upload)
     uint8_t* d_vox = nullptr;
@@ -172,7 +174,8 @@ int rto_create(int device_ordinal, rto_context** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipMalloc(&c->d_counters, sizeof(Counters))) != hipSuccess ||
-        (e = hipMalloc(&c->d_visibleCount, sizeof(int64_t))) != hipSuccess) {
+        (e = hipMalloc(&c->d_visibleCount, sizeof(int64_t))) != hipSuccess ||
+        (e = hipMalloc(&c->d_sortViolations, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_sortViolations, 0, sizeof(int))) != hipSuccess) {
         std::string msg = std::string("rto_create: ") + hipGetErrorString(e);
         rto_destroy(c);
         return fail(nullptr, RTO_E_HIP, msg);
@@ -195,6 +198,7 @@ void rto_destroy(rto_context* c) {
     (void)hipFree(c->d_steps);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_visibleCount);
+    (void)hipFree(c->d_sortViolations);
     for (hipEvent_t e : c->ringStart) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ringStop) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -539,6 +543,26 @@ int rto_set_launch_order(rto_context* c, int policy, int refresh_period) {
     return RTO_OK;
 }
 
+int rto_forget_stream(rto_context* c, void* hip_stream) {
+    if (!c) return RTO_E_INVALID;
+    auto it = c->orders.find((hipStream_t)hip_stream);
+    if (it == c->orders.end()) return RTO_OK;
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipDeviceSynchronize());          // no kernel still reads the tables
+    (void)hipFree(it->second.d_tileCost); (void)hipFree(it->second.d_tileOrder); (void)hipFree(it->second.d_sortHist); (void)hipFree(it->second.d_queue);
+    if (c->lastOrderStream == it->first) c->lastOrderStream = nullptr;
+    c->orders.erase(it);
+    return RTO_OK;
+}
+
+int rto_debug_sort_violations(rto_context* c, int* count) {
+    if (!c || !count) return RTO_E_INVALID;
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipDeviceSynchronize());
+    RTO_HIP(c, hipMemcpy(count, c->d_sortViolations, sizeof(int), hipMemcpyDeviceToHost));
+    return RTO_OK;
+}
+
 int rto_octree_info_get(const rto_context* c, rto_octree_info* out) {
     if (!c || !out) return RTO_E_INVALID;
     out->num_nodes = c->numNodes;
@@ -553,7 +577,7 @@ int rto_octree_info_get(const rto_context* c, rto_octree_info* out) {
 
 int rto_set_kernel(rto_context* c, int kernel) {
     if (!c) return RTO_E_INVALID;
-    if (kernel < RTO_KERNEL_AUTO || kernel > RTO_KERNEL_PACKED_PERSISTENT)
+    if (kernel < RTO_KERNEL_AUTO || kernel > RTO_KERNEL_PACKED_V3)
         return fail(c, RTO_E_INVALID, "rto_set_kernel: unknown kernel id");
     if (kernel >= RTO_KERNEL_PACKED && c->numNodes > 0 && !c->canonical)
         return fail(c, RTO_E_UNSUPPORTED, "rto_set_kernel: packed kernel needs a canonical BFS octree");
@@ -562,26 +586,11 @@ int rto_set_kernel(rto_context* c, int kernel) {
 }
 
 // ---------------------------------------------------------------- frustum culling
-int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, float aspect, int enable) {
-    if (!c) return RTO_E_INVALID;
-    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_update_frustum: no octree uploaded");
-    RTO_HIP(c, hipSetDevice(c->device));
-    // the visibility masks live in the descriptors every traversal kernel reads: frames still in flight on caller
-    // streams must be done before they change, and the change must be complete before this returns
-    RTO_HIP(c, hipDeviceSynchronize());
+// One frustum update for the given planes (LEFT, RIGHT, TOP, BOTTOM, NEAR, FAR; normalised) and margin.
+static int update_frustum_planes(rto_context* c, const float planes[24], float margin) {
     const int64_t n = c->numNodes;
     const int nb = (int)((n + kBlock - 1) / kBlock);
     const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
-    if (!enable) {
-        if (c->culling && c->canonical && nbInt > 0) {
-            hipLaunchKernelGGL(k_desc_visall, dim3(nbInt), dim3(kBlock), 0, c->stream, c->numInternal, c->d_desc);
-            RTO_HIP(c, hipGetLastError());
-            RTO_HIP(c, hipStreamSynchronize(c->stream));
-        }
-        c->culling = false; c->rootVisible = 1; c->visibleNodes = n;
-        return RTO_OK;
-    }
-    if (!view) return fail(c, RTO_E_INVALID, "rto_update_frustum: view is NULL");
     if (!c->d_vis) {
         RTO_HIP(c, hipMalloc(&c->d_vis, (size_t)n));
         RTO_HIP(c, hipMalloc(&c->d_remap, (size_t)n * sizeof(int)));
@@ -589,14 +598,11 @@ int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, floa
         RTO_HIP(c, hipMalloc(&c->d_blockBase, (size_t)nb * sizeof(int)));
         RTO_HIP(c, hipMalloc(&c->d_compact, (size_t)n * sizeof(rto_node)));
     }
-    // S/RT:731-734: Frustum(perspective(radians(fov), aspect, 0.01, 5000) * view)
     CullParams C;
-    rtmath::mat4 proj = rtmath::perspective(rtmath::radians(fov_deg), aspect, 0.01f, 5000.f);
-    rtmath::mat4 vp = proj * rtmath::mat4::from(view);
-    rtmath::frustum_planes(vp, C.planes);
+    std::memcpy(C.planes, planes, sizeof C.planes);
     std::memcpy(C.gridMin, c->gridMin, sizeof C.gridMin);
     C.voxelSize = c->voxelSize;
-    C.margin = 150.0f;
+    C.margin = margin;
     hipLaunchKernelGGL(k_cull_flags, dim3(nb), dim3(kBlock), 0, c->stream, C, c->d_nodes, n, c->d_vis, c->d_blockCount);
     hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, c->stream, c->d_blockCount, nb, c->d_blockBase, c->d_visibleCount);
     hipLaunchKernelGGL(k_cull_remap, dim3(nb), dim3(kBlock), 0, c->stream, c->d_vis, n, c->d_blockBase, c->d_remap);
@@ -613,6 +619,41 @@ int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, floa
     c->rootVisible = rootVis ? 1 : 0;
     c->culling = true;
     return RTO_OK;
+}
+
+int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, float aspect, int enable) {
+    if (!c) return RTO_E_INVALID;
+    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_update_frustum: no octree uploaded");
+    RTO_HIP(c, hipSetDevice(c->device));
+    // the visibility masks live in the descriptors every traversal kernel reads: frames still in flight on caller
+    // streams must be done before they change, and the change must be complete before this returns
+    RTO_HIP(c, hipDeviceSynchronize());
+    if (!enable) {
+        const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
+        if (c->culling && c->canonical && nbInt > 0) {
+            hipLaunchKernelGGL(k_desc_visall, dim3(nbInt), dim3(kBlock), 0, c->stream, c->numInternal, c->d_desc);
+            RTO_HIP(c, hipGetLastError());
+            RTO_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        c->culling = false; c->rootVisible = 1; c->visibleNodes = c->numNodes;
+        return RTO_OK;
+    }
+    if (!view) return fail(c, RTO_E_INVALID, "rto_update_frustum: view is NULL");
+    // S/RT:731-734: Frustum(perspective(radians(fov), aspect, 0.01, 5000) * view), margin 150 (S/RT:755)
+    float planes[24];
+    rtmath::mat4 proj = rtmath::perspective(rtmath::radians(fov_deg), aspect, 0.01f, 5000.f);
+    rtmath::mat4 vp = proj * rtmath::mat4::from(view);
+    rtmath::frustum_planes(vp, planes);
+    return update_frustum_planes(c, planes, 150.0f);
+}
+
+int rto_debug_update_frustum_planes(rto_context* c, const float planes[24], float margin) {
+    if (!c) return RTO_E_INVALID;
+    if (!planes) return fail(c, RTO_E_INVALID, "rto_debug_update_frustum_planes: planes is NULL");
+    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_debug_update_frustum_planes: no octree uploaded");
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipDeviceSynchronize());
+    return update_frustum_planes(c, planes, margin);
 }
 
 int rto_download_visible_nodes(rto_context* c, rto_node* out, int64_t capacity, int64_t* count) {
@@ -644,7 +685,10 @@ int rto_partition_rows(const rto_frame* f, const rto_partition* p) {
 
 }  // extern "C"
 
-static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* p, RenderParams& P) {
+static bool stream_is_capturing(hipStream_t s);
+
+// launch_stream: the stream the frame is about to be launched on (to refuse work a capture in progress cannot hold)
+static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* p, RenderParams& P, hipStream_t launch_stream = nullptr) {
     if (!f) return fail(c, RTO_E_INVALID, "render: frame is NULL");
     if (f->width <= 0 || f->height <= 0) return fail(c, RTO_E_INVALID, "render: width/height must be positive");
     if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "render: no octree uploaded (setOctree first)");
@@ -670,6 +714,9 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     P.rootVisible = c->rootVisible;
     // S/RT:341-346: nx depends on the column only, ny on the row only -> two small tables, same float ops
     if (c->rayW != P.W || c->rayH != P.H || c->rayAspect != P.aspect || c->rayTan != P.tanHalfFov || !c->d_rayX) {
+        if (launch_stream && stream_is_capturing(launch_stream))
+            return fail(c, RTO_E_UNSUPPORTED, "render: a frame of a new width/height/aspect/fov rebuilds the ray tables (allocation + "
+                                              "synchronisation); render one such frame before hipStreamBeginCapture");
         std::vector<float> tx((size_t)P.W), ty((size_t)P.H);
         for (int px = 0; px < P.W; px++) {
             float nx = ((float)px + 0.5f) / (float)P.W * 2.0f - 1.0f;
@@ -747,6 +794,28 @@ static bool stream_is_capturing(hipStream_t s) {
     return hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
 }
 
+// The scheduling state of launch stream `s` (temporal launch order, persistent-kernel counter).  At most
+// kMaxOrderStreams streams are tracked; when a new stream arrives at the limit, the entry that was used longest ago is
+// dropped (its buffers are freed after a device synchronise, so a capture in progress refuses instead: see callers).
+static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, bool capturing) {
+    auto it = c->orders.find(s);
+    if (it != c->orders.end()) { it->second.lastUse = ++c->orderClock; return &it->second; }
+    if (c->orders.size() >= rto_context::kMaxOrderStreams) {
+        if (capturing) return nullptr;                       // eviction frees memory: not inside a capture
+        auto victim = c->orders.begin();
+        for (auto jt = c->orders.begin(); jt != c->orders.end(); ++jt)
+            if (jt->second.lastUse < victim->second.lastUse) victim = jt;
+        (void)hipDeviceSynchronize();
+        (void)hipFree(victim->second.d_tileCost); (void)hipFree(victim->second.d_tileOrder);
+        (void)hipFree(victim->second.d_sortHist); (void)hipFree(victim->second.d_queue);
+        if (c->lastOrderStream == victim->first) c->lastOrderStream = nullptr;
+        c->orders.erase(victim);
+    }
+    rto_context::OrderState* st = &c->orders[s];
+    st->lastUse = ++c->orderClock;
+    return st;
+}
+
 template <int MODE>
 static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hipStream_t s) {
     const int tiles = P.tilesX * P.tilesY;
@@ -754,12 +823,16 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
     const bool packed = c->kernelMode >= RTO_KERNEL_PACKED || (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
     if (packed && !c->canonical) return fail(c, RTO_E_UNSUPPORTED, "render: packed kernel needs a canonical BFS octree");
+    const bool capturing = stream_is_capturing(s);
     bool stopRecorded = false;
     hipEvent_t evA = c->ev0, evB = c->ev1;
-    if (c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
-    const bool capturing = stream_is_capturing(s);
+    // a timing-ring slot is only taken by a launch that records events (events inside a capture cannot be timed)
+    if (!capturing && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
     if (!capturing) RTO_HIP(c, hipEventRecord(evA, s));
-    if (packed) {
+    // culling edge (S/RT:765-812): the root was culled but descendants survive.  The reference then starts at whatever
+    // node landed at compacted index 0; only the generic kernel over the compacted array can follow that literally.
+    const bool rootCulledEdge = c->culling && !c->rootVisible && c->visibleNodes > 0;
+    if (packed && !rootCulledEdge) {
         const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint2);
         if (c->kernelMode == RTO_KERNEL_PACKED_V1)
             hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
@@ -771,16 +844,14 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             bool recordCost = false;
             const bool useOrder = c->orderPolicy == RTO_ORDER_TEMPORAL && (MODE == kModeColor || MODE == kModeShade || MODE == kModeTimeline) &&
                                   (size_t)((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * sizeof(int) <= 96 * 1024;   // table must fit LDS
-            rto_context::OrderState* st = nullptr;      // this stream's scheduling state
-            {
-                auto it = c->orders.find(s);
-                if (it != c->orders.end()) st = &it->second;
-                else if (c->orders.size() < rto_context::kMaxOrderStreams) st = &c->orders[s];
-            }
+            rto_context::OrderState* st = order_state(c, s, capturing);      // this stream's scheduling state
             rto_context::OrderState* o = useOrder ? st : nullptr;
             if (o) {
                 c->lastOrderStream = s;
                 if (o->tiles != tiles) {
+                    if (capturing)
+                        return fail(c, RTO_E_UNSUPPORTED, "render: the first frame of a new size on a stream allocates its launch-order "
+                                                          "tables; render one such frame before hipStreamBeginCapture");
                     // hipFree waits for the device: no kernel still reads the old tables
                     (void)hipFree(o->d_tileCost); (void)hipFree(o->d_tileOrder); (void)hipFree(o->d_sortHist);
                     o->d_tileCost = o->d_tileOrder = o->d_sortHist = nullptr; o->tiles = 0;
@@ -804,19 +875,22 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             const bool persistent = c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT && st && (MODE == kModeColor || MODE == kModeShade);
             if (persistent) {
                 if (!st->d_queue) {
-                    RTO_HIP(c, hipMalloc(&st->d_queue, 2 * sizeof(int)));
-                    RTO_HIP(c, hipMemsetAsync(st->d_queue, 0, 2 * sizeof(int), s));
-                    st->queuePing = 0;
+                    if (capturing)
+                        return fail(c, RTO_E_UNSUPPORTED, "render: the first persistent-kernel frame on a stream allocates its slot counter; "
+                                                          "render one frame before hipStreamBeginCapture");
+                    RTO_HIP(c, hipMalloc(&st->d_queue, sizeof(int)));
                 }
+                // every launch zeroes its own counter (a memset node when captured): replaying a graph of any number of
+                // frames finds the same state each time
+                RTO_HIP(c, hipMemsetAsync(st->d_queue, 0, sizeof(int), s));
                 // enough workgroups to fill the machine at this kernel's occupancy; the rest of the slots come from the counter
-                const int resident = c->numCUs * RTO_PACKED3_WAVES;
-                int* qCur = st->d_queue + st->queuePing;
-                int* qNext = st->d_queue + (1 - st->queuePing);
-                st->queuePing = 1 - st->queuePing;
-                hipLaunchKernelGGL(k_trace_packed3_persistent<MODE>, dim3(std::min(blocks, resident)), dim3(kBlock), lds, s, Q, c->d_desc, d_out,
-                                   c->d_steps, c->d_counters, qCur, qNext);
-            } else {
+                const int resident = c->numCUs * RTO_LEAN_WAVES;
+                hipLaunchKernelGGL(k_trace_lean_persistent<MODE>, dim3(std::min(blocks, resident)), dim3(kBlock), lds, s, Q, c->d_desc, d_out,
+                                   c->d_steps, c->d_counters, st->d_queue);
+            } else if (c->kernelMode == RTO_KERNEL_PACKED_V3) {
                 hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+            } else {
+                hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             }
             if (!capturing) RTO_HIP(c, hipEventRecord(evB, s));       // the traversal kernel alone; the order kernel follows
             stopRecorded = true;
@@ -825,7 +899,8 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 const int nsb = (tiles + kSortBlock - 1) / kSortBlock;
                 int* cur = o->d_sortHist + (size_t)o->histPing * nsb * kCostBuckets;
                 int* nxt = o->d_sortHist + (size_t)(1 - o->histPing) * nsb * kCostBuckets;
-                hipLaunchKernelGGL(k_sort_scatter, dim3(nsb), dim3(kSortBlock), (size_t)nsb * kCostBuckets * sizeof(int), s, o->d_tileCost, tiles, cur, nsb, o->d_tileOrder, nxt);
+                hipLaunchKernelGGL(k_sort_scatter, dim3(nsb), dim3(kSortBlock), (size_t)nsb * kCostBuckets * sizeof(int), s, o->d_tileCost, tiles, cur, nsb, o->d_tileOrder, nxt,
+                                   c->d_sortViolations);
                 o->histPing = 1 - o->histPing;
                 o->valid = true;
                 o->age = 0;
@@ -869,7 +944,7 @@ int rto_render_device(rto_context* c, const rto_frame* f, const rto_partition* p
     if (!d_out) return fail(c, RTO_E_INVALID, "rto_render_device: d_out is NULL");
     RTO_HIP(c, hipSetDevice(c->device));
     RenderParams P;
-    int rc = fill_params(c, f, p, P);
+    int rc = fill_params(c, f, p, P, (hipStream_t)hip_stream);
     if (rc != RTO_OK) return rc;
     return launch_trace<kModeColor>(c, P, (float4*)d_out, (hipStream_t)hip_stream);
 }
@@ -879,7 +954,7 @@ int rto_render_shade_device(rto_context* c, const rto_frame* f, const rto_partit
     if (!d_shade) return fail(c, RTO_E_INVALID, "rto_render_shade_device: d_shade is NULL");
     RTO_HIP(c, hipSetDevice(c->device));
     RenderParams P;
-    int rc = fill_params(c, f, p, P);
+    int rc = fill_params(c, f, p, P, (hipStream_t)hip_stream);
     if (rc != RTO_OK) return rc;
     return launch_trace<kModeShade>(c, P, (float4*)d_shade, (hipStream_t)hip_stream);
 }
@@ -941,7 +1016,7 @@ int rto_render_batch_device(rto_context* c, const rto_frame* frames, int n, cons
         if (frames[i].width != frames[0].width || frames[i].height != frames[0].height)
             return fail(c, RTO_E_INVALID, "rto_render_batch_device: the frames of a batch share width and height");
         RenderParams P;
-        int rc = fill_params(c, &frames[i], p, P);
+        int rc = fill_params(c, &frames[i], p, P, (hipStream_t)hip_stream);
         if (rc != RTO_OK) return rc;
         float4* out = reinterpret_cast<float4*>(static_cast<char*>(d_out) + (size_t)i * frame_stride_bytes);
         rc = shade_payload ? launch_trace<kModeShade>(c, P, out, (hipStream_t)hip_stream) : launch_trace<kModeColor>(c, P, out, (hipStream_t)hip_stream);

@@ -732,31 +732,257 @@ __global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3(Ren
     trace_tile_packed3<MODE>(P, desc, out, stepsOut, counters, stk, lane, blockIdx.x * (kBlock / kWave) + wave);
 }
 
-// Persistent-threads form of the same kernel (RTO_KERNEL_PACKED_PERSISTENT): the grid only fills the machine, every
-// wave renders its first tile and then keeps taking the next launch slot from a global counter until none is left.
-// queueCur is this frame's counter; queueNext, the next frame's, is zeroed here (the host alternates the two).
+// ================================================================ packed kernel, lean loop body (the default)
+// k_trace_packed3 spends about as many VALU instructions on bookkeeping as on the 8 slab tests, and most of the
+// bookkeeping exists for ONE purpose: knowing `traversalSteps` (S/RT:254, :260) at every pop, so that the 512-pop cap
+// can end the loop.  This body does not count pops inside the loop at all.  It relies on two identities of the
+// reference's LIFO traversal (every visible child of an entered internal node is pushed, S/RT:313-318, and each of
+// them is popped exactly once unless the loop ends first):
+//
+//   (1) a ray that exhausts its stack has popped   T = 1 + S   nodes, S = sum of popcount(visible children) over the
+//       internal nodes it entered.  One v_bcnt_u32_b32 per loop trip accumulates S.
+//   (2) when a solid leaf is accepted, the pops so far are   1 + S - R , where R counts the pushed-but-unpopped
+//       nodes: for every node on the path from the root to the leaf's parent, its visible children BELOW the child
+//       the path took.  R is rebuilt ONCE per ray after the loop from the per-level LDS entries (<= depth reads), and
+//       only when it can matter: 1 + S <= 512 already proves the hit lies within the cap.
+//
+// A hit with 1 + S - R > 512 is a hit the reference never reaches (its loop stopped at 512 pops): the pixel is black
+// and the step count 512, exactly what S/RT:254 produces.  A ray is abandoned as soon as S >= 512 + 7*depth, because
+// R <= 7*depth makes every later hit fall beyond the cap.  Pixels, per-pixel step counts and frame counters are
+// therefore identical to k_trace_packed3's; the loop shrinks from ~180 to ~125 VALU instructions per trip:
+// no tail pre-sums, no belowPrev masks, no cap compare per pop, no "first solid hit" cut of the candidate mask
+// (children below a solid hit are never popped anyway: the hit ends the ray).
+//
+// LDS entry of level l: .x = pending children (8) | internal mask, unmasked (8) << 8 | visible mask (8) << 16, .y =
+// first-internal-child descriptor.  The entry is also written when a solid leaf is accepted, so that after the loop
+// the entries of levels 0..leaf level-1 all describe nodes of the hit path (their visible masks feed R).
+
+// Children that FAIL S/RT:269-274 (bit k set), fast form; see child_pass_mask_fast for the arithmetic.
+__device__ __forceinline__ unsigned child_fail_mask_fast(const RenderParams& P, const Ray& r, int cx, int cy, int cz, int half) {
+    const float vs = P.voxelSize;
+    const float fh = (float)half;
+    const float sv = fh * vs;
+    const float kEps = __uint_as_float(1u);
+    const float kBelow1e30 = __uint_as_float(0x7149f2c9u);
+    float tmn[3][2], tmx[3][2];
+    const int c[3] = { cx, cy, cz };
+    const float o[3] = { r.ox, r.oy, r.oz };
+    const float inv[3] = { r.ix, r.iy, r.iz };
+    const f32x2 addHalf = { 0.0f, fh };
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float fc = (float)c[a];
+        const f32x2 fcc = (f32x2){ fc, fc } + addHalf;
+        const f32x2 lo = (f32x2){ P.gridMin[a], P.gridMin[a] } + fcc * vs;
+        const f32x2 hi = lo + sv;
+        const f32x2 t1 = (lo - o[a]) * inv[a];
+        const f32x2 t2 = (hi - o[a]) * inv[a];
+        tmn[a][0] = __builtin_fminf(t1.x, t2.x); tmx[a][0] = __builtin_fmaxf(t1.x, t2.x);
+        tmn[a][1] = __builtin_fminf(t1.y, t2.y); tmx[a][1] = __builtin_fmaxf(t1.y, t2.y);
+    }
+    tmn[0][0] = __builtin_fmaxf(tmn[0][0], kEps); tmn[0][1] = __builtin_fmaxf(tmn[0][1], kEps);
+    tmx[0][0] = __builtin_fminf(tmx[0][0], kBelow1e30); tmx[0][1] = __builtin_fminf(tmx[0][1], kBelow1e30);
+#define RTO_D(k) __float_as_uint(min3f(tmx[0][(k) & 1], tmx[1][((k) >> 1) & 1], tmx[2][(k) >> 2]) - \
+                                 max3f(tmn[0][(k) & 1], tmn[1][((k) >> 1) & 1], tmn[2][(k) >> 2]))
+    unsigned fa = 0, fb = 0;
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(7), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(3), 31);
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(6), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(2), 31);
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(5), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(1), 31);
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(4), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(0), 31);
+#undef RTO_D
+    return (fa << 4) | fb;
+}
+
+// The same 8 verdicts with glm's NaN-faithful (y<x)?y:x min/max, one child at a time (waves that hold a ray with a
+// non-finite reciprocal direction -- axis-parallel rays -- are rare: small code and few registers matter here, not
+// speed).  Same float expressions as slab_exact on the child's box (S/RT:265-269).
+__device__ __forceinline__ unsigned child_fail_mask_exact(float gx, float gy, float gz, float vs, float ox, float oy, float oz,
+                                                       float ix, float iy, float iz, int cx, int cy, int cz, int half) {
+    const float sv = (float)half * vs;
+    unsigned fail = 0;
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        const float mnx = gx + (float)(cx + ((k & 1) ? half : 0)) * vs;
+        const float mny = gy + (float)(cy + ((k & 2) ? half : 0)) * vs;
+        const float mnz = gz + (float)(cz + ((k & 4) ? half : 0)) * vs;
+        const float t1x = (mnx - ox) * ix, t1y = (mny - oy) * iy, t1z = (mnz - oz) * iz;
+        const float t2x = ((mnx + sv) - ox) * ix, t2y = ((mny + sv) - oy) * iy, t2z = ((mnz + sv) - oz) * iz;
+        const float tn = gmax(gmax(gmin(t1x, t2x), gmin(t1y, t2y)), gmin(t1z, t2z));
+        const float tf = gmin(gmin(gmax(t1x, t2x), gmax(t1y, t2y)), gmax(t1z, t2z));
+        const bool ok = (tn <= tf) && (tf > 0.0f) && !(tn >= 1e30f);
+        fail |= ok ? 0u : (1u << k);
+    }
+    return fail;
+}
+
 template <int MODE>
-__global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3_persistent(RenderParams P, const uint2* __restrict__ desc,
+__device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uint2* __restrict__ desc, float4* __restrict__ out,
+                                                int* __restrict__ stepsOut, Counters* __restrict__ counters, uint2* stk,
+                                                const int lane, const int slot) {
+    unsigned long long tl0 = 0;
+    if (MODE == kModeTimeline) tl0 = wall_clock64();
+
+    int tile = slot;
+    int tx = 0, ty = P.tilesY;
+    if (slot < P.tilesX * P.tilesY) {
+        if (P.tileOrder) { tile = P.tileOrder[slot]; ty = tile / P.tilesX; tx = tile - ty * P.tilesX; }
+        else { tile_of(P, slot, tx, ty); tile = ty * P.tilesX + tx; }
+    }
+    const int px = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    const bool inImage = valid && (py < P.H);
+
+    bool hit = false;
+    int steps0 = 0;              // the root's own pop (S/RT:254-270 with nodeIdx 0)
+    Ray r;
+    bool alive = false;
+    const bool outsideRoot = px < P.rootX0 || px > P.rootX1 || py < P.rootY0 || py > P.rootY1;
+    if (inImage && P.rootVisible) {
+        steps0 = 1;
+        if (!outsideRoot) {
+            r = generate_ray_tab(P, px, py);
+            float tNear, tFar, a0, a1, a2, a3, a4, a5;
+            alive = slab_exact(P, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+        }
+    }
+    const bool risky = alive && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
+                                  __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
+    const bool anyRisky = __builtin_amdgcn_ballot_w64(risky) != 0ull;   // wave-uniform, fixed for the whole traversal
+
+    unsigned cur = 0;
+    int cx = 0, cy = 0, cz = 0;
+    int lvl = 0;
+    unsigned lvlPending = 0;
+    int S = 0;                                                          // identity (1): children pushed so far
+    const int capBound = kMaxTraversalSteps + 7 * P.depth;              // S >= capBound: every later hit lies beyond the cap
+    int trips = 0;                                                      // wave-uniform trip count = this tile's cost
+    while (alive) {
+        trips++;
+        const uint2 d = desc[cur];
+        // the resume entry depends only on lvlPending: fetch it under the descriptor load and the slab math
+        const int L = 31 - __builtin_clz(lvlPending | 1u);
+        const uint2 e = stk[L * kWave];
+        const int bpos = P.depth - 1 - lvl;                             // log2 of the children's edge
+        unsigned fail8;
+        if (anyRisky) fail8 = child_fail_mask_exact(P.gridMin[0], P.gridMin[1], P.gridMin[2], P.voxelSize, r.ox, r.oy, r.oz,
+                                                    r.ix, r.iy, r.iz, cx, cy, cz, 1 << bpos);
+        else fail8 = child_fail_mask_fast(P, r, cx, cy, cz, 1 << bpos);
+        const unsigned vm0 = __builtin_amdgcn_ubfe(d.x, 16, 8);
+        S += __builtin_popcount(vm0);
+        // children that do more than count a pop: visible internal ones and visible solid leaves that pass the slab test
+        const unsigned cand = (d.x | (d.x >> 8)) & vm0 & ~fail8;
+        const bool noWork = cand == 0;
+        const bool dead = (noWork && lvlPending == 0) || S >= capBound;
+        // merge with "resume at the deepest level that still has unpopped candidates"
+        const unsigned W = noWork ? e.x : ((d.x & 0x00ffff00u) | cand);
+        const unsigned base = noWork ? e.y : d.y;
+        const int lvl2 = noWork ? L : lvl;
+        const int bpos2 = P.depth - 1 - lvl2;
+        const int keep = (int)(0xfffffffeu << bpos2);
+        cx &= keep; cy &= keep; cz &= keep;                              // no-op for a freshly entered node
+        // pop its next candidate: the highest one (children pop 7..0)
+        const int j = 31 - __builtin_clz((W & 0xffu) | 1u);
+        const unsigned bitj = 1u << j;
+        const unsigned im = __builtin_amdgcn_ubfe(W, 8, 8);
+        const bool solid = (im & bitj) == 0;
+        hit = !dead && solid;                                            // S/RT:278-288 (cap applied after the loop)
+        const bool descend = !dead && !solid;
+        const unsigned Wn = W ^ bitj;
+        if (!dead) stk[lvl2 * kWave] = make_uint2(Wn, base);
+        const unsigned lb = 1u << lvl2;
+        lvlPending = (lvlPending & ~lb) | ((Wn & 0xffu) ? lb : 0u);
+        cur = base + (unsigned)__builtin_popcount(im & (bitj - 1u));
+        cx |= (j & 1) << bpos2; cy |= ((j >> 1) & 1) << bpos2; cz |= (j >> 2) << bpos2;   // the popped child (kept on a hit)
+        lvl = lvl2 + 1;
+        alive = descend;
+    }
+    if (P.tileCost && lane == 0 && ty < P.tilesY) {
+        P.tileCost[tile] = trips;
+        if (trips > 0) atomicAdd(&P.tileHist[(tile >> 10) * kCostBuckets + cost_bucket(trips)], 1);
+    }
+
+    // identity (2): pops at the accepted leaf.  Needed for every hit when steps are reported, else only when the
+    // upper bound 1 + S does not already clear the cap.
+    int steps = steps0 + S;
+    if (hit && (MODE == kModeSteps || steps > kMaxTraversalSteps)) {
+        int R = 0;
+        for (int l = 0; l < lvl; l++) {                                  // lvl = level of the leaf; its ancestors are levels 0..lvl-1
+            const unsigned w = stk[l * kWave].x;
+            const int b = P.depth - 1 - l;
+            const unsigned jl = ((cx >> b) & 1) | (((cy >> b) & 1) << 1) | (((cz >> b) & 1) << 2);
+            R += __builtin_popcount(__builtin_amdgcn_ubfe(w, 16, 8) & ((1u << jl) - 1u));
+        }
+        steps -= R;
+        if (steps > kMaxTraversalSteps) hit = false;                     // S/RT:254: the loop ended before this pop
+    }
+    if (steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
+
+    if (MODE == kModeShade) {
+        if (valid) __builtin_nontemporal_store(hit ? shade_term(P, r, cx, cy, cz, P.rootSize >> lvl) : kShadeMiss, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);
+    } else if (MODE == kModeColor || MODE == kModeTimeline) {
+        if (valid) {
+            float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+            if (hit) color = shade_hit(P, r, cx, cy, cz, P.rootSize >> lvl);
+            store_pixel(out + (size_t)ly * P.W + px, color);
+        }
+        if (MODE == kModeTimeline) {
+            const int act = __builtin_popcountll(__builtin_amdgcn_ballot_w64(steps0 + S > 1));
+            if (lane == 0 && ty < P.tilesY) {
+                const unsigned long long tl1 = wall_clock64();
+                unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+                unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+                int* rec = stepsOut + (size_t)tile * 8;
+                rec[0] = (int)(tl0 & 0xffffffffu); rec[1] = (int)(tl0 >> 32);
+                rec[2] = (int)(tl1 & 0xffffffffu); rec[3] = (int)(tl1 >> 32);
+                rec[4] = trips; rec[5] = (int)hwid; rec[6] = (int)xcc; rec[7] = act;
+            }
+        }
+    } else {
+        if (inImage) stepsOut[(size_t)py * P.W + px] = hit ? steps : -steps;
+        wave_accumulate(counters, steps, hit, inImage);
+    }
+}
+
+#ifndef RTO_LEAN_WAVES
+#define RTO_LEAN_WAVES 6
+#endif
+template <int MODE>
+__global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean(RenderParams P, const uint2* __restrict__ desc,
                                                            float4* __restrict__ out, int* __restrict__ stepsOut,
-                                                           Counters* __restrict__ counters, int* __restrict__ queueCur,
-                                                           int* __restrict__ queueNext) {
+                                                           Counters* __restrict__ counters) {
+    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;
+    trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, blockIdx.x * (kBlock / kWave) + wave);
+}
+
+// Persistent-threads form of the default kernel (RTO_KERNEL_PACKED_PERSISTENT): the grid only fills the machine, every
+// wave renders its first tile and then keeps taking launch slots from a global counter until none is left.  The host
+// zeroes the counter with a memset node in front of every launch, so each launch is self-contained (safe to capture
+// into a HIP graph and to replay any number of times).
+template <int MODE>
+__global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_persistent(RenderParams P, const uint2* __restrict__ desc,
+                                                           float4* __restrict__ out, int* __restrict__ stepsOut,
+                                                           Counters* __restrict__ counters, int* __restrict__ queue) {
     extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;
     const int tiles = P.tilesX * P.tilesY;
     const int firstFree = gridDim.x * (kBlock / kWave);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *queueNext = 0;
     int slot = blockIdx.x * (kBlock / kWave) + wave;
     int left = 1;                                              // slots of the current chunk still to render
-    while (slot < tiles) {                                     // wave-uniform
-        trace_tile_packed3<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
+    while (slot < tiles) {                                     // wave-uniform; ends once the counter has run past `tiles`
+        trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
         slot++;
         if (--left == 0) {
             // same-address atomics serialise (about 10 ns each): one per tile would cost 0.3 ms per 1080p frame,
             // so a wave takes kPersistChunk consecutive slots at a time
             int next = 0;
-            if (lane == 0) next = atomicAdd(queueCur, kPersistChunk);
+            if (lane == 0) next = atomicAdd(queue, kPersistChunk);
             slot = firstFree + __builtin_amdgcn_readfirstlane(next);
             left = kPersistChunk;
         }
@@ -785,7 +1011,8 @@ __device__ __forceinline__ void wave_bucket_add(int b, int lane, int* counters, 
 }
 
 __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const int* __restrict__ tileCost, int tiles, const int* __restrict__ blockHist,
-                                                              int numBlocks, int* __restrict__ order, int* __restrict__ nextHist) {
+                                                              int numBlocks, int* __restrict__ order, int* __restrict__ nextHist,
+                                                              int* __restrict__ violations) {
     extern __shared__ int tab[];                       // [numBlocks][kCostBuckets] copy of the histogram table
     __shared__ int base[kCostBuckets], fill[kCostBuckets], total[kCostBuckets];
     for (int i = threadIdx.x; i < numBlocks * kCostBuckets; i += kSortBlock) tab[i] = blockHist[i];
@@ -820,7 +1047,13 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const int* __restri
     const int bkt = i < tiles ? cost_bucket(tileCost[i]) : -1;
     int pos;
     wave_bucket_add(bkt, threadIdx.x & 63, fill, pos);
-    if (bkt >= 0) order[base[bkt] + pos] = i;
+    if (bkt >= 0) {
+        // base/fill come from histograms an earlier kernel accumulated: a table that does not match this frame's costs
+        // must not turn into a stray write (it did once).  Refused writes are counted; tests assert 0.
+        const int dst = base[bkt] + pos;
+        if (dst >= 0 && dst < tiles) order[dst] = i;
+        else atomicAdd(violations, 1);
+    }
 }
 
 // ================================================================ frustum culling (N3)

@@ -14,7 +14,7 @@ from . import _build
 
 RTO_OK = 0
 RTO_E_INVALID, RTO_E_NO_OCTREE, RTO_E_HIP, RTO_E_NO_DEVICE, RTO_E_UNSUPPORTED = -1, -2, -3, -4, -5
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED, KERNEL_PACKED_V1, KERNEL_PACKED_PERSISTENT = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED, KERNEL_PACKED_V1, KERNEL_PACKED_PERSISTENT, KERNEL_PACKED_V3 = 0, 1, 2, 3, 4, 5
 
 # struct GPUNodes (453-skeleton/RayTracerBVH.h:21-26)
 NODE_DTYPE = np.dtype(
@@ -25,12 +25,12 @@ NODE_DTYPE = np.dtype(
 # every symbol include/rto_hip.h declares
 SYMBOLS = (
     "rto_create", "rto_destroy", "rto_last_error", "rto_device_name",
-    "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel", "rto_set_launch_order",
-    "rto_update_frustum", "rto_download_visible_nodes",
+    "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel", "rto_set_launch_order", "rto_forget_stream",
+    "rto_update_frustum", "rto_debug_update_frustum_planes", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
     "rto_render_shade_device", "rto_assemble_shade_device", "rto_assemble_batch_device", "rto_render_batch_device", "rto_assemble_batch_all_device", "rto_render_resident", "rto_resident_frame", "rto_download_resident",
     "rto_upload_leaf_triangles", "rto_build_leaf_triangles", "rto_download_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
-    "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
+    "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_debug_sort_violations", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
 )
 
 
@@ -96,6 +96,9 @@ def load():
     L.rto_last_build_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rto_set_kernel.argtypes = [vp, C.c_int]
     L.rto_set_launch_order.argtypes = [vp, C.c_int, C.c_int]
+    L.rto_forget_stream.argtypes = [vp, vp]
+    L.rto_debug_update_frustum_planes.argtypes = [vp, C.POINTER(C.c_float), C.c_float]
+    L.rto_debug_sort_violations.argtypes = [vp, C.POINTER(C.c_int)]
     L.rto_update_frustum.argtypes = [vp, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int]
     L.rto_download_visible_nodes.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.rto_render_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp]
@@ -224,6 +227,20 @@ class Context:
         v = np.ascontiguousarray(np.asarray(view, dtype=np.float32).reshape(16))
         self._check(self._L.rto_update_frustum(self._h, v.ctypes.data_as(C.POINTER(C.c_float)),
                                                _f(fov_deg), _f(aspect), 1 if enable else 0))
+
+    def debug_update_frustum_planes(self, planes, margin: float):
+        """Developer aid: a frustum update with caller-supplied planes (6 x (nx, ny, nz, d), normalised) and margin."""
+        pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float32).reshape(24))
+        self._check(self._L.rto_debug_update_frustum_planes(self._h, pl.ctypes.data_as(C.POINTER(C.c_float)), _f(margin)))
+
+    def forget_stream(self, stream: int):
+        """Drop the launch-order tables kept for `stream` (call before destroying the stream)."""
+        self._check(self._L.rto_forget_stream(self._h, C.c_void_p(stream) if stream else None))
+
+    def debug_sort_violations(self) -> int:
+        n = C.c_int()
+        self._check(self._L.rto_debug_sort_violations(self._h, C.byref(n)))
+        return n.value
 
     def download_visible_nodes(self) -> np.ndarray:
         cnt = C.c_int64()

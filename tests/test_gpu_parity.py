@@ -18,8 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 TOL = 1e-4   # north-star tolerance; never reached: see assert_bit_exact
 
-KERNELS = [("packed", rto.KERNEL_PACKED), ("packed_persistent", rto.KERNEL_PACKED_PERSISTENT), ("packed_v1", rto.KERNEL_PACKED_V1),
-           ("generic", rto.KERNEL_GENERIC)]
+KERNELS = [("packed", rto.KERNEL_PACKED), ("packed_persistent", rto.KERNEL_PACKED_PERSISTENT), ("packed_v3", rto.KERNEL_PACKED_V3),
+           ("packed_v1", rto.KERNEL_PACKED_V1), ("generic", rto.KERNEL_GENERIC)]
 
 
 def oracle_frame(orc, s, view, pos, W, H, aspect=None, fov=45.0):
