@@ -181,7 +181,7 @@ def build_scene(args):
             grid = rto.VoxelGrid.from_array(data, gmin, voxel)
             cam = rto.Camera(0.6, 0.5, 4500.0)
             centre = gmin + 0.5 * np.array([tx, ty, tz], np.float32) * voxel
-            cam.setTarget(float(centre[0]), float(centre[1]), float(centre[2]))
+            cam.setTarget(centre)
             what = "sceneCache.bin resampled nearest-neighbour to 512x512x128 (SYNTHETIC stand-in for the grid BASELINE.json names)"
             camtxt = "Camera(0.6,0.5,4500) on the grid centre"
         else:
@@ -517,11 +517,11 @@ def main(argv=None):
             if n_orbit > 0:
                 # a camera that moves: theta advances 0.01 rad per frame, plain stream launches (no graph), the launch-order
                 # table is rebuilt after every --order-period-th frame from that frame's costs
-                th0, ph0, r0 = cam.theta, cam.phi, cam.radius
+                th0, ph0, r0, tg0 = float(cam.theta), float(cam.phi), float(cam.radius), cam.getTarget()
                 oframes = []
                 for i in range(n_orbit):
                     c2 = rto.Camera(th0 + 0.01 * i, ph0, r0)
-                    c2.setTarget(*cam.target)
+                    c2.setTarget(tg0)
                     oframes.append(rto.make_frame(c2.getView(), c2.getPos(), W / H, 45.0, W, H))
                 obuf = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
                 ctx.timing_begin(0)

@@ -113,10 +113,12 @@ int  rto_last_build_ms(const rto_context* ctx, float* kernels_ms, float* upload_
 int  rto_octree_info_get(const rto_context* ctx, rto_octree_info* out);
 int  rto_set_kernel(rto_context* ctx, int kernel /* RTO_KERNEL_* */);
 /* Launch order of the 8x8-pixel tiles in the packed kernel (a scheduling hint; pixels never depend on it).
- * The frame ends when its deepest rays end, so the waves that will run longest should start first.
+ * Only the tiles of the root box's screen rectangle get a wave; the frame ends when its deepest rays end, so the
+ * waves that will run longest should start first.
  * CENTRE_OUT: outwards from the projection of the solid geometry's centre.  TEMPORAL (default): by the per-tile
- * trip counts an earlier frame of the same size recorded (CENTRE_OUT until one exists); the table is rebuilt
- * every refresh_period-th frame (default 8; 0 keeps the current period) by one small kernel after that frame. */
+ * trip counts earlier frames of the same size recorded (CENTRE_OUT until one exists); the table is rebuilt by one
+ * small kernel in front of a frame whenever the rectangle's tile box moved and at least every refresh_period-th frame
+ * (default 8; 0 keeps the current period). */
 #define RTO_ORDER_CENTRE_OUT 0
 #define RTO_ORDER_TEMPORAL   1
 int  rto_set_launch_order(rto_context* ctx, int policy, int refresh_period);
@@ -237,7 +239,8 @@ int  rto_frame_stats(rto_context* ctx, const rto_frame* frame, rto_stats* out);
 int  rto_render_steps_host(rto_context* ctx, const rto_frame* frame, int32_t* host_steps);
 /* Developer aid: per-wave timeline of one frame of the packed kernel.  8 int32 per 8x8 tile (row-major
  * tiles): start lo/hi, end lo/hi (100 MHz wall clock), loop iterations, HW_ID, XCC_ID, lanes that entered
- * the tree.  host_records may be NULL to query *num_tiles. */
+ * the tree; all zero for tiles outside the root rectangle's tile box, which get no wave (their pixels are written
+ * by the waves of the box as wide stores).  host_records may be NULL to query *num_tiles. */
 int  rto_debug_timeline(rto_context* ctx, const rto_frame* frame, int32_t* host_records, int64_t capacity_tiles,
                         int64_t* num_tiles);
 /* Developer aids for the launch-order study: per-tile trip counts of the last frame, and a caller-supplied

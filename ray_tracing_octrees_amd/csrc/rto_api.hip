@@ -35,6 +35,7 @@ struct rto_context {
     float voxelSize = 1.f;
     int kernelMode = RTO_KERNEL_AUTO;
     float solidCentre[3] = { 0, 0, 0 };   // centre of the bounding box of the solid leaves, voxel units (launch-order heuristic)
+    int solidLo[3] = { 0, 0, 0 }, solidHi[3] = { 0, 0, 0 };   // that bounding box, voxel units; lo > hi: no solid leaf at all
 
     // frustum culling state
     bool culling = false;
@@ -56,14 +57,14 @@ struct rto_context {
     int orderPeriod = 8;            // rebuild the table every orderPeriod-th frame: cost maps change slowly (tools/order_period.py:
                                     // 8 or 16 beat 4 for a static, an orbiting and a fast-moving camera alike)
     struct OrderState {
-        int* d_tileCost = nullptr;
-        int* d_tileOrder = nullptr;
-        int* d_sortHist = nullptr;      // 2 x [sort blocks][kCostBuckets], ping-pong
-        int histPing = 0;
+        int* d_tileCost = nullptr;      // tile -> trip count of the last colour / shade frame that rendered it (row-major over all tiles)
+        int* d_tileOrder = nullptr;     // launch slot -> tile: a permutation of the tiles of `box`
         int tiles = 0;                  // tile count the buffers are sized for
-        long key[6] = { 0, 0, 0, 0, 0, 0 };   // W, H, numParts, part, bandRows, tiles of the frame the history belongs to
-        bool valid = false;
-        bool fixed = false;             // debug: the caller supplied the table, do not rebuild it
+        long key[6] = { 0, 0, 0, 0, 0, 0 };   // W, H, numParts, part, bandRows, tiles of the frames the history belongs to
+        bool costValid = false;         // a frame of this geometry has recorded its costs
+        bool valid = false;             // d_tileOrder holds a table for `box`
+        int box[4] = { 0, 0, 0, 0 };    // the tile box the table enumerates
+        bool fixed = false;             // debug: the caller supplied the table (over ALL tiles), do not rebuild it
         int age = 0;                    // frames rendered since the table was built
         int* d_queue = nullptr;         // persistent-threads variant: the slot counter (zeroed in front of every launch)
         unsigned long lastUse = 0;      // orderClock value of the last launch on this stream (eviction order)
@@ -134,7 +135,7 @@ static void free_octree(rto_context* c) {
     (void)hipFree(c->d_vox); c->d_vox = nullptr;
     c->voxDim[0] = c->voxDim[1] = c->voxDim[2] = 0;
     c->numTris = 0;
-    for (auto& kv : c->orders) kv.second.valid = false;
+    for (auto& kv : c->orders) { kv.second.valid = false; kv.second.costValid = false; }
     c->numNodes = c->numInternal = 0;
     c->canonical = false; c->culling = false; c->rootVisible = 1; c->visibleNodes = 0;
 }
@@ -180,6 +181,8 @@ int rto_create(int device_ordinal, rto_context** out) {
         rto_destroy(c);
         return fail(nullptr, RTO_E_HIP, msg);
     }
+    // the launch-order kernel stages one byte per tile of the box in LDS (up to 144 KB of the CU's 160 KB)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_order_build), hipFuncAttributeMaxDynamicSharedMemorySize, kOrderLdsTiles);
     *out = c;
     return RTO_OK;
 }
@@ -192,7 +195,7 @@ void rto_destroy(rto_context* c) {
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_rayX);
     (void)hipFree(c->d_rayY);
-    for (auto& kv : c->orders) { (void)hipFree(kv.second.d_tileCost); (void)hipFree(kv.second.d_tileOrder); (void)hipFree(kv.second.d_sortHist); (void)hipFree(kv.second.d_queue); }
+    for (auto& kv : c->orders) { (void)hipFree(kv.second.d_tileCost); (void)hipFree(kv.second.d_tileOrder); (void)hipFree(kv.second.d_queue); }
     c->orders.clear();
     (void)hipFree(c->d_mcCases);
     (void)hipFree(c->d_steps);
@@ -289,7 +292,10 @@ int rto_upload_octree(rto_context* c, const rto_node* nodes, int64_t n, const fl
                 if (mn[a] + nd.size > hi[a]) hi[a] = mn[a] + nd.size;
             }
         }
-        for (int a = 0; a < 3; a++) c->solidCentre[a] = lo[a] <= hi[a] ? 0.5f * (float)(lo[a] + hi[a]) : 0.5f * (float)nodes[0].size;
+        for (int a = 0; a < 3; a++) {
+            c->solidCentre[a] = lo[a] <= hi[a] ? 0.5f * (float)(lo[a] + hi[a]) : 0.5f * (float)nodes[0].size;
+            c->solidLo[a] = lo[a] <= hi[a] ? (int)lo[a] : 1; c->solidHi[a] = lo[a] <= hi[a] ? (int)hi[a] : 0;
+        }
     }
     std::vector<uint2> desc;
     std::vector<int> firstChild;
@@ -469,7 +475,10 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     int box[6];
     RTO_HIP(c, hipMemcpyAsync(box, d_bbox, sizeof box, hipMemcpyDeviceToHost, s));
     RTO_HIP(c, hipStreamSynchronize(s));
-    for (int a = 0; a < 3; a++) c->solidCentre[a] = box[a] <= box[3 + a] ? 0.5f * (float)(box[a] + box[3 + a]) : 0.5f * (float)(1 << R);
+    for (int a = 0; a < 3; a++) {
+        c->solidCentre[a] = box[a] <= box[3 + a] ? 0.5f * (float)(box[a] + box[3 + a]) : 0.5f * (float)(1 << R);
+        c->solidLo[a] = box[a] <= box[3 + a] ? box[a] : 1; c->solidHi[a] = box[a] <= box[3 + a] ? box[3 + a] : 0;
+    }
     RTO_HIP(c, hipEventElapsedTime(&c->buildUploadMs, e0, e1));
     RTO_HIP(c, hipEventElapsedTime(&c->buildMs, e1, e2));
 
@@ -517,10 +526,6 @@ int rto_debug_set_tile_order(rto_context* c, const int32_t* host_order, int64_t 
         if (it == c->orders.end()) return RTO_OK;
         rto_context::OrderState& o = it->second;
         o.fixed = false; o.valid = false;
-        if (o.d_sortHist) {
-            RTO_HIP(c, hipDeviceSynchronize());
-            RTO_HIP(c, hipMemset(o.d_sortHist, 0, (size_t)((o.tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * 2 * sizeof(int)));
-        }
         return RTO_OK;
     }
     if (it == c->orders.end() || n != it->second.tiles || !it->second.d_tileOrder)
@@ -539,7 +544,7 @@ int rto_set_launch_order(rto_context* c, int policy, int refresh_period) {
     if (refresh_period < 0) return fail(c, RTO_E_INVALID, "rto_set_launch_order: refresh_period must be >= 0 (0 keeps the current one)");
     c->orderPolicy = policy;
     if (refresh_period > 0) c->orderPeriod = refresh_period;
-    for (auto& kv : c->orders) { kv.second.valid = false; kv.second.age = 0; }
+    for (auto& kv : c->orders) { if (!kv.second.fixed) kv.second.valid = false; kv.second.age = 0; }
     return RTO_OK;
 }
 
@@ -549,7 +554,7 @@ int rto_forget_stream(rto_context* c, void* hip_stream) {
     if (it == c->orders.end()) return RTO_OK;
     RTO_HIP(c, hipSetDevice(c->device));
     RTO_HIP(c, hipDeviceSynchronize());          // no kernel still reads the tables
-    (void)hipFree(it->second.d_tileCost); (void)hipFree(it->second.d_tileOrder); (void)hipFree(it->second.d_sortHist); (void)hipFree(it->second.d_queue);
+    (void)hipFree(it->second.d_tileCost); (void)hipFree(it->second.d_tileOrder); (void)hipFree(it->second.d_queue);
     if (c->lastOrderStream == it->first) c->lastOrderStream = nullptr;
     c->orders.erase(it);
     return RTO_OK;
@@ -687,6 +692,98 @@ int rto_partition_rows(const rto_frame* f, const rto_partition* p) {
 
 static bool stream_is_capturing(hipStream_t s);
 
+// Conservative pixel rectangle (inclusive) of the world-space box [lo, hi]: rays through pixels outside it miss the box
+// for certain.  Valid only when all 8 corners are strictly in front of the eye (then the box projects onto the convex
+// hull of its projected corners); computed in double with a margin of 2 pixels plus the box's float rounding, far above
+// any float error of the per-pixel ray directions.  Otherwise: the whole image.  x0 > x1 or y0 > y1: nothing can hit.
+static void screen_rectangle(const rto_frame* f, const RenderParams& P, const double lo[3], const double hi[3], int out[4]) {
+    out[0] = 0; out[1] = 0; out[2] = P.W - 1; out[3] = P.H - 1;
+    const double tanH = (double)P.tanHalfFov, asp = (double)P.aspect;
+    double lox = 1e300, loy = 1e300, hix = -1e300, hiy = -1e300;
+    bool allInFront = tanH > 0.0 && asp > 0.0 && std::isfinite(hi[0] - lo[0]) && std::isfinite(hi[1] - lo[1]) && std::isfinite(hi[2] - lo[2]);
+    // the kernels build the boxes in float (gridMin + float(c) * voxel): widen by a few float ulps of the largest coordinate
+    double big = 0.0;
+    for (int a = 0; a < 3; a++) big = std::max(big, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+    const double pad = big * 4.0 * 1.1920929e-7;
+    for (int k = 0; k < 8 && allInFront; k++) {
+        const double wx = (k & 1) ? hi[0] + pad : lo[0] - pad, wy = (k & 2) ? hi[1] + pad : lo[1] - pad, wz = (k & 4) ? hi[2] + pad : lo[2] - pad;
+        const float* v = f->view;
+        const double vx = v[0] * wx + v[4] * wy + v[8] * wz + v[12], vy = v[1] * wx + v[5] * wy + v[9] * wz + v[13],
+                     vz = v[2] * wx + v[6] * wy + v[10] * wz + v[14];
+        if (!(vz < -1e-6 * (1.0 + std::fabs(vx) + std::fabs(vy)))) { allInFront = false; break; }
+        const double sx = ((vx / -vz) / (asp * tanH) * 0.5 + 0.5) * P.W, sy = (0.5 - (vy / -vz) / tanH * 0.5) * P.H;
+        if (!std::isfinite(sx) || !std::isfinite(sy)) { allInFront = false; break; }
+        lox = std::min(lox, sx); hix = std::max(hix, sx); loy = std::min(loy, sy); hiy = std::max(hiy, sy);
+    }
+    if (allInFront) {
+        const double x0 = std::floor(lox) - 2.0, x1 = std::ceil(hix) + 2.0, y0 = std::floor(loy) - 2.0, y1 = std::ceil(hiy) + 2.0;
+        out[0] = (int)std::max(0.0, std::min(x0, (double)P.W));        // may exceed W-1: then nothing can hit
+        out[2] = (int)std::max(-1.0, std::min(x1, (double)P.W - 1.0));
+        out[1] = (int)std::max(0.0, std::min(y0, (double)P.H));
+        out[3] = (int)std::max(-1.0, std::min(y1, (double)P.H - 1.0));
+    }
+}
+
+// Launch geometry "one wave per tile of the whole image, every wave stores all its pixels" (generic / V1 / triangle kernels,
+// instrumentation modes, caller-supplied orders).
+static void whole_image_box(RenderParams& P) {
+    P.boxX0 = 0; P.boxY0 = 0; P.boxW = P.tilesX; P.boxH = P.tilesY;
+    P.traceWaves = P.launchWaves = P.tilesX * P.tilesY;
+    P.skipOutside = 0; P.fillChunks = 0;
+    P.fillTopRows = 0; P.fillBotRow0 = P.localRows; P.fillLeftW = 0; P.fillRightX0 = P.W;
+    P.fillTopChunks = P.fillBotChunks = P.fillLeftPer = P.fillRightPer = 0;
+}
+
+// Launch geometry of the packed kernels' colour / shade frames: waves only for the tiles that can meet the root
+// rectangle, the region outside it shared out as 64-pixel chunks (RenderParams, rto_device.hip.h).
+static int local_row_of_first_global_at_least(const RenderParams& P, int gy) {
+    // local rows are ordered by their global row: count the local rows whose global row is < gy
+    if (gy <= 0) return 0;
+    if (P.numParts == 1) return std::min(gy, P.localRows);
+    int rows = 0;
+    const int bands = (P.H + P.bandRows - 1) / P.bandRows;
+    for (int b = P.part; b < bands; b += P.numParts) {
+        const int lo = b * P.bandRows, hi = std::min(lo + P.bandRows, P.H);
+        if (hi <= gy) rows += hi - lo;
+        else { if (lo < gy) rows += gy - lo; break; }
+    }
+    return std::min(rows, P.localRows);
+}
+
+static void root_rectangle_box(RenderParams& P, int minFillWaves) {
+    const bool nothing = !P.rootVisible || P.rootX0 > P.rootX1 || P.rootY0 > P.rootY1;   // no ray can meet the root box
+    int lyA, lyB, x0, x1;                       // rows [lyA, lyB) and columns [x0, x1] hold the rectangle's pixels
+    if (nothing) { lyA = lyB = P.localRows; x0 = 0; x1 = -1; }
+    else {
+        lyA = local_row_of_first_global_at_least(P, P.rootY0);
+        lyB = local_row_of_first_global_at_least(P, P.rootY1 + 1);
+        x0 = std::max(P.rootX0, 0); x1 = std::min(P.rootX1, P.W - 1);
+        if (lyA >= lyB || x0 > x1) { lyA = lyB = P.localRows; x0 = 0; x1 = -1; }
+    }
+    if (lyA >= lyB) { P.boxX0 = P.boxY0 = 0; P.boxW = P.boxH = 0; }
+    else {
+        // tile box, rounded outwards to multiples of 4 tiles: under a moving camera the box (and with it the launch-order
+        // table) then changes 4x less often; the extra tiles are waves without work
+        const int tx0 = (x0 / 8) & ~3, ty0 = (lyA / 8) & ~3;
+        const int tx1 = std::min(P.tilesX - 1, ((x1 / 8) | 3)), ty1 = std::min(P.tilesY - 1, (((lyB - 1) / 8) | 3));
+        P.boxX0 = tx0; P.boxY0 = ty0; P.boxW = tx1 - tx0 + 1; P.boxH = ty1 - ty0 + 1;
+    }
+    P.traceWaves = P.boxW * P.boxH;
+    P.skipOutside = 1;
+    P.fillTopRows = lyA; P.fillBotRow0 = lyB;
+    P.fillLeftW = x0; P.fillRightX0 = x1 + 1;
+    if (lyA >= lyB) { P.fillLeftW = 0; P.fillRightX0 = P.W; }           // no middle rows
+    const long topPix = (long)lyA * P.W, botPix = (long)(P.localRows - lyB) * P.W;
+    P.fillTopChunks = (int)((topPix + kWave - 1) / kWave);
+    P.fillBotChunks = (int)((botPix + kWave - 1) / kWave);
+    P.fillLeftPer = (P.fillLeftW + kWave - 1) / kWave;
+    P.fillRightPer = (P.W - P.fillRightX0 + kWave - 1) / kWave;
+    P.fillChunks = P.fillTopChunks + P.fillBotChunks + (lyB - lyA) * (P.fillLeftPer + P.fillRightPer);
+    // a tiny (or empty) box still needs enough waves to write the outside region at memory speed
+    P.launchWaves = std::max(P.traceWaves, std::min(P.fillChunks, minFillWaves));
+    if (P.launchWaves <= 0) P.launchWaves = 1;
+}
+
 // launch_stream: the stream the frame is about to be launched on (to refuse work a capture in progress cannot hold)
 static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* p, RenderParams& P, hipStream_t launch_stream = nullptr) {
     if (!f) return fail(c, RTO_E_INVALID, "render: frame is NULL");
@@ -737,33 +834,24 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
         c->rayW = P.W; c->rayH = P.H; c->rayAspect = P.aspect; c->rayTan = P.tanHalfFov;
     }
     P.rayX = c->d_rayX; P.rayY = c->d_rayY;
-    P.tileOrder = nullptr; P.tileCost = nullptr; P.tileHist = nullptr;
-    {   // Conservative pixel rectangle of the root box: rays through pixels outside it miss the root for certain.
-        // Valid only when all 8 corners are strictly in front of the eye (then the box projects onto the convex hull
-        // of its projected corners); computed in double with a 2-pixel margin, far above any float error of the
-        // per-pixel ray directions.  Otherwise: the whole image.
-        P.rootX0 = 0; P.rootY0 = 0; P.rootX1 = P.W - 1; P.rootY1 = P.H - 1;
+    P.tileOrder = nullptr; P.tileCost = nullptr;
+    {   // rays through pixels outside these rectangles miss the root box / every solid leaf for certain
+        int r[4];
         const double ext = (double)c->rootSize * (double)c->voxelSize;
-        const double tanH = (double)P.tanHalfFov, asp = (double)P.aspect;
-        double lox = 1e300, loy = 1e300, hix = -1e300, hiy = -1e300;
-        bool allInFront = tanH > 0.0 && asp > 0.0 && std::isfinite(ext);
-        for (int k = 0; k < 8 && allInFront; k++) {
-            const double wx = (double)c->gridMin[0] + ((k & 1) ? ext : 0.0), wy = (double)c->gridMin[1] + ((k & 2) ? ext : 0.0),
-                         wz = (double)c->gridMin[2] + ((k & 4) ? ext : 0.0);
-            const float* v = f->view;
-            const double vx = v[0] * wx + v[4] * wy + v[8] * wz + v[12], vy = v[1] * wx + v[5] * wy + v[9] * wz + v[13],
-                         vz = v[2] * wx + v[6] * wy + v[10] * wz + v[14];
-            if (!(vz < -1e-6 * (1.0 + std::fabs(vx) + std::fabs(vy)))) { allInFront = false; break; }
-            const double sx = ((vx / -vz) / (asp * tanH) * 0.5 + 0.5) * P.W, sy = (0.5 - (vy / -vz) / tanH * 0.5) * P.H;
-            if (!std::isfinite(sx) || !std::isfinite(sy)) { allInFront = false; break; }
-            lox = std::min(lox, sx); hix = std::max(hix, sx); loy = std::min(loy, sy); hiy = std::max(hiy, sy);
-        }
-        if (allInFront) {
-            const double x0 = std::floor(lox) - 2.0, x1 = std::ceil(hix) + 2.0, y0 = std::floor(loy) - 2.0, y1 = std::ceil(hiy) + 2.0;
-            P.rootX0 = (int)std::max(0.0, std::min(x0, (double)P.W));        // may exceed W-1: then nothing can hit
-            P.rootX1 = (int)std::max(-1.0, std::min(x1, (double)P.W - 1.0));
-            P.rootY0 = (int)std::max(0.0, std::min(y0, (double)P.H));
-            P.rootY1 = (int)std::max(-1.0, std::min(y1, (double)P.H - 1.0));
+        const double rlo[3] = { c->gridMin[0], c->gridMin[1], c->gridMin[2] };
+        const double rhi[3] = { rlo[0] + ext, rlo[1] + ext, rlo[2] + ext };
+        screen_rectangle(f, P, rlo, rhi, r);
+        P.rootX0 = r[0]; P.rootY0 = r[1]; P.rootX1 = r[2]; P.rootY1 = r[3];
+        if (c->solidLo[0] > c->solidHi[0]) { P.solidX0 = P.solidY0 = 0; P.solidX1 = P.solidY1 = -1; }     // nothing solid: nothing to hit
+        else {
+            double slo[3], shi[3];
+            for (int a = 0; a < 3; a++) {
+                slo[a] = (double)c->gridMin[a] + (double)c->solidLo[a] * (double)c->voxelSize;
+                shi[a] = (double)c->gridMin[a] + (double)c->solidHi[a] * (double)c->voxelSize;
+            }
+            screen_rectangle(f, P, slo, shi, r);
+            P.solidX0 = std::max(r[0], P.rootX0); P.solidY0 = std::max(r[1], P.rootY0);
+            P.solidX1 = std::min(r[2], P.rootX1); P.solidY1 = std::min(r[3], P.rootY1);
         }
     }
     {   // project the centre of the solid geometry; any value is valid, it only orders the launch
@@ -784,6 +872,7 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
         if (P.tilesX <= 0) P.orderCx = 0;
         if (P.tilesY <= 0) P.orderCy = 0;
     }
+    whole_image_box(P);
     return RTO_OK;
 }
 
@@ -807,7 +896,7 @@ static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, bool 
             if (jt->second.lastUse < victim->second.lastUse) victim = jt;
         (void)hipDeviceSynchronize();
         (void)hipFree(victim->second.d_tileCost); (void)hipFree(victim->second.d_tileOrder);
-        (void)hipFree(victim->second.d_sortHist); (void)hipFree(victim->second.d_queue);
+        (void)hipFree(victim->second.d_queue);
         if (c->lastOrderStream == victim->first) c->lastOrderStream = nullptr;
         c->orders.erase(victim);
     }
@@ -828,24 +917,23 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     hipEvent_t evA = c->ev0, evB = c->ev1;
     // a timing-ring slot is only taken by a launch that records events (events inside a capture cannot be timed)
     if (!capturing && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
-    if (!capturing) RTO_HIP(c, hipEventRecord(evA, s));
+    bool startRecorded = false;
     // culling edge (S/RT:765-812): the root was culled but descendants survive.  The reference then starts at whatever
     // node landed at compacted index 0; only the generic kernel over the compacted array can follow that literally.
     const bool rootCulledEdge = c->culling && !c->rootVisible && c->visibleNodes > 0;
     if (packed && !rootCulledEdge) {
-        const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint2);
-        if (c->kernelMode == RTO_KERNEL_PACKED_V1)
+        const size_t lds = (size_t)(kBlock / kWave) * (P.depth + 1) * kWave * sizeof(uint2);   // +1: the lean kernel's dummy entry
+        if (c->kernelMode == RTO_KERNEL_PACKED_V1) {
+            if (!capturing) RTO_HIP(c, hipEventRecord(evA, s));
+            startRecorded = true;
             hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
-        else {
-            // temporal launch order: this frame consumes the table built from the previous frame of the same geometry
+        } else {
             RenderParams Q = P;
-            Q.tileOrder = nullptr; Q.tileCost = nullptr; Q.tileHist = nullptr;
+            Q.tileOrder = nullptr; Q.tileCost = nullptr;
+            const bool frameMode = MODE == kModeColor || MODE == kModeShade;
             const long key[6] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles };
-            bool recordCost = false;
-            const bool useOrder = c->orderPolicy == RTO_ORDER_TEMPORAL && (MODE == kModeColor || MODE == kModeShade || MODE == kModeTimeline) &&
-                                  (size_t)((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * sizeof(int) <= 96 * 1024;   // table must fit LDS
             rto_context::OrderState* st = order_state(c, s, capturing);      // this stream's scheduling state
-            rto_context::OrderState* o = useOrder ? st : nullptr;
+            rto_context::OrderState* o = (c->orderPolicy == RTO_ORDER_TEMPORAL && (frameMode || MODE == kModeTimeline)) ? st : nullptr;
             if (o) {
                 c->lastOrderStream = s;
                 if (o->tiles != tiles) {
@@ -853,26 +941,44 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                         return fail(c, RTO_E_UNSUPPORTED, "render: the first frame of a new size on a stream allocates its launch-order "
                                                           "tables; render one such frame before hipStreamBeginCapture");
                     // hipFree waits for the device: no kernel still reads the old tables
-                    (void)hipFree(o->d_tileCost); (void)hipFree(o->d_tileOrder); (void)hipFree(o->d_sortHist);
-                    o->d_tileCost = o->d_tileOrder = o->d_sortHist = nullptr; o->tiles = 0;
+                    (void)hipFree(o->d_tileCost); (void)hipFree(o->d_tileOrder);
+                    o->d_tileCost = o->d_tileOrder = nullptr; o->tiles = 0;
                     RTO_HIP(c, hipMalloc(&o->d_tileCost, (size_t)tiles * sizeof(int)));
                     RTO_HIP(c, hipMalloc(&o->d_tileOrder, (size_t)tiles * sizeof(int)));
-                    const size_t histInts = (size_t)((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets * 2;   // ping-pong
-                    RTO_HIP(c, hipMalloc(&o->d_sortHist, histInts * sizeof(int)));
-                    RTO_HIP(c, hipMemsetAsync(o->d_sortHist, 0, histInts * sizeof(int), s));
-                    o->histPing = 0;
-                    o->tiles = tiles; o->valid = false; o->fixed = false;
+                    o->tiles = tiles; o->valid = false; o->costValid = false; o->fixed = false;
                 }
-                if (std::memcmp(key, o->key, sizeof key) != 0) { o->valid = false; o->fixed = false; std::memcpy(o->key, key, sizeof key); }
-                Q.tileOrder = o->valid ? o->d_tileOrder : nullptr;
-                // A stream that is being captured into a HIP graph gets a frozen schedule: a rebuild mutates device state
-                // (cost table, histograms, the table itself) that a replayed graph would not find as it was at capture.
-                // costs are recorded only by the frame whose epilogue is followed by a rebuild
-                recordCost = (MODE == kModeColor || MODE == kModeShade) && !o->fixed && !capturing && (!o->valid || o->age + 1 >= c->orderPeriod);
-                Q.tileCost = recordCost ? o->d_tileCost : nullptr;
-                Q.tileHist = o->d_sortHist + (size_t)o->histPing * ((tiles + kSortBlock - 1) / kSortBlock) * kCostBuckets;
+                if (std::memcmp(key, o->key, sizeof key) != 0) { o->valid = false; o->costValid = false; o->fixed = false; std::memcpy(o->key, key, sizeof key); }
             }
-            const bool persistent = c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT && st && (MODE == kModeColor || MODE == kModeShade);
+            // launch geometry: frames get waves for the root rectangle's tiles only and share the outside region out
+            // as wide stores; instrumentation modes and caller-supplied orders keep one wave per tile of the image
+            if ((frameMode || MODE == kModeTimeline) && !(o && o->fixed)) {
+                // a frame only needs the pixels that can meet a SOLID leaf: every other ray is black whatever it pops on the
+                // way (S/RT:363), so the rectangle of the solid leaves' bounding box replaces the root box's
+                Q.rootX0 = P.solidX0; Q.rootY0 = P.solidY0; Q.rootX1 = P.solidX1; Q.rootY1 = P.solidY1;
+                root_rectangle_box(Q, 8 * c->numCUs);
+            }
+            if (o) {
+                const int box[4] = { Q.boxX0, Q.boxY0, Q.boxW, Q.boxH };
+                // The table is a scheduling hint rebuilt from the costs the previous frames recorded: when the box moved
+                // (camera) or every orderPeriod-th frame.  k_order_build emits a permutation of the box's tiles whatever the
+                // cost array holds and keeps no state between calls, so rebuilding inside a stream capture is safe too.
+                if (!o->fixed && Q.traceWaves > 0 && (!o->valid || std::memcmp(box, o->box, sizeof box) != 0 || o->age >= c->orderPeriod)) {
+                    if (o->costValid) {
+                        const int staged = Q.traceWaves <= kOrderLdsTiles ? 1 : 0;
+                        hipLaunchKernelGGL(k_order_build, dim3(1), dim3(kOrderBlock), staged ? (size_t)((Q.traceWaves + 15) & ~15) : 0, s, o->d_tileCost, Q.tilesX,
+                                           Q.boxX0, Q.boxY0, Q.boxW, Q.boxH, staged, o->d_tileOrder, c->d_sortViolations);
+                        std::memcpy(o->box, box, sizeof box);
+                        o->valid = true; o->age = 0;
+                    } else o->valid = false;
+                }
+                Q.tileOrder = (o->valid && Q.traceWaves > 0) ? o->d_tileOrder : nullptr;
+                if (frameMode && !o->fixed) { Q.tileCost = o->d_tileCost; o->costValid = true; }
+                if (frameMode) o->age++;
+            }
+            const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
+            if (!capturing) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
+            startRecorded = true;
+            const bool persistent = c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT && st && frameMode;
             if (persistent) {
                 if (!st->d_queue) {
                     if (capturing)
@@ -885,25 +991,12 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 RTO_HIP(c, hipMemsetAsync(st->d_queue, 0, sizeof(int), s));
                 // enough workgroups to fill the machine at this kernel's occupancy; the rest of the slots come from the counter
                 const int resident = c->numCUs * RTO_LEAN_WAVES;
-                hipLaunchKernelGGL(k_trace_lean_persistent<MODE>, dim3(std::min(blocks, resident)), dim3(kBlock), lds, s, Q, c->d_desc, d_out,
+                hipLaunchKernelGGL(k_trace_lean_persistent<MODE>, dim3(std::min(lblocks, resident)), dim3(kBlock), lds, s, Q, c->d_desc, d_out,
                                    c->d_steps, c->d_counters, st->d_queue);
             } else if (c->kernelMode == RTO_KERNEL_PACKED_V3) {
-                hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+                hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(lblocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             } else {
-                hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
-            }
-            if (!capturing) RTO_HIP(c, hipEventRecord(evB, s));       // the traversal kernel alone; the order kernel follows
-            stopRecorded = true;
-            if (o && (MODE == kModeColor || MODE == kModeShade) && !recordCost) o->age++;
-            if (o && recordCost) {
-                const int nsb = (tiles + kSortBlock - 1) / kSortBlock;
-                int* cur = o->d_sortHist + (size_t)o->histPing * nsb * kCostBuckets;
-                int* nxt = o->d_sortHist + (size_t)(1 - o->histPing) * nsb * kCostBuckets;
-                hipLaunchKernelGGL(k_sort_scatter, dim3(nsb), dim3(kSortBlock), (size_t)nsb * kCostBuckets * sizeof(int), s, o->d_tileCost, tiles, cur, nsb, o->d_tileOrder, nxt,
-                                   c->d_sortViolations);
-                o->histPing = 1 - o->histPing;
-                o->valid = true;
-                o->age = 0;
+                hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(lblocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             }
         }
     } else {
@@ -911,9 +1004,12 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
         RenderParams Q = P;
         if (c->culling && c->visibleNodes == 0) Q.rootVisible = 0;   // empty SSBO: nothing to traverse
         else if (c->culling) Q.rootVisible = 1;                      // compacted index 0 is whatever survived first (S/RT:765-772)
+        if (!capturing) RTO_HIP(c, hipEventRecord(evA, s));
+        startRecorded = true;
         hipLaunchKernelGGL(k_trace_generic<MODE>, dim3(blocks), dim3(kBlock), 0, s, Q, nodes, d_out, c->d_steps, c->d_counters);
     }
     RTO_HIP(c, hipGetLastError());
+    (void)startRecorded;
     if (!stopRecorded && !capturing) RTO_HIP(c, hipEventRecord(evB, s));
     if (evA != c->ev0) { c->lastA = evA; c->lastB = evB; } else { c->lastA = c->ev0; c->lastB = c->ev1; }
     c->timed = !capturing;
@@ -1083,6 +1179,7 @@ int rto_debug_timeline(rto_context* c, const rto_frame* f, int32_t* host_records
     if ((rc = ensure_steps(c, (size_t)tiles * 8 > pixels ? (size_t)tiles * 8 : pixels)) != RTO_OK) return rc;
     const int saved = c->kernelMode;
     if (saved < RTO_KERNEL_PACKED) c->kernelMode = RTO_KERNEL_PACKED;
+    RTO_HIP(c, hipMemsetAsync(c->d_steps, 0, (size_t)tiles * 8 * sizeof(int), c->stream));   // tiles without a wave: all-zero records
     rc = launch_trace<kModeTimeline>(c, P, c->d_frame, c->stream);
     c->kernelMode = saved;
     if (rc != RTO_OK) return rc;

@@ -52,10 +52,6 @@ constexpr int kBlock = RTO_BLOCK;         // 4 waves, each owns one 8x8 pixel ti
 #define RTO_PERSIST_CHUNK 8       // launch slots a persistent wave takes per atomic (A/B builds: -DRTO_PERSIST_CHUNK=n)
 #endif
 constexpr int kMaxDepth = 20;             // log2(root size) supported by the packed kernel
-// temporal launch order: tiles are bucketed by their trip count; 1024 tiles per sort block
-constexpr int kSortBlock = 1024;
-constexpr int kCostBuckets = 16;          // bucket 0: trip count 0; bucket b>=1: trips in (4b-4, 4b], last one open-ended
-__device__ __forceinline__ int cost_bucket(int trips) { return trips <= 0 ? 0 : min((trips + 3) >> 2, kCostBuckets - 1); }
 
 struct RenderParams {
     float invView[16];     // glm::inverse(view), hoisted from S/RT:348 (pixel independent)
@@ -73,9 +69,23 @@ struct RenderParams {
     int rootVisible;                // 0 => frustum update culled the root: black frame
     int orderCx, orderCy;           // tile nearest the projected scene centre: tiles launch centre-out (heavy first)
     int rootX0, rootY0, rootX1, rootY1;   // pixel rectangle (inclusive, GLOBAL rows) outside of which no ray can meet the root box
-    const int* tileOrder;           // launch slot -> tile, costliest tiles of the PREVIOUS frame first (null: centre-out)
+    int solidX0, solidY0, solidX1, solidY1;   // the same for the bounding box of the solid leaves (host side: replaces root* for colour / shade frames)
+    const int* tileOrder;           // launch slot -> tile (row-major id over tilesX x tilesY): the tiles of the box below, costliest
+                                    // tiles of an EARLIER frame first (null: centre-out over the box)
     int* tileCost;                  // tile -> loop trip count of its wave in THIS frame (null: not recorded)
-    int* tileHist;                  // [tile / 1024][kCostBuckets] histogram of this frame's trip counts (zeroed beforehand)
+    // Launch geometry of the packed kernels.  Only tiles of the box [boxX0, boxX0+boxW) x [boxY0, boxY0+boxH) -- the tile
+    // bounding box of the root rectangle, rounded outwards -- get a wave (traceWaves = boxW*boxH).  With skipOutside
+    // the pixels OUTSIDE the root rectangle (black for certain, one pop) are not stored by their tile's wave: the
+    // outside region is cut into 64-pixel chunks of contiguous memory and wave `slot` stores the chunks
+    // slot, slot + launchWaves, ... after its own tile (1 KB per store instruction instead of 8 x 128 B, and no wave
+    // at all for the ~80 % of the tiles of a typical frame that lie wholly outside).
+    int boxX0, boxY0, boxW, boxH;
+    int traceWaves, launchWaves;
+    int skipOutside;
+    int fillChunks;                 // chunks of the outside region: top band, bottom band, then per middle row left + right strip
+    int fillTopRows, fillBotRow0;   // local rows [0, fillTopRows) and [fillBotRow0, localRows) lie wholly outside
+    int fillLeftW, fillRightX0;     // in the rows between: pixels [0, fillLeftW) and [fillRightX0, W)
+    int fillTopChunks, fillBotChunks, fillLeftPer, fillRightPer;
     const float* rayX;              // [W]  ((px+.5)/W*2-1)*aspect*tanHalfFov, the separable part of S/RT:341-346 (host-computed)
     const float* rayY;              // [H]  (1-(py+.5)/H*2)*tanHalfFov
 };
@@ -157,14 +167,25 @@ __device__ __forceinline__ Ray generate_ray_tab(const RenderParams& P, int px, i
     return r;
 }
 
+// The grid's origin and voxel size as four scalars.  Read straight from the kernel-argument struct, clang's vectoriser
+// merges the loads of gridMin[2] and voxelSize into <2 x float> pieces that overlap the gridMin array, SROA then cannot
+// split the by-value copy of RenderParams, and the four floats live in SCRATCH (a store at wave start, reloads at every
+// use: 13,800 waves x 64 lanes x 16 B of memory traffic per frame).  The empty asm keeps them four separate SGPR values.
+struct Geo { float gx, gy, gz, vs; };
+__device__ __forceinline__ Geo geo_of(const RenderParams& P) {
+    Geo g = { P.gridMin[0], P.gridMin[1], P.gridMin[2], P.voxelSize };
+    asm volatile("" : "+s"(g.gx), "+s"(g.gy), "+s"(g.gz), "+s"(g.vs));
+    return g;
+}
+
 // S/RT:226-236 intersectAABB + S/RT:265-266 node box, for one node given by integer coords.
-__device__ __forceinline__ bool slab_exact(const RenderParams& P, const Ray& r, int x, int y, int z, int size,
+__device__ __forceinline__ bool slab_exact(const Geo& G, const Ray& r, int x, int y, int z, int size,
                                            float& tNear, float& tFar,
                                            float& mnx, float& mny, float& mnz, float& mxx, float& mxy, float& mxz) {
-    float vs = P.voxelSize;
-    mnx = P.gridMin[0] + (float)x * vs;
-    mny = P.gridMin[1] + (float)y * vs;
-    mnz = P.gridMin[2] + (float)z * vs;
+    float vs = G.vs;
+    mnx = G.gx + (float)x * vs;
+    mny = G.gy + (float)y * vs;
+    mnz = G.gz + (float)z * vs;
     float ext = (float)size * vs;
     mxx = mnx + ext; mxy = mny + ext; mxz = mnz + ext;
     float t1x = (mnx - r.ox) * r.ix, t1y = (mny - r.oy) * r.iy, t1z = (mnz - r.oz) * r.iz;
@@ -175,15 +196,20 @@ __device__ __forceinline__ bool slab_exact(const RenderParams& P, const Ray& r, 
     tFar = gmin(gmin(tmaxx, tmaxy), tmaxz);
     return (tNear <= tFar && tFar > 0.0f);
 }
+__device__ __forceinline__ bool slab_exact(const RenderParams& P, const Ray& r, int x, int y, int z, int size,
+                                           float& tNear, float& tFar,
+                                           float& mnx, float& mny, float& mnz, float& mxx, float& mxy, float& mxz) {
+    return slab_exact(geo_of(P), r, x, y, z, size, tNear, tFar, mnx, mny, mnz, mxx, mxy, mxz);
+}
 
 // Hit epilogue: S/RT:279-285 (tHit, centre pseudo-normal) + S/RT:331-336 (Lambert).
 // Split in two so that the multi-GPU path can ship the 4-byte Lambert term instead of the 16-byte pixel:
 // shade_term() is everything up to max(dot(n, -L), 0); shade_color() is the final colour expression, evaluated
 // either in the traversal kernel (RGBA32F output) or in k_assemble_shade on the gathering GPU.  Same float
 // operations in the same order either way, so the pixel bits do not depend on where the second half runs.
-__device__ __forceinline__ float shade_term(const RenderParams& P, const Ray& r, int x, int y, int z, int size) {
+__device__ __forceinline__ float shade_term(const RenderParams& P, const Geo& G, const Ray& r, int x, int y, int z, int size) {
     float tNear, tFar, mnx, mny, mnz, mxx, mxy, mxz;
-    slab_exact(P, r, x, y, z, size, tNear, tFar, mnx, mny, mnz, mxx, mxy, mxz);
+    slab_exact(G, r, x, y, z, size, tNear, tFar, mnx, mny, mnz, mxx, mxy, mxz);
     float tHit = gmax(0.0f, tNear);
     float cx = 0.5f * (mnx + mxx), cy = 0.5f * (mny + mxy), cz = 0.5f * (mnz + mxz);
     float px = r.ox + r.dx * tHit, py = r.oy + r.dy * tHit, pz = r.oz + r.dz * tHit;
@@ -198,6 +224,10 @@ constexpr float kShadeMiss = -1.0f;   // shade-buffer code of a ray without a hi
 __device__ __forceinline__ float4 shade_color(float ndotl) {
     if (ndotl < 0.0f) return make_float4(0.f, 0.f, 0.f, 1.f);                             // S/RT:363 background
     return make_float4(1.0f * ndotl + 0.1f, 0.8f * ndotl + 0.1f, 0.6f * ndotl + 0.1f, 1.0f);
+}
+
+__device__ __forceinline__ float shade_term(const RenderParams& P, const Ray& r, int x, int y, int z, int size) {
+    return shade_term(P, geo_of(P), r, x, y, z, size);
 }
 
 __device__ __forceinline__ float4 shade_hit(const RenderParams& P, const Ray& r, int x, int y, int z, int size) {
@@ -485,9 +515,49 @@ __device__ __forceinline__ int unrank_centre_out(int k, int c, int n) {
 }
 
 __device__ __forceinline__ void tile_of(const RenderParams& P, int t, int& tx, int& ty) {
-    const int rowRank = t / P.tilesX, colRank = t - rowRank * P.tilesX;
-    ty = unrank_centre_out(rowRank, P.orderCy, P.tilesY);
-    tx = unrank_centre_out(colRank, P.orderCx, P.tilesX);
+    // t-th tile of the box, enumerated outwards from the tile nearest the projected scene centre
+    const int rowRank = t / P.boxW, colRank = t - rowRank * P.boxW;
+    ty = P.boxY0 + unrank_centre_out(rowRank, min(max(P.orderCy - P.boxY0, 0), P.boxH - 1), P.boxH);
+    tx = P.boxX0 + unrank_centre_out(colRank, min(max(P.orderCx - P.boxX0, 0), P.boxW - 1), P.boxW);
+}
+
+// Launch slot -> tile.  Slots >= traceWaves exist only to share the fill duty (tiny boxes): no tile.
+__device__ __forceinline__ bool resolve_slot(const RenderParams& P, int slot, int& tx, int& ty, int& tile) {
+    tx = 0; ty = P.tilesY; tile = 0;
+    if (slot >= P.traceWaves) return false;
+    if (P.tileOrder) { tile = P.tileOrder[slot]; ty = tile / P.tilesX; tx = tile - ty * P.tilesX; }
+    else { tile_of(P, slot, tx, ty); tile = ty * P.tilesX + tx; }
+    return true;
+}
+
+// The fill duty of launch slot `slot`: chunks slot, slot + launchWaves, ... of the region outside the root rectangle.
+// Every pixel there is black after the root's pop (S/RT:254-270, :363): (0,0,0,1), or kShadeMiss in the shade buffer.
+template <int MODE>
+__device__ __forceinline__ void fill_outside(const RenderParams& P, float4* __restrict__ out, int lane, int slot) {
+    if (!(MODE == kModeColor || MODE == kModeShade || MODE == kModeTimeline) || !P.skipOutside) return;
+    const int per = P.fillLeftPer + P.fillRightPer;
+    for (int c = slot; c < P.fillChunks; c += P.launchWaves) {            // wave-uniform
+        size_t pix;
+        bool ok;
+        if (c < P.fillTopChunks) {
+            const int p = c * kWave + lane;
+            ok = p < P.fillTopRows * P.W; pix = (size_t)p;
+        } else if (c < P.fillTopChunks + P.fillBotChunks) {
+            const int p = (c - P.fillTopChunks) * kWave + lane;
+            ok = p < (P.localRows - P.fillBotRow0) * P.W; pix = (size_t)P.fillBotRow0 * P.W + p;
+        } else {
+            const int m = c - P.fillTopChunks - P.fillBotChunks;
+            const int row = m / per, k = m - row * per;
+            int x;
+            if (k < P.fillLeftPer) { x = k * kWave + lane; ok = x < P.fillLeftW; }
+            else { x = P.fillRightX0 + (k - P.fillLeftPer) * kWave + lane; ok = x < P.W; }
+            pix = (size_t)(P.fillTopRows + row) * P.W + x;
+        }
+        if (ok) {
+            if (MODE == kModeShade) __builtin_nontemporal_store(kShadeMiss, reinterpret_cast<float*>(out) + pix);
+            else store_pixel(out + pix, make_float4(0.f, 0.f, 0.f, 1.f));
+        }
+    }
 }
 
 // hipcc does not fold fmax(fmax(a,b),c) into v_max3_f32 when a, b, c are themselves min/max results (it cannot
@@ -566,12 +636,8 @@ __device__ __forceinline__ void trace_tile_packed3(const RenderParams& P, const 
     // Launch order.  The frame ends when its deepest waves end, so they must start first.  With temporal order the
     // slot -> tile table lists the tiles by their trip count in the previous frame (a scheduling hint only: every
     // tile is rendered exactly once either way); without history, tiles go centre-out from the projected geometry.
-    int tile = slot;
-    int tx = 0, ty = P.tilesY;
-    if (slot < P.tilesX * P.tilesY) {
-        if (P.tileOrder) { tile = P.tileOrder[slot]; ty = tile / P.tilesX; tx = tile - ty * P.tilesX; }
-        else { tile_of(P, slot, tx, ty); tile = ty * P.tilesX + tx; }
-    }
+    int tile, tx, ty;
+    resolve_slot(P, slot, tx, ty, tile);
     const int px = tx * 8 + (lane & 7);
     const int ly = ty * 8 + (lane >> 3);
     const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
@@ -684,20 +750,19 @@ __device__ __forceinline__ void trace_tile_packed3(const RenderParams& P, const 
         RTO_T(3);                                   // [C] pop, stack write, next node
     }
     if (!hit && steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
-    if (P.tileCost && lane == 0 && ty < P.tilesY) {
-        P.tileCost[tile] = trips;
-        // zero-cost tiles (most of a typical frame) are not counted: their number follows from the block size
-        if (trips > 0) atomicAdd(&P.tileHist[(tile >> 10) * kCostBuckets + cost_bucket(trips)], 1);
-    }
+    if (P.tileCost && lane == 0 && ty < P.tilesY) P.tileCost[tile] = trips;
 
+    const bool mine = valid && !(P.skipOutside && outsideRoot);     // pixels outside the root rectangle belong to the fill duty
     if (MODE == kModeShade) {
-        if (valid) __builtin_nontemporal_store(hit ? shade_term(P, r, cx, cy, cz, P.rootSize >> lvl) : kShadeMiss, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);
+        if (mine) __builtin_nontemporal_store(hit ? shade_term(P, r, cx, cy, cz, P.rootSize >> lvl) : kShadeMiss, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);
+        fill_outside<MODE>(P, out, lane, slot);
     } else if (MODE == kModeColor || MODE == kModeTimeline) {
-        if (valid) {
+        if (mine) {
             float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
             if (hit) color = shade_hit(P, r, cx, cy, cz, P.rootSize >> lvl);
             store_pixel(out + (size_t)ly * P.W + px, color);
         }
+        fill_outside<MODE>(P, out, lane, slot);
         if (MODE == kModeTimeline) {
             int it = tlIters;
             for (int off = 32; off > 0; off >>= 1) it = max(it, __shfl_down(it, off));
@@ -729,7 +794,9 @@ __global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3(Ren
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;
-    trace_tile_packed3<MODE>(P, desc, out, stepsOut, counters, stk, lane, blockIdx.x * (kBlock / kWave) + wave);
+    const int slot = blockIdx.x * (kBlock / kWave) + wave;
+    if (slot >= P.launchWaves) return;
+    trace_tile_packed3<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
 }
 
 // ================================================================ packed kernel, lean loop body (the default)
@@ -753,42 +820,64 @@ __global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3(Ren
 // no tail pre-sums, no belowPrev masks, no cap compare per pop, no "first solid hit" cut of the candidate mask
 // (children below a solid hit are never popped anyway: the hit ends the ray).
 //
-// LDS entry of level l: .x = pending children (8) | internal mask, unmasked (8) << 8 | visible mask (8) << 16, .y =
-// first-internal-child descriptor.  The entry is also written when a solid leaf is accepted, so that after the loop
-// the entries of levels 0..leaf level-1 all describe nodes of the hit path (their visible masks feed R).
+// LDS entry of a node whose children have edge 2^b (entry b, b = depth-1-level): .x = pending children (8) | internal
+// mask, unmasked (8) << 8 | visible mask (8) << 16, .y = first-internal-child descriptor.  The entry is written on
+// every pop -- also when a solid leaf is accepted -- so that after the loop the entries of the leaf's ancestors all
+// describe nodes of the hit path (their visible masks feed R).
 
-// Children that FAIL S/RT:269-274 (bit k set), fast form; see child_pass_mask_fast for the arithmetic.
-__device__ __forceinline__ unsigned child_fail_mask_fast(const RenderParams& P, const Ray& r, int cx, int cy, int cz, int half) {
-    const float vs = P.voxelSize;
-    const float fh = (float)half;
-    const float sv = fh * vs;
-    const float kEps = __uint_as_float(1u);
-    const float kBelow1e30 = __uint_as_float(0x7149f2c9u);
-    float tmn[3][2], tmx[3][2];
-    const int c[3] = { cx, cy, cz };
-    const float o[3] = { r.ox, r.oy, r.oz };
-    const float inv[3] = { r.ix, r.iy, r.iz };
-    const f32x2 addHalf = { 0.0f, fh };
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        const float fc = (float)c[a];
-        const f32x2 fcc = (f32x2){ fc, fc } + addHalf;
-        const f32x2 lo = (f32x2){ P.gridMin[a], P.gridMin[a] } + fcc * vs;
-        const f32x2 hi = lo + sv;
-        const f32x2 t1 = (lo - o[a]) * inv[a];
-        const f32x2 t2 = (hi - o[a]) * inv[a];
-        tmn[a][0] = __builtin_fminf(t1.x, t2.x); tmx[a][0] = __builtin_fmaxf(t1.x, t2.x);
-        tmn[a][1] = __builtin_fminf(t1.y, t2.y); tmx[a][1] = __builtin_fmaxf(t1.y, t2.y);
-    }
-    tmn[0][0] = __builtin_fmaxf(tmn[0][0], kEps); tmn[0][1] = __builtin_fmaxf(tmn[0][1], kEps);
-    tmx[0][0] = __builtin_fminf(tmx[0][0], kBelow1e30); tmx[0][1] = __builtin_fminf(tmx[0][1], kBelow1e30);
-#define RTO_D(k) __float_as_uint(min3f(tmx[0][(k) & 1], tmx[1][((k) >> 1) & 1], tmx[2][(k) >> 2]) - \
-                                 max3f(tmn[0][(k) & 1], tmn[1][((k) >> 1) & 1], tmn[2][(k) >> 2]))
+// 3-input bitwise op, full issue rate on gfx950 (v_bitop3_b32; v_and_or / v_lshl_or / v_bfi / v_cndmask issue at half rate,
+// tools/ubench/valu_rate2.hip).  TT = truth table, bit (a<<2 | b<<1 | c).
+template <int TT> __device__ __forceinline__ unsigned bop3(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, TT); }
+constexpr int kSelC = 0xD8;       // c ? b : a      (c is an all-ones / all-zeros lane mask)
+constexpr int kAndOr = 0xEA;      // (a & b) | c
+constexpr int kOrAnd = 0xF8;      // a | (b & c)
+constexpr int kAndAndNot = 0x40;  // a & b & ~c
+constexpr int kReplace = 0x74;    // (a & ~b) | (b & ~c)
+
+// Children that FAIL S/RT:269-274 (bit k set), fast form (no NaN can occur: see `risky`); arithmetic of
+// child_pass_mask_fast with one change: min(t1,t2) / max(t1,t2) of an axis are SELECTED by the sign of the ray's
+// reciprocal direction instead of computed.  hi >= lo (hi = lo + sv, sv > 0) and float subtraction / multiplication by a
+// finite non-zero factor are monotonic, so t1 <= t2 exactly when inv > 0: the select returns the same value as
+// v_min / v_max up to the sign of a zero, which no later operation observes -- at full rate (v_bitop3) instead of half
+// rate (v_min_f32 / v_max_f32).  sgn[a] = all ones when inv[a] < 0.
+// one axis of child_fail_mask_fast: entry / exit parameters of the low (0) and high (1) child halves
+__device__ __forceinline__ void child_axis_terms(float g, float o, float inv, unsigned sgn, int c, float fh, float vs, float sv,
+                                                 float& n0, float& n1, float& f0, float& f1) {
+    const float fc = (float)c;
+    const f32x2 fcc = (f32x2){ fc, fc } + (f32x2){ 0.0f, fh };       // (fc, fc + fh): both exact (integers < 2^24; fc + 0 == fc)
+    const f32x2 lo = (f32x2){ g, g } + fcc * vs;                      // nodeMin of the low / high children
+    const f32x2 hi = lo + sv;                                         // their nodeMax
+    const f32x2 t1 = (lo - o) * inv;
+    const f32x2 t2 = (hi - o) * inv;
+    const unsigned a1x = __float_as_uint(t1.x), a2x = __float_as_uint(t2.x), a1y = __float_as_uint(t1.y), a2y = __float_as_uint(t2.y);
+    n0 = __uint_as_float(bop3<kSelC>(a1x, a2x, sgn)); f0 = __uint_as_float(bop3<kSelC>(a2x, a1x, sgn));
+    n1 = __uint_as_float(bop3<kSelC>(a1y, a2y, sgn)); f1 = __uint_as_float(bop3<kSelC>(a2y, a1y, sgn));
+}
+
+__device__ __forceinline__ unsigned child_fail_mask_fast(float gx, float gy, float gz, float vs, float ox, float oy, float oz,
+                                                         float ix, float iy, float iz, unsigned sx, unsigned sy, unsigned sz,
+                                                         int cx, int cy, int cz, float fh) {
+    const float sv = fh * vs;                                  // vec3(node.size) * voxelSize
+    const float kEps = __uint_as_float(1u);                   // smallest positive float: tFar > 0  <=>  tFar >= kEps
+    const float kBelow1e30 = __uint_as_float(0x7149f2c9u);    // largest float < 1e30f:  tNear < 1e30 <=> tNear <= this
+    float nx0, nx1, fx0, fx1, ny0, ny1, fy0, fy1, nz0, nz1, fz0, fz1;
+    child_axis_terms(gx, ox, ix, sx, cx, fh, vs, sv, nx0, nx1, fx0, fx1);
+    child_axis_terms(gy, oy, iy, sy, cy, fh, vs, sv, ny0, ny1, fy0, fy1);
+    child_axis_terms(gz, oz, iz, sz, cz, fh, vs, sv, nz0, nz1, fz0, fz1);
+    // fold "tFar > 0" and "tNear < 1e30" into the x terms (spelled as instructions: behind a bitwise select the compiler
+    // would first canonicalise the operand with an extra v_max_f32 x, x)
+    asm("v_max_f32 %0, %1, %2" : "=v"(nx0) : "v"(nx0), "v"(kEps));
+    asm("v_max_f32 %0, %1, %2" : "=v"(nx1) : "v"(nx1), "v"(kEps));
+    asm("v_min_f32 %0, %1, %2" : "=v"(fx0) : "v"(fx0), "v"(kBelow1e30));
+    asm("v_min_f32 %0, %1, %2" : "=v"(fx1) : "v"(fx1), "v"(kBelow1e30));
+    // verdict of child k = sign bit of (min3 - max3): no NaN can occur here, and a float difference carries the
+    // exact sign of the comparison (x - x is +0).  v_alignbit shifts the sign into an accumulator: two 4-deep chains.
+#define RTO_D(kx, ky, kz) __float_as_uint(min3f(fx##kx, fy##ky, fz##kz) - max3f(nx##kx, ny##ky, nz##kz))
     unsigned fa = 0, fb = 0;
-    fa = __builtin_amdgcn_alignbit(fa, RTO_D(7), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(3), 31);
-    fa = __builtin_amdgcn_alignbit(fa, RTO_D(6), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(2), 31);
-    fa = __builtin_amdgcn_alignbit(fa, RTO_D(5), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(1), 31);
-    fa = __builtin_amdgcn_alignbit(fa, RTO_D(4), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(0), 31);
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(1, 1, 1), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(1, 1, 0), 31);
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(0, 1, 1), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(0, 1, 0), 31);
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(1, 0, 1), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(1, 0, 0), 31);
+    fa = __builtin_amdgcn_alignbit(fa, RTO_D(0, 0, 1), 31); fb = __builtin_amdgcn_alignbit(fb, RTO_D(0, 0, 0), 31);
 #undef RTO_D
     return (fa << 4) | fb;
 }
@@ -822,18 +911,15 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     unsigned long long tl0 = 0;
     if (MODE == kModeTimeline) tl0 = wall_clock64();
 
-    int tile = slot;
-    int tx = 0, ty = P.tilesY;
-    if (slot < P.tilesX * P.tilesY) {
-        if (P.tileOrder) { tile = P.tileOrder[slot]; ty = tile / P.tilesX; tx = tile - ty * P.tilesX; }
-        else { tile_of(P, slot, tx, ty); tile = ty * P.tilesX + tx; }
-    }
+    int tile, tx, ty;
+    resolve_slot(P, slot, tx, ty, tile);
     const int px = tx * 8 + (lane & 7);
     const int ly = ty * 8 + (lane >> 3);
     const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
     const int py = global_row(P, ly);
     const bool inImage = valid && (py < P.H);
 
+    const Geo G = geo_of(P);
     bool hit = false;
     int steps0 = 0;              // the root's own pop (S/RT:254-270 with nodeIdx 0)
     Ray r;
@@ -844,73 +930,88 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
         if (!outsideRoot) {
             r = generate_ray_tab(P, px, py);
             float tNear, tFar, a0, a1, a2, a3, a4, a5;
-            alive = slab_exact(P, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+            alive = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
         }
     }
     const bool risky = alive && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
                                   __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
     const bool anyRisky = __builtin_amdgcn_ballot_w64(risky) != 0ull;   // wave-uniform, fixed for the whole traversal
 
+    // The loop is written for gfx950's VALU issue costs (tools/ubench/valu_rate2.hip, valu_rate3.hip: add / sub / mul f32,
+    // add / sub u32, and / or / xor, shifts by an immediate and v_bitop3 issue every 2 cycles per SIMD; min / max, cvt,
+    // cmp, cndmask, bfe, variable shifts, bcnt, ffbh and every other 3-operand form every 4): lane classes are merged
+    // with bitwise selects on all-ones masks instead of v_cmp + v_cndmask, levels are indexed by the child-edge exponent
+    // b = depth-1-level (what the arithmetic needs) and the stack write is unconditional (a lane owns its LDS column;
+    // a finished lane's column is never read again except by its own identity-(2) walk, which a hit keeps valid).
     unsigned cur = 0;
     int cx = 0, cy = 0, cz = 0;
-    int lvl = 0;
-    unsigned lvlPending = 0;
+    int bpos = P.depth - 1;                                             // log2 of the edge of the current node's children
+    unsigned lvlPending = 0;                                            // bit b: the entry of exponent b still has unpopped candidates
+    const unsigned sentinel = 1u << P.depth;                            // entry `depth` is a dummy: what "nothing pending" reads
     int S = 0;                                                          // identity (1): children pushed so far
     const int capBound = kMaxTraversalSteps + 7 * P.depth;              // S >= capBound: every later hit lies beyond the cap
+    const unsigned sgnX = (unsigned)((int)__float_as_uint(r.ix) >> 31), sgnY = (unsigned)((int)__float_as_uint(r.iy) >> 31),
+                   sgnZ = (unsigned)((int)__float_as_uint(r.iz) >> 31);          // all ones: the reciprocal direction is negative
+    const char* descBytes = reinterpret_cast<const char*>(desc);
     int trips = 0;                                                      // wave-uniform trip count = this tile's cost
     while (alive) {
         trips++;
-        const uint2 d = desc[cur];
+#if defined(RTO_PRIO)
+        // A/B build: waves still running after many trips are the frame's critical path: let them win VALU arbitration
+        if (trips == RTO_PRIO) __builtin_amdgcn_s_setprio(1);
+        else if (trips == 2 * RTO_PRIO) __builtin_amdgcn_s_setprio(2);
+        else if (trips == 3 * RTO_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
+        const uint2 d = *reinterpret_cast<const uint2*>(descBytes + (cur << 3));
         // the resume entry depends only on lvlPending: fetch it under the descriptor load and the slab math
-        const int L = 31 - __builtin_clz(lvlPending | 1u);
-        const uint2 e = stk[L * kWave];
-        const int bpos = P.depth - 1 - lvl;                             // log2 of the children's edge
+        const int Lb = __builtin_ctz(lvlPending | sentinel);
+        const uint2 e = stk[Lb * kWave];
+        const float fh = __uint_as_float((unsigned)(bpos + 127) << 23);        // (float)(1 << bpos), exact
         unsigned fail8;
-        if (anyRisky) fail8 = child_fail_mask_exact(P.gridMin[0], P.gridMin[1], P.gridMin[2], P.voxelSize, r.ox, r.oy, r.oz,
+        if (anyRisky) fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz,
                                                     r.ix, r.iy, r.iz, cx, cy, cz, 1 << bpos);
-        else fail8 = child_fail_mask_fast(P, r, cx, cy, cz, 1 << bpos);
-        const unsigned vm0 = __builtin_amdgcn_ubfe(d.x, 16, 8);
+        else fail8 = child_fail_mask_fast(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                          sgnX, sgnY, sgnZ, cx, cy, cz, fh);
+        const unsigned vm0 = (d.x >> 16) & 0xffu;
         S += __builtin_popcount(vm0);
         // children that do more than count a pop: visible internal ones and visible solid leaves that pass the slab test
-        const unsigned cand = (d.x | (d.x >> 8)) & vm0 & ~fail8;
-        const bool noWork = cand == 0;
-        const bool dead = (noWork && lvlPending == 0) || S >= capBound;
-        // merge with "resume at the deepest level that still has unpopped candidates"
-        const unsigned W = noWork ? e.x : ((d.x & 0x00ffff00u) | cand);
-        const unsigned base = noWork ? e.y : d.y;
-        const int lvl2 = noWork ? L : lvl;
-        const int bpos2 = P.depth - 1 - lvl2;
-        const int keep = (int)(0xfffffffeu << bpos2);
-        cx &= keep; cy &= keep; cz &= keep;                              // no-op for a freshly entered node
+        const unsigned cand = bop3<kAndAndNot>(d.x | (d.x >> 8), vm0, fail8);
+        const unsigned noWork = (unsigned)(((int)cand - 1) >> 31);       // all ones: nothing to pop here
+        const bool dead = (cand | lvlPending) == 0 || S >= capBound;
+        // merge with "resume at the entry of the smallest exponent (= deepest level) that still has candidates"
+        const unsigned W = bop3<kSelC>(bop3<kAndOr>(d.x, 0x00ffff00u, cand), e.x, noWork);
+        const unsigned base = bop3<kSelC>(d.y, e.y, noWork);
+        const int bpos2 = (int)bop3<kSelC>((unsigned)bpos, (unsigned)Lb, noWork);
         // pop its next candidate: the highest one (children pop 7..0)
-        const int j = 31 - __builtin_clz((W & 0xffu) | 1u);
+        const int j = 31 - __builtin_clz(W & 0xffu);                     // W & 0xff != 0 unless the lane is dead
         const unsigned bitj = 1u << j;
-        const unsigned im = __builtin_amdgcn_ubfe(W, 8, 8);
-        const bool solid = (im & bitj) == 0;
+        const unsigned imv = W >> 8;                                     // bits 0..7: internal mask (unmasked); above: visible mask
+        const bool solid = (imv & bitj) == 0;
         hit = !dead && solid;                                            // S/RT:278-288 (cap applied after the loop)
-        const bool descend = !dead && !solid;
         const unsigned Wn = W ^ bitj;
-        if (!dead) stk[lvl2 * kWave] = make_uint2(Wn, base);
-        const unsigned lb = 1u << lvl2;
-        lvlPending = (lvlPending & ~lb) | ((Wn & 0xffu) ? lb : 0u);
-        cur = base + (unsigned)__builtin_popcount(im & (bitj - 1u));
-        cx |= (j & 1) << bpos2; cy |= ((j >> 1) & 1) << bpos2; cz |= (j >> 2) << bpos2;   // the popped child (kept on a hit)
-        lvl = lvl2 + 1;
-        alive = descend;
+        stk[bpos2 * kWave] = make_uint2(Wn, base);
+        const unsigned hl = 1u << bpos2;
+        const unsigned noneLeft = (unsigned)(((int)(Wn & 0xffu) - 1) >> 31);
+        lvlPending = bop3<kReplace>(lvlPending, hl, noneLeft);           // set the bit iff candidates are left at this level
+        cur = base + (unsigned)__builtin_popcount(imv & (bitj - 1u));
+        const unsigned keep = 0u - (hl + hl);
+        const unsigned sj = (unsigned)j << bpos2;
+        cx = (int)bop3<kOrAnd>((unsigned)cx & keep, sj, hl);             // the popped child (kept on a hit)
+        cy = (int)bop3<kOrAnd>((unsigned)cy & keep, sj >> 1, hl);
+        cz = (int)bop3<kOrAnd>((unsigned)cz & keep, sj >> 2, hl);
+        bpos = bpos2 - 1;
+        alive = !dead && !solid;
     }
-    if (P.tileCost && lane == 0 && ty < P.tilesY) {
-        P.tileCost[tile] = trips;
-        if (trips > 0) atomicAdd(&P.tileHist[(tile >> 10) * kCostBuckets + cost_bucket(trips)], 1);
-    }
+    if (P.tileCost && lane == 0 && ty < P.tilesY) P.tileCost[tile] = trips;
+    const int leafShift = bpos + 1;                                      // on a hit: log2 of the leaf's edge
 
     // identity (2): pops at the accepted leaf.  Needed for every hit when steps are reported, else only when the
     // upper bound 1 + S does not already clear the cap.
     int steps = steps0 + S;
     if (hit && (MODE == kModeSteps || steps > kMaxTraversalSteps)) {
         int R = 0;
-        for (int l = 0; l < lvl; l++) {                                  // lvl = level of the leaf; its ancestors are levels 0..lvl-1
-            const unsigned w = stk[l * kWave].x;
-            const int b = P.depth - 1 - l;
+        for (int b = P.depth - 1; b > bpos; b--) {                       // the entries of the leaf's ancestors
+            const unsigned w = stk[b * kWave].x;
             const unsigned jl = ((cx >> b) & 1) | (((cy >> b) & 1) << 1) | (((cz >> b) & 1) << 2);
             R += __builtin_popcount(__builtin_amdgcn_ubfe(w, 16, 8) & ((1u << jl) - 1u));
         }
@@ -919,14 +1020,17 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     }
     if (steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
 
+    const bool mine = valid && !(P.skipOutside && outsideRoot);     // pixels outside the root rectangle belong to the fill duty
     if (MODE == kModeShade) {
-        if (valid) __builtin_nontemporal_store(hit ? shade_term(P, r, cx, cy, cz, P.rootSize >> lvl) : kShadeMiss, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);
+        if (mine) __builtin_nontemporal_store(hit ? shade_term(P, G, r, cx, cy, cz, 1 << leafShift) : kShadeMiss, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);
+        fill_outside<MODE>(P, out, lane, slot);
     } else if (MODE == kModeColor || MODE == kModeTimeline) {
-        if (valid) {
+        if (mine) {
             float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
-            if (hit) color = shade_hit(P, r, cx, cy, cz, P.rootSize >> lvl);
+            if (hit) color = shade_color(shade_term(P, G, r, cx, cy, cz, 1 << leafShift));
             store_pixel(out + (size_t)ly * P.W + px, color);
         }
+        fill_outside<MODE>(P, out, lane, slot);
         if (MODE == kModeTimeline) {
             const int act = __builtin_popcountll(__builtin_amdgcn_ballot_w64(steps0 + S > 1));
             if (lane == 0 && ty < P.tilesY) {
@@ -955,8 +1059,10 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean(RenderPar
     extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;
-    trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, blockIdx.x * (kBlock / kWave) + wave);
+    uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64], b in [0, depth]
+    const int slot = blockIdx.x * (kBlock / kWave) + wave;
+    if (slot >= P.launchWaves) return;
+    trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
 }
 
 // Persistent-threads form of the default kernel (RTO_KERNEL_PACKED_PERSISTENT): the grid only fills the machine, every
@@ -970,12 +1076,12 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_persisten
     extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;
-    const int tiles = P.tilesX * P.tilesY;
+    uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;
+    const int tiles = P.launchWaves;
     const int firstFree = gridDim.x * (kBlock / kWave);
     int slot = blockIdx.x * (kBlock / kWave) + wave;
     int left = 1;                                              // slots of the current chunk still to render
-    while (slot < tiles) {                                     // wave-uniform; ends once the counter has run past `tiles`
+    while (slot < tiles) {                                     // wave-uniform; ends once the counter has run past the last slot
         trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
         slot++;
         if (--left == 0) {
@@ -989,69 +1095,55 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_persisten
     }
 }
 
-// Counting sort of the tiles by descending cost (64 buckets of min(trips, 63)) -> next frame's launch order.
-// Two small multi-block kernels, no global atomics: (1) each 1024-tile block writes its 64-bucket histogram,
-// built in LDS with wave-aggregated atomics (one LDS atomic per DISTINCT bucket per wave: costs cluster
-// spatially); (2) each block derives its write offsets from the block-histogram table (costlier buckets first,
-// lower blocks first) and scatters.  Runs after the render kernel on the same stream.
+// Launch order of the box's tiles: a counting sort by descending cost (trip count an earlier frame recorded, 64
+// buckets of min(trips, 63)) done by ONE 1,024-thread block -- a few thousand tiles, no inter-block state: whatever the
+// cost array holds (stale values, tiles that were outside the box when it was written), the result is a permutation of
+// the box's tiles, so every tile is rendered exactly once.  The buckets are staged in LDS first (one pass of independent,
+// coalesced loads: reading the costs inside the counting loops cost a dependent global load per step, 80 us per build);
+// wave w then owns the id range [w*chunk, (w+1)*chunk) of the box (ids row-major over boxW x boxH) and counts / places
+// its tiles with LDS atomics.  Tiles of one bucket keep their wave order; within a wave the order is the atomics'.
+constexpr int kOrderBuckets = 64;
+constexpr int kOrderBlock = 1024;
+constexpr int kOrderLdsTiles = 144 * 1024;          // buckets staged in LDS (1 byte per tile); larger boxes re-read the costs
 
-__device__ __forceinline__ void wave_bucket_add(int b, int lane, int* counters, int& posOut) {
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(b >= 0);
-    posOut = 0;
-    while (todo) {
-        const int lead = __builtin_ctzll(todo);
-        const int bl = __shfl(b, lead);
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(b == bl);
-        int p0 = 0;
-        if (lane == lead) p0 = atomicAdd(&counters[bl], __builtin_popcountll(m));
-        p0 = __shfl(p0, lead);
-        if (b == bl) posOut = p0 + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-        todo &= ~m;
-    }
-}
-
-__global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const int* __restrict__ tileCost, int tiles, const int* __restrict__ blockHist,
-                                                              int numBlocks, int* __restrict__ order, int* __restrict__ nextHist,
-                                                              int* __restrict__ violations) {
-    extern __shared__ int tab[];                       // [numBlocks][kCostBuckets] copy of the histogram table
-    __shared__ int base[kCostBuckets], fill[kCostBuckets], total[kCostBuckets];
-    for (int i = threadIdx.x; i < numBlocks * kCostBuckets; i += kSortBlock) tab[i] = blockHist[i];
-    if (threadIdx.x < kCostBuckets) nextHist[blockIdx.x * kCostBuckets + threadIdx.x] = 0;   // the table the NEXT frame accumulates into
+__global__ __launch_bounds__(kOrderBlock) void k_order_build(const int* __restrict__ tileCost, int tilesX, int boxX0, int boxY0, int boxW, int boxH,
+                                                              int staged, int* __restrict__ order, int* __restrict__ violations) {
+    constexpr int kWaves = kOrderBlock / kWave;
+    extern __shared__ unsigned char stagedBucket[];  // [n] when staged
+    __shared__ int cnt[kWaves][kOrderBuckets];      // pass 1: counts; then each wave's write cursor per bucket
+    __shared__ int bucketBase[kOrderBuckets];
+    const int n = boxW * boxH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = ((n + kWaves - 1) / kWaves + kWave - 1) / kWave * kWave;
+    const int lo = wave * chunk, hi = min(n, lo + chunk);
+    auto tile_of_id = [&](int i) { const int ry = i / boxW, rx = i - ry * boxW; return (boxY0 + ry) * tilesX + boxX0 + rx; };
+    auto bucket_of = [&](int i) {
+        return staged ? (int)stagedBucket[i] : min(max(tileCost[tile_of_id(i)], 0), kOrderBuckets - 1);
+    };
+    for (int i = threadIdx.x; i < kWaves * kOrderBuckets; i += kOrderBlock) (&cnt[0][0])[i] = 0;
+    if (staged)
+        for (int i = threadIdx.x; i < n; i += kOrderBlock) stagedBucket[i] = (unsigned char)min(max(tileCost[tile_of_id(i)], 0), kOrderBuckets - 1);
     __syncthreads();
-    // bucket 0 is implicit: a block's tiles minus the counted ones (zero-cost tiles do no atomics)
-    for (int k = threadIdx.x; k < numBlocks; k += kSortBlock) {
-        int counted = 0;
-#pragma unroll
-        for (int bk = 1; bk < kCostBuckets; bk++) counted += tab[k * kCostBuckets + bk];
-        tab[k * kCostBuckets] = min(kSortBlock, tiles - k * kSortBlock) - counted;
+    for (int i = lo + lane; i < hi; i += kWave) atomicAdd(&cnt[wave][bucket_of(i)], 1);
+    __syncthreads();
+    if (threadIdx.x < kOrderBuckets) {              // per bucket: exclusive prefix over the waves, total
+        int run = 0;
+        for (int w = 0; w < kWaves; w++) { const int h = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += h; }
+        bucketBase[threadIdx.x] = run;
     }
     __syncthreads();
-    if (threadIdx.x < kCostBuckets) {
-        int before = 0, all = 0;                       // tiles of this bucket in earlier blocks / in all blocks
-        for (int k = 0; k < numBlocks; k++) {
-            const int h = tab[k * kCostBuckets + threadIdx.x];
-            all += h;
-            if (k < (int)blockIdx.x) before += h;
-        }
-        total[threadIdx.x] = all;
-        fill[threadIdx.x] = before;
+    if (threadIdx.x == 0) {                         // costlier buckets first
+        int run = 0;
+        for (int b = kOrderBuckets - 1; b >= 0; b--) { const int h = bucketBase[b]; bucketBase[b] = run; run += h; }
     }
     __syncthreads();
-    if (threadIdx.x < kCostBuckets) {
-        int sum = 0;
-        for (int k = kCostBuckets - 1; k > (int)threadIdx.x; k--) sum += total[k];   // costlier buckets first
-        base[threadIdx.x] = sum;
-    }
+    for (int i = threadIdx.x; i < kWaves * kOrderBuckets; i += kOrderBlock) (&cnt[0][0])[i] += bucketBase[i % kOrderBuckets];
     __syncthreads();
-    const int i = blockIdx.x * kSortBlock + threadIdx.x;
-    const int bkt = i < tiles ? cost_bucket(tileCost[i]) : -1;
-    int pos;
-    wave_bucket_add(bkt, threadIdx.x & 63, fill, pos);
-    if (bkt >= 0) {
-        // base/fill come from histograms an earlier kernel accumulated: a table that does not match this frame's costs
-        // must not turn into a stray write (it did once).  Refused writes are counted; tests assert 0.
-        const int dst = base[bkt] + pos;
-        if (dst >= 0 && dst < tiles) order[dst] = i;
+    for (int i = lo + lane; i < hi; i += kWave) {
+        const int pos = atomicAdd(&cnt[wave][bucket_of(i)], 1);
+        // cannot fall outside by construction (both passes see the same buckets: the kernel that writes the costs runs
+        // before or after this one on the stream, never beside it); refused writes are counted and tests assert 0
+        if (pos >= 0 && pos < n) order[pos] = tile_of_id(i);
         else atomicAdd(violations, 1);
     }
 }

@@ -25,7 +25,7 @@ def main(out):
     for f in glob.glob(os.path.join(out, "pmc*", "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            if "k_trace" not in name or "<1>" in name:
+            if "k_trace" not in name or "<1>" in name or "<1," in name:
                 continue
             acc.setdefault((name, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     for (name, ctr), v in sorted(acc.items()):

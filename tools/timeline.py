@@ -21,6 +21,9 @@ for _ in range(3):
     ctx.render_host(f)
 rec = ctx.debug_timeline(f)
 rec = ctx.debug_timeline(f)
+all_tiles = len(rec)
+rec = rec[(rec[:, 0] != 0) | (rec[:, 1] != 0)]          # tiles outside the root rectangle's box get no wave
+print(f"tiles {all_tiles}, waves with a tile {len(rec)}")
 t0 = (rec[:, 0].astype(np.uint32).astype(np.uint64) | (rec[:, 1].astype(np.uint32).astype(np.uint64) << 32)).astype(np.int64)
 t1 = (rec[:, 2].astype(np.uint32).astype(np.uint64) | (rec[:, 3].astype(np.uint32).astype(np.uint64) << 32)).astype(np.int64)
 base = t0.min()
