@@ -199,6 +199,36 @@ int  rto_render_batch_device(rto_context* ctx, const rto_frame* frames, int n, c
 int  rto_assemble_batch_all_device(rto_context* ctx, const rto_frame* frames, int batch, const rto_partition* part,
                                    const void* d_gathered, int shade_payload, void* d_frames, size_t frame_stride_bytes, void* hip_stream);
 
+/* ---- multi-GPU: screen split + ONE gather per batch, below the C boundary ---------------------------------
+ * No reference counterpart (the reference is single-GPU).  A communicator binds one context
+ * (= one GPU, holding the whole octree) to a rank of a world of GPUs of one node.  rto_comm_submit renders this rank's
+ * bands (band b of band_rows rows belongs to rank b % world) of n consecutive frames as the 4-byte payload of
+ * rto_render_shade_device, ships them to rank 0 with ONE grouped ncclSend/ncclRecv (RCCL over xGMI: a direct gather into
+ * the root, never a ring) and, on rank 0, re-interleaves and finishes the colours into d_frames + i*frame_stride_bytes
+ * (RGBA32F, bit-identical to rto_render_device).  Asynchronous and pipelined: the call returns when the work is
+ * enqueued on the communicator's own two HIP streams, the gather of batch k overlaps the render of batch k+1 (two
+ * sets of buffers alternate); d_frames must stay valid until rto_comm_flush (or a wait on rto_comm_stream) returns.
+ * Every rank makes the same sequence of calls.  mode: RTO_RESIDENT_OCTREE / _TRIANGLES / _TRIANGLES_SHADOW.
+ *
+ * One process per GPU: rank 0 calls rto_comm_unique_id, hands the RTO_COMM_ID_BYTES bytes to the other ranks by any
+ * means (MPI, a TCP store, a file), every rank calls rto_comm_create.  One process, several GPUs (what
+ * RayTracerBVH::setDevices uses): rto_comm_create_all over n contexts on n different devices, then
+ * rto_comm_submit_all issues every rank's part of a batch from the calling thread.  librccl is loaded on first use. */
+typedef struct rto_comm rto_comm;
+#define RTO_COMM_ID_BYTES 128
+int  rto_comm_unique_id(void* id /* RTO_COMM_ID_BYTES */);
+int  rto_comm_create(rto_context* ctx, int world, int rank, const void* id, int band_rows, rto_comm** out);
+int  rto_comm_create_all(rto_context* const* ctxs, int n, int band_rows, rto_comm** out /* n handles */);
+void rto_comm_destroy(rto_comm* comm);
+const char* rto_comm_last_error(const rto_comm* comm);
+int  rto_comm_submit(rto_comm* comm, const rto_frame* frames, int n, int mode, void* d_frames /* rank 0 */, size_t frame_stride_bytes);
+int  rto_comm_submit_all(rto_comm* const* comms, int n_comms, const rto_frame* frames, int n, int mode, void* d_frames, size_t frame_stride_bytes);
+/* single-process group: one frame through all ranks into rank 0's resident framebuffer (cf. rto_render_resident);
+ * asynchronous, rto_download_resident / rto_resident_frame of rank 0's context give the assembled frame */
+int  rto_comm_render_resident_all(rto_comm* const* comms, int n_comms, const rto_frame* frame, int mode);
+int  rto_comm_flush(rto_comm* comm);              /* waits until every submitted batch is complete on this rank */
+void* rto_comm_stream(rto_comm* comm);            /* hipStream_t the gathers and (rank 0) the assembled frames are ordered on */
+
 /* ---- N2: leaf triangles + shadow ray (BASELINE config 5) -------------------------
  * No upstream counterpart: the reference has no ray/triangle code (its MC triangles are rasterised).  The
  * triangles are those MarchingCubesRenderer emits per leaf (localMC, S/OctreeVoxel.cpp:780-879;

@@ -16,6 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBORC = os.path.join(HERE, "liborc.so")
 LIBREF = os.path.join(HERE, "_ref", "libref.so")
+LIBREF_VR = os.path.join(HERE, "_ref", "libref_vr.so")
 REFERENCE_ROOT = "/root/reference"
 
 NODE_DTYPE = np.dtype(
@@ -106,6 +107,8 @@ def lib():
                                    C.c_int, C.c_int, C.c_void_p]
     L.orc_octree_ray_skip.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float]
     L.orc_octree_ray_skip.restype = C.c_float
+    L.orc_octree_ray_skip_vis.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float, C.c_void_p]
+    L.orc_octree_ray_skip_vis.restype = C.c_float
     L.orc_local_mc.argtypes = [C.POINTER(_Grid), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.orc_local_mc.restype = C.c_int64
     L.orc_build_leaf_triangles.argtypes = [C.POINTER(_Grid), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
@@ -254,10 +257,22 @@ def render_steps(nodes, grid_min, voxel_size, view, cam_pos, aspect, fov_deg, W,
     return steps
 
 
-def octree_ray_skip(nodes, grid_min, voxel_size, ro, rd, tmin=0.0, tmax=1e30):
+def octree_ray_skip(nodes, grid_min, voxel_size, ro, rd, tmin=0.0, tmax=1e30, visible=None):
+    """octreeRaySkip (453-skeleton/VolumeRaycastRenderer.cpp:50-155) for one ray; `visible`: one flag per node (the
+    reference's visibility map, :64-67)."""
     nodes = np.ascontiguousarray(nodes)
-    return lib().orc_octree_ray_skip(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size),
-                                     _f32(ro), _f32(rd), tmin, tmax)
+    if visible is None:
+        return lib().orc_octree_ray_skip(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size),
+                                         _f32(ro), _f32(rd), tmin, tmax)
+    v = np.ascontiguousarray(visible, dtype=np.uint8)
+    assert len(v) == len(nodes)
+    return lib().orc_octree_ray_skip_vis(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size),
+                                         _f32(ro), _f32(rd), tmin, tmax, v.ctypes.data)
+
+
+def octree_ray_skip_many(nodes, grid_min, voxel_size, ro, rds, tmin=0.0, tmax=1e30, visible=None) -> np.ndarray:
+    rds = _f32(rds).reshape(-1, 3)
+    return np.array([octree_ray_skip(nodes, grid_min, voxel_size, ro, rds[i], tmin, tmax, visible) for i in range(len(rds))], np.float32)
 
 
 def local_mc(g: Grid, x0, y0, z0, size) -> np.ndarray:
@@ -378,3 +393,41 @@ def ref_local_mc(g: Grid, x0, y0, z0, size) -> np.ndarray:
     arr = np.frombuffer(C.string_at(out.value, max(n, 0) * 72), dtype=np.float32).copy().reshape(-1, 18)
     ref().ref_free(out)
     return arr
+
+
+# ---- the reference's static octreeRaySkip, through oracle/ref_shim_vr.cpp (make -C oracle refvr)
+_refvr = None
+
+
+def refvr_available() -> bool:
+    return os.path.exists(LIBREF_VR)
+
+
+def refvr():
+    global _refvr
+    if _refvr is None:
+        R = C.CDLL(LIBREF_VR)
+        R.refvr_octree_ray_skip.argtypes = [C.POINTER(_Grid), _f32p, _f32p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_int64, _f32p]
+        R.refvr_octree_ray_skip.restype = C.c_int64
+        R.refvr_probe_rays.argtypes = [_f32p, _f32p, C.c_float, _f32p]
+        _refvr = R
+    return _refvr
+
+
+def ref_octree_ray_skip(g: Grid, ro, rds, tmin=0.0, tmax=1e30, visible=None) -> np.ndarray:
+    """The reference's own compiled octreeRaySkip on its own octree of `g`, one call per direction."""
+    rds = _f32(rds).reshape(-1, 3)
+    out = np.zeros(len(rds), np.float32)
+    cg = g.c()
+    v = None if visible is None else np.ascontiguousarray(visible, dtype=np.uint8)
+    n = refvr().refvr_octree_ray_skip(C.byref(cg), _f32(ro), rds.reshape(-1), len(rds), tmin, tmax,
+                                      None if v is None else v.ctypes.data, 0 if v is None else len(v), out)
+    if n == 0:
+        raise RuntimeError("refvr_octree_ray_skip failed (node count mismatch?)")
+    return out
+
+
+def ref_probe_rays(view, eye, aspect) -> np.ndarray:
+    rd = np.zeros(49 * 3, np.float32)
+    refvr().refvr_probe_rays(_f32(view).reshape(16), _f32(eye), aspect, rd)
+    return rd.reshape(49, 3)

@@ -674,8 +674,9 @@ void orc_render_visits(const orc_node* nodes, int64_t n, const float gridMin[3],
 /* N1: octreeRaySkip (S/VolumeRaycastRenderer.cpp:50-155), on the flat array */
 /* ------------------------------------------------------------------ */
 static float ray_skip_rec(const orc_node* nodes, int32_t idx, const float gridMin[3], float vx,
-                          v3 ro, v3 rd, float tMin, float tMax) {
+                          v3 ro, v3 rd, float tMin, float tMax, const uint8_t* vis) {
     if (idx < 0) return 1e30f;                                   /* :60-62 */
+    if (vis && !vis[idx]) return 1e30f;                          /* :64-67: a node the visibility map holds as false */
     const orc_node* node = &nodes[idx];
     /* :70-77 */
     float wx0 = gridMin[0] + node->x * vx;
@@ -712,7 +713,7 @@ static float ray_skip_rec(const orc_node* nodes, int32_t idx, const float gridMi
             if (bitDiff != dist) continue;
             int32_t child = node->child[octant];
             if (child < 0) continue;
-            float childT = ray_skip_rec(nodes, child, gridMin, vx, ro, rd, enterT, exitT);
+            float childT = ray_skip_rec(nodes, child, gridMin, vx, ro, rd, enterT, exitT, vis);
             if (childT < bestT) {
                 bestT = childT;
                 if (childT < 1e30f) return childT;
@@ -725,7 +726,14 @@ static float ray_skip_rec(const orc_node* nodes, int32_t idx, const float gridMi
 float orc_octree_ray_skip(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
                           const float ro[3], const float rd[3], float tMin, float tMax) {
     if (n <= 0) return 1e30f;
-    return ray_skip_rec(nodes, 0, gridMin, voxelSize, v3_(ro[0], ro[1], ro[2]), v3_(rd[0], rd[1], rd[2]), tMin, tMax);
+    return ray_skip_rec(nodes, 0, gridMin, voxelSize, v3_(ro[0], ro[1], ro[2]), v3_(rd[0], rd[1], rd[2]), tMin, tMax, NULL);
+}
+
+/* the same with the reference's visibility map (S/VolumeRaycastRenderer.cpp:64-67) as one flag per node of the flat array */
+float orc_octree_ray_skip_vis(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                              const float ro[3], const float rd[3], float tMin, float tMax, const uint8_t* vis) {
+    if (n <= 0) return 1e30f;
+    return ray_skip_rec(nodes, 0, gridMin, voxelSize, v3_(ro[0], ro[1], ro[2]), v3_(rd[0], rd[1], rd[2]), tMin, tMax, vis);
 }
 
 /* ------------------------------------------------------------------ */

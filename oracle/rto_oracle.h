@@ -113,6 +113,8 @@ void orc_render_visits(const orc_node* nodes, int64_t n, const float gridMin[3],
 /* ---- N1: front-to-back nearest hit (S/VolumeRaycastRenderer.cpp:50-155) - */
 float orc_octree_ray_skip(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
                           const float ro[3], const float rd[3], float tMin, float tMax);
+float orc_octree_ray_skip_vis(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                              const float ro[3], const float rd[3], float tMin, float tMax, const uint8_t* vis);
 
 /* ---- N2: leaf triangles + shadow ray (BASELINE config 5) -------------------------------------------
  * localMC is a restatement of S/OctreeVoxel.cpp:780-879 and IS pinned by the reference's own triangles

@@ -55,7 +55,7 @@ def _sources(d: str, exts: tuple[str, ...]) -> list[str]:
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    deps = _sources(CSRC, (".hip", ".h")) + [os.path.join(HOST, "rtmath.h"), os.path.join(ROOT, "include", "rto_hip.h")]
+    deps = _sources(CSRC, (".hip", ".h", ".inc")) + [os.path.join(HOST, "rtmath.h"), os.path.join(ROOT, "include", "rto_hip.h")]
     if not force and _newer(LIB_HIP, deps):
         return LIB_HIP
     extra = os.environ.get("RTO_HIP_EXTRA_FLAGS", "").split()      # developer aid: A/B builds such as -DRTO_STAMP

@@ -1517,3 +1517,5 @@ int rto_synchronize(rto_context* c) {
 }
 
 }  // extern "C"
+
+#include "rto_comm.inc"

@@ -31,7 +31,11 @@ SYMBOLS = (
     "rto_render_shade_device", "rto_assemble_shade_device", "rto_assemble_batch_device", "rto_render_batch_device", "rto_assemble_batch_all_device", "rto_render_resident", "rto_resident_frame", "rto_download_resident",
     "rto_upload_leaf_triangles", "rto_build_leaf_triangles", "rto_download_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_debug_sort_violations", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
+    "rto_comm_unique_id", "rto_comm_create", "rto_comm_create_all", "rto_comm_destroy", "rto_comm_last_error", "rto_comm_submit",
+    "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_stream",
 )
+COMM_ID_BYTES = 128
+RESIDENT_OCTREE, RESIDENT_TRIANGLES, RESIDENT_TRIANGLES_SHADOW = 0, 1, 2
 
 
 class RtoError(RuntimeError):
@@ -132,6 +136,19 @@ def load():
     L.rto_timing_read.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.rto_stream.argtypes = [vp]
     L.rto_stream.restype = vp
+    L.rto_comm_unique_id.argtypes = [vp]
+    L.rto_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
+    L.rto_comm_create_all.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]
+    L.rto_comm_destroy.argtypes = [vp]
+    L.rto_comm_destroy.restype = None
+    L.rto_comm_last_error.argtypes = [vp]
+    L.rto_comm_last_error.restype = C.c_char_p
+    L.rto_comm_submit.argtypes = [vp, C.POINTER(Frame), C.c_int, C.c_int, vp, C.c_size_t]
+    L.rto_comm_submit_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Frame), C.c_int, C.c_int, vp, C.c_size_t]
+    L.rto_comm_render_resident_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Frame), C.c_int]
+    L.rto_comm_flush.argtypes = [vp]
+    L.rto_comm_stream.argtypes = [vp]
+    L.rto_comm_stream.restype = vp
     _lib = L
     return L
 
@@ -418,3 +435,97 @@ class Context:
 
     def synchronize(self):
         self._check(self._L.rto_synchronize(self._h))
+
+
+def comm_unique_id() -> bytes:
+    """rank 0: the 128 bytes every other rank needs for Comm(ctx, world, rank, id)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().rto_comm_unique_id(buf)
+    if rc != RTO_OK:
+        raise RtoError(rc, load().rto_last_error(None).decode())
+    return buf.raw
+
+
+class Comm:
+    """rto_comm: one rank of the screen-split renderer (one process per GPU).  submit() renders this rank's bands of a batch
+    of frames, ONE grouped RCCL send/recv lands them on rank 0, which assembles them into `d_frames`; flush() waits."""
+
+    def __init__(self, ctx: Context, world: int, rank: int, unique_id: bytes, band_rows: int = 16):
+        self._L = load()
+        self.ctx, self.world, self.rank = ctx, world, rank
+        h = C.c_void_p()
+        idbuf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        rc = self._L.rto_comm_create(ctx._h, world, rank, idbuf, band_rows, C.byref(h))
+        if rc != RTO_OK:
+            raise RtoError(rc, self._L.rto_last_error(ctx._h).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rto_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != RTO_OK:
+            raise RtoError(rc, self._L.rto_comm_last_error(self._h).decode())
+
+    def submit(self, frames_arr, d_frames: int = 0, frame_stride_bytes: int = 0, mode: int = RESIDENT_OCTREE):
+        """frames_arr: Context.frame_array([...]); d_frames (rank 0): device pointer of len(frames_arr) RGBA32F frames."""
+        self._check(self._L.rto_comm_submit(self._h, frames_arr, len(frames_arr), mode, C.c_void_p(d_frames) if d_frames else None, frame_stride_bytes))
+
+    def flush(self):
+        self._check(self._L.rto_comm_flush(self._h))
+
+    @property
+    def stream(self) -> int:
+        return self._L.rto_comm_stream(self._h) or 0
+
+
+class CommGroup:
+    """rto_comm_create_all: one process driving several GPUs (one Context each, all on different devices).  render_resident()
+    sends one frame through every rank into rank 0's resident framebuffer; submit()/flush() are the batched, pipelined form."""
+
+    def __init__(self, contexts, band_rows: int = 16):
+        self._L = load()
+        self.contexts = list(contexts)
+        n = len(self.contexts)
+        ctxs = (C.c_void_p * n)(*[c._h for c in self.contexts])
+        self._handles = (C.c_void_p * n)()
+        rc = self._L.rto_comm_create_all(ctxs, n, band_rows, self._handles)
+        if rc != RTO_OK:
+            self._handles = None
+            raise RtoError(rc, self._L.rto_last_error(self.contexts[0]._h).decode())
+
+    def close(self):
+        if getattr(self, "_handles", None):
+            for h in self._handles:
+                if h:
+                    self._L.rto_comm_destroy(h)
+            self._handles = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != RTO_OK:
+            raise RtoError(rc, self._L.rto_comm_last_error(self._handles[0]).decode())
+
+    def render_resident(self, frame: Frame, mode: int = RESIDENT_OCTREE):
+        self._check(self._L.rto_comm_render_resident_all(self._handles, len(self.contexts), C.byref(frame), mode))
+
+    def submit(self, frames_arr, d_frames: int, frame_stride_bytes: int, mode: int = RESIDENT_OCTREE):
+        self._check(self._L.rto_comm_submit_all(self._handles, len(self.contexts), frames_arr, len(frames_arr), mode,
+                                                C.c_void_p(d_frames), frame_stride_bytes))
+
+    def flush(self):
+        for h in self._handles:
+            self._check(self._L.rto_comm_flush(h))

@@ -87,6 +87,8 @@ def load():
     L.rtoh_rt_new.restype = _vp
     L.rtoh_rt_free.argtypes = [_vp]
     L.rtoh_rt_free.restype = None
+    L.rtoh_rt_set_devices.argtypes = [_vp, C.c_int, C.c_int]
+    L.rtoh_rt_set_devices.restype = None
     L.rtoh_rt_ensure_compute_initialized.argtypes = [_vp]
     L.rtoh_rt_ensure_compute_initialized.restype = None
     L.rtoh_rt_set_octree.argtypes = [_vp, _vp, _vp]
@@ -314,6 +316,10 @@ class RayTracerBVH:
         if getattr(self, "_h", None) and _lib is not None:
             _lib.rtoh_rt_free(self._h)
             self._h = None
+
+    def setDevices(self, n: int, bandRows: int = 16):
+        """Before ensureComputeInitialized(): split every frame over n GPUs of this node + ONE RCCL gather (rto_comm_*)."""
+        load().rtoh_rt_set_devices(self._h, n, bandRows)
 
     def ensureComputeInitialized(self):
         load().rtoh_rt_ensure_compute_initialized(self._h)

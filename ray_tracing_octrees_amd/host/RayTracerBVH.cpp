@@ -29,6 +29,10 @@ struct HipApi {
     decltype(&rto_download_resident) download_resident = nullptr;
     decltype(&rto_synchronize) synchronize = nullptr;
     decltype(&rto_render_triangles_host) render_triangles_host = nullptr;
+    decltype(&rto_comm_create_all) comm_create_all = nullptr;
+    decltype(&rto_comm_destroy) comm_destroy = nullptr;
+    decltype(&rto_comm_last_error) comm_last_error = nullptr;
+    decltype(&rto_comm_render_resident_all) comm_render_resident_all = nullptr;
     std::string error;
 
     bool load() {
@@ -69,6 +73,10 @@ struct HipApi {
         download_resident = reinterpret_cast<decltype(download_resident)>(sym("rto_download_resident"));
         synchronize = reinterpret_cast<decltype(synchronize)>(sym("rto_synchronize"));
         render_triangles_host = reinterpret_cast<decltype(render_triangles_host)>(sym("rto_render_triangles_host"));
+        comm_create_all = reinterpret_cast<decltype(comm_create_all)>(sym("rto_comm_create_all"));
+        comm_destroy = reinterpret_cast<decltype(comm_destroy)>(sym("rto_comm_destroy"));
+        comm_last_error = reinterpret_cast<decltype(comm_last_error)>(sym("rto_comm_last_error"));
+        comm_render_resident_all = reinterpret_cast<decltype(comm_render_resident_all)>(sym("rto_comm_render_resident_all"));
         if (!ok) { dlclose(handle); handle = nullptr; }
         return ok;
     }
@@ -87,7 +95,32 @@ RayTracerBVH::RayTracerBVH()
       m_frustumCullingEnabled(true), m_device(0), m_ctx(nullptr), m_frameW(0), m_frameH(0) {}
 
 RayTracerBVH::~RayTracerBVH() {
-    if (m_ctx) api().destroy(m_ctx);
+    for (rto_comm* m : m_comms) if (m) api().comm_destroy(m);
+    for (rto_context* c : m_ctxs) if (c) api().destroy(c);
+}
+
+// Runs `call(ctx)` (an rto_* call returning RTO_OK or an error code) on every GPU's context.
+template <class F> bool RayTracerBVH::forEachContext(F&& call, const char* what) {
+    for (rto_context* c : m_ctxs) {
+        if (call(c) != RTO_OK) {
+            m_lastError = api().last_error(c);
+            std::cerr << "[RayTracerBVH] " << what << " failed: " << m_lastError << std::endl;
+            return false;
+        }
+    }
+    return true;
+}
+
+// One frame into the (first GPU's) resident framebuffer: a plain render, or the split over all GPUs + one gather.
+bool RayTracerBVH::renderFrame(const rto_frame& f, int mode) {
+    if (m_comms.empty()) {
+        if (api().render_resident(m_ctx, &f, mode) == RTO_OK) return true;
+        m_lastError = api().last_error(m_ctx);
+        return false;
+    }
+    if (api().comm_render_resident_all(m_comms.data(), (int)m_comms.size(), &f, mode) == RTO_OK) return true;
+    m_lastError = api().comm_last_error(m_comms[0]);
+    return false;
 }
 
 std::vector<GPUNodes> RayTracerBVH::flatten(const OctreeNode* root) {
@@ -126,12 +159,10 @@ void RayTracerBVH::setOctree(OctreeNode* root, const VoxelGrid& grid) {
     m_numNodes = static_cast<int>(m_flatNodes.size());
     if (!m_ctx) return;                 // uploaded by ensureComputeInitialized() once the device exists
     const float gridMin[3] = { m_grid.minX, m_grid.minY, m_grid.minZ };
-    if (api().upload_octree(m_ctx, reinterpret_cast<const rto_node*>(m_flatNodes.data()), m_numNodes, gridMin,
-                            m_grid.voxelSize) != RTO_OK) {
-        m_lastError = api().last_error(m_ctx);
-        std::cerr << "[RayTracerBVH] octree upload failed: " << m_lastError << std::endl;
+    if (!forEachContext([&](rto_context* c) {
+            return api().upload_octree(c, reinterpret_cast<const rto_node*>(m_flatNodes.data()), m_numNodes, gridMin, m_grid.voxelSize);
+        }, "octree upload"))
         m_computeOk = false;
-    }
 }
 
 void RayTracerBVH::setOctreeFromGrid(const VoxelGrid& grid) {
@@ -143,12 +174,10 @@ void RayTracerBVH::setOctreeFromGrid(const VoxelGrid& grid) {
     if (!m_computeOk || grid.dimX <= 0 || grid.dimY <= 0 || grid.dimZ <= 0) return;
     const float gridMin[3] = { grid.minX, grid.minY, grid.minZ };
     static_assert(sizeof(VoxelState) == 1, "VoxelGrid.data is one byte per voxel");
-    if (api().build_octree(m_ctx, reinterpret_cast<const uint8_t*>(grid.data.data()), grid.dimX, grid.dimY, grid.dimZ, gridMin,
-                           grid.voxelSize) != RTO_OK) {
-        m_lastError = api().last_error(m_ctx);
-        std::cerr << "[RayTracerBVH] GPU octree build failed: " << m_lastError << std::endl;
+    if (!forEachContext([&](rto_context* c) {
+            return api().build_octree(c, reinterpret_cast<const uint8_t*>(grid.data.data()), grid.dimX, grid.dimY, grid.dimZ, gridMin, grid.voxelSize);
+        }, "GPU octree build"))
         return;
-    }
     rto_octree_info info;
     if (api().octree_info(m_ctx, &info) == RTO_OK) m_numNodes = static_cast<int>(info.num_nodes);
 }
@@ -161,21 +190,35 @@ void RayTracerBVH::ensureComputeInitialized() {
         std::cerr << "[RayTracerBVH] " << m_lastError << std::endl;
         return;
     }
-    if (api().create(m_device, &m_ctx) != RTO_OK) {
-        m_lastError = api().last_error(nullptr);
-        std::cerr << "[RayTracerBVH] " << m_lastError << std::endl;
-        m_ctx = nullptr;
-        return;
+    for (int i = 0; i < m_numDevices; i++) {
+        rto_context* c = nullptr;
+        if (api().create(m_device + i, &c) != RTO_OK) {
+            m_lastError = api().last_error(nullptr);
+            std::cerr << "[RayTracerBVH] " << m_lastError << std::endl;
+            for (rto_context* d : m_ctxs) api().destroy(d);
+            m_ctxs.clear();
+            m_ctx = nullptr;
+            return;
+        }
+        m_ctxs.push_back(c);
+    }
+    m_ctx = m_ctxs[0];
+    if (m_numDevices > 1) {
+        m_comms.assign((size_t)m_numDevices, nullptr);
+        if (api().comm_create_all(m_ctxs.data(), m_numDevices, m_bandRows, m_comms.data()) != RTO_OK) {
+            m_lastError = api().last_error(m_ctx);
+            std::cerr << "[RayTracerBVH] " << m_lastError << std::endl;
+            m_comms.clear();
+            return;                                    // m_computeOk stays false: no silent single-GPU fallback
+        }
     }
     m_computeOk = true;
     if (m_numNodes > 0 && !m_flatNodes.empty()) {   // setOctree() came first
         const float gridMin[3] = { m_grid.minX, m_grid.minY, m_grid.minZ };
-        if (api().upload_octree(m_ctx, reinterpret_cast<const rto_node*>(m_flatNodes.data()), m_numNodes, gridMin,
-                                m_grid.voxelSize) != RTO_OK) {
-            m_lastError = api().last_error(m_ctx);
-            std::cerr << "[RayTracerBVH] octree upload failed: " << m_lastError << std::endl;
+        if (!forEachContext([&](rto_context* c) {
+                return api().upload_octree(c, reinterpret_cast<const rto_node*>(m_flatNodes.data()), m_numNodes, gridMin, m_grid.voxelSize);
+            }, "octree upload"))
             m_computeOk = false;
-        }
     }
 }
 
@@ -192,8 +235,7 @@ bool RayTracerBVH::render(const Camera& camera, int width, int height, float asp
     if (width <= 0 || height <= 0) return false;
     // like the reference's texture, the frame stays on the GPU (asynchronous); framebuffer() fetches it on demand
     m_frameW = m_frameH = 0; m_frameStale = false;
-    if (api().render_resident(m_ctx, &f, RTO_RESIDENT_OCTREE) != RTO_OK) {
-        m_lastError = api().last_error(m_ctx);
+    if (!renderFrame(f, RTO_RESIDENT_OCTREE)) {
         std::cerr << "[RayTracerBVH] render failed: " << m_lastError << std::endl;
         m_frame.clear();
         return false;
@@ -212,10 +254,7 @@ void RayTracerBVH::buildLeafTriangles() {
     // (after setOctreeFromGrid the voxels are already resident: NULL)
     static_assert(sizeof(VoxelState) == 1, "VoxelState is a byte upstream (S/OctreeVoxel.h:10-13)");
     const uint8_t* vox = m_flatNodes.empty() ? nullptr : reinterpret_cast<const uint8_t*>(m_grid.data.data());
-    if (api().build_leaf_triangles(m_ctx, vox, m_grid.dimX, m_grid.dimY, m_grid.dimZ) != RTO_OK) {
-        m_lastError = api().last_error(m_ctx);
-        std::cerr << "[RayTracerBVH] leaf-triangle build failed: " << m_lastError << std::endl;
-    }
+    forEachContext([&](rto_context* c) { return api().build_leaf_triangles(c, vox, m_grid.dimX, m_grid.dimY, m_grid.dimZ); }, "leaf-triangle build");
 }
 
 #ifndef RTO_REFERENCE_HEADERS
@@ -229,10 +268,7 @@ void RayTracerBVH::buildLeafTrianglesOnHost() {
     std::vector<float> tris;
     std::vector<int32_t> off;
     ::buildLeafTriangles(m_grid, GPUNodesView{ reinterpret_cast<const int32_t*>(m_flatNodes.data()), (int64_t)m_flatNodes.size() }, tris, off);
-    if (api().upload_leaf_triangles(m_ctx, tris.data(), (int64_t)(tris.size() / 12), off.data()) != RTO_OK) {
-        m_lastError = api().last_error(m_ctx);
-        std::cerr << "[RayTracerBVH] triangle upload failed: " << m_lastError << std::endl;
-    }
+    forEachContext([&](rto_context* c) { return api().upload_leaf_triangles(c, tris.data(), (int64_t)(tris.size() / 12), off.data()); }, "triangle upload");
 }
 #endif
 
@@ -249,8 +285,7 @@ void RayTracerBVH::renderSceneTriangles(const Camera& camera, int width, int hei
     f.cam_pos[0] = pos.x; f.cam_pos[1] = pos.y; f.cam_pos[2] = pos.z;
     f.aspect = aspect; f.fov_deg = fovDeg; f.width = width; f.height = height;
     m_frameW = m_frameH = 0; m_frameStale = false;
-    if (api().render_resident(m_ctx, &f, shadow ? RTO_RESIDENT_TRIANGLES_SHADOW : RTO_RESIDENT_TRIANGLES) != RTO_OK) {
-        m_lastError = api().last_error(m_ctx);
+    if (!renderFrame(f, shadow ? RTO_RESIDENT_TRIANGLES_SHADOW : RTO_RESIDENT_TRIANGLES)) {
         std::cerr << "[RayTracerBVH] render failed: " << m_lastError << std::endl;
         m_frame.clear();
         return;
@@ -272,7 +307,7 @@ const std::vector<float>& RayTracerBVH::framebuffer() const {
 }
 
 void RayTracerBVH::finish() const {
-    if (m_ctx) (void)api().synchronize(m_ctx);
+    for (rto_context* c : m_ctxs) (void)api().synchronize(c);
 }
 
 void RayTracerBVH::renderSceneCompute(const Camera& camera, int width, int height, float aspect, float fovDeg) {
@@ -298,11 +333,7 @@ void RayTracerBVH::renderSceneComputeWithCulling(const Camera& camera, int width
         // the reference recomputes visibility on the CPU and re-uploads the compacted array
         // (RayTracerBVH.cpp:725-813); here the same test and compaction run on the GPU.
         const auto view = camera.getView();
-        if (api().update_frustum(m_ctx, &view[0][0], fovDeg, aspect, 1) != RTO_OK) {
-            m_lastError = api().last_error(m_ctx);
-            std::cerr << "[RayTracerBVH] frustum update failed: " << m_lastError << std::endl;
-            return;
-        }
+        if (!forEachContext([&](rto_context* c) { return api().update_frustum(c, &view[0][0], fovDeg, aspect, 1); }, "frustum update")) return;
     }
     render(camera, width, height, aspect, fovDeg);
 }

@@ -84,6 +84,12 @@ public:
     int frameWidth() const { return m_frameW; }
     int frameHeight() const { return m_frameH; }
     void setDevice(int ordinal) { m_device = ordinal; }                  // before ensureComputeInitialized()
+    // Multi-GPU (no upstream counterpart; before ensureComputeInitialized()): the GPUs `m_device .. m_device + n - 1` of this
+    // node each hold the octree and render the bands `b % n` of every frame (bands of bandRows rows); ONE grouped RCCL
+    // send/recv per frame lands the parts on the first GPU, which assembles the image (rto_comm_* in rto_hip.h).  The
+    // reference's call sequence stays as it is; framebuffer() reads the assembled frame.
+    void setDevices(int n, int bandRows = 16) { m_numDevices = n < 1 ? 1 : n; m_bandRows = bandRows; }
+    int numDevices() const { return m_numDevices; }
     rto_context* context() const { return m_ctx; }
     const std::string& lastError() const { return m_lastError; }
 
@@ -99,7 +105,12 @@ private:
     bool m_computeOk;
     bool m_frustumCullingEnabled;
     int m_device;
-    rto_context* m_ctx;
+    int m_numDevices = 1, m_bandRows = 16;
+    rto_context* m_ctx;                       // the first GPU's context (== m_ctxs[0])
+    std::vector<rto_context*> m_ctxs;         // one per GPU
+    std::vector<rto_comm*> m_comms;           // setDevices(n > 1): the single-process communicator group
+    template <class F> bool forEachContext(F&& call, const char* what);
+    bool renderFrame(const rto_frame& f, int mode);
     mutable std::string m_lastError;
 
     mutable std::vector<float> m_frame;

@@ -144,6 +144,7 @@ RayTracerBVH* rtoh_rt_new(int device) {
     return rt;
 }
 void rtoh_rt_free(RayTracerBVH* rt) { delete rt; }
+void rtoh_rt_set_devices(RayTracerBVH* rt, int n, int bandRows) { rt->setDevices(n, bandRows); }
 void rtoh_rt_ensure_compute_initialized(RayTracerBVH* rt) { rt->ensureComputeInitialized(); }
 void rtoh_rt_set_octree(RayTracerBVH* rt, OctreeNode* root, const VoxelGrid* g) { rt->setOctree(root, *g); }
 void rtoh_rt_set_octree_from_grid(RayTracerBVH* rt, const VoxelGrid* g) { rt->setOctreeFromGrid(*g); }

@@ -817,6 +817,23 @@ def test_reference_host_stack_drives_the_hip_path(orc, scenes, camera, tmp_path)
     assert_bit_exact(got, want, "reference host stack + HIP path")
 
 
+@pytest.mark.parametrize("scene", ["sphere32", "odd", "calgary"])
+def test_octree_ray_skip_equals_the_reference_vectors(ctx, scenes, golden, scene):
+    """N1 on the GPU against the reference's own compiled octreeRaySkip (tests/golden/ref_ray_skip.npz, see
+    test_oracle_golden.py): probe grid, random, inside, axis-parallel / clamp cases and a narrowed interval, both kernels."""
+    z = golden("ref_ray_skip.npz")
+    s = scenes(scene)
+    upload(ctx, s)
+    for tag in ("probe", "random", "inside", "axis_inside", "axis_outside0", "axis_outside1", "axis_outside2", "narrow"):
+        key = f"{scene}_{tag}"
+        ro, rd, (tmin, tmax), want = z[key + "_ro"], z[key + "_rd"], z[key + "_t"], z[key + "_out"]
+        for kname, kernel in (("descriptors", rto.KERNEL_AUTO), ("nodes", rto.KERNEL_GENERIC)):
+            ctx.set_kernel(kernel)
+            got = ctx.octree_ray_skip(ro, rd, float(tmin), float(tmax))
+            assert got.tobytes() == want.tobytes(), f"{key} {kname}: {int((got.view(np.uint32) != want.view(np.uint32)).sum())} of {len(want)} differ"
+    ctx.set_kernel(rto.KERNEL_AUTO)
+
+
 def test_octree_ray_skip_matches_oracle(ctx, orc, scenes, camera):
     """N1: the GPU form of octreeRaySkip, bit-exact distances vs the oracle's restatement of the recursion,
     on random rays, axis-aligned rays (the 1e-10 clamp, S/VR:83-87) and the reference's 7x7 probe pattern."""
@@ -1132,3 +1149,95 @@ def test_root_screen_rectangle_never_changes_pixels(ctx, orc, scenes):
         ctx.set_kernel(rto.KERNEL_PACKED)
         assert_bit_exact(ctx.render_host(f), want, f"root rectangle cam {(t, p, r, tgt, fov)}")
         np.testing.assert_array_equal(ctx.render_steps(f), orc.render_steps(s.nodes, s.min, s.voxel, view, pos, W / H, fov, W, H))
+
+
+def test_comm_one_rank_through_the_c_abi(ctx, orc, scenes):
+    """The multi-GPU path below the C boundary (rto_comm_*: render part -> ONE grouped ncclSend/ncclRecv -> assemble on rank 0),
+    driven with a one-rank RCCL communicator -- everything except traffic between GPUs: batches of 1 and 4 frames, six
+    submits in flight before the flush (the two buffer sets alternate), octree and triangle modes, bit-exact frames."""
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere64")
+    upload(ctx, s)
+    W, H = 417, 250
+    cams = [orc.Camera(0.5 + 0.3 * i, 0.7 + 0.05 * i, 1.8) for i in range(4)]
+    frames = [rto.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H) for c in cams]
+    wants = [oracle_frame(orc, s, c.get_view(), c.get_pos(), W, H)[0] for c in cams]
+    comm = hip.Comm(ctx, 1, 0, hip.comm_unique_id(), band_rows=16)
+    try:
+        out = torch.full((6, 4, H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+        arr4 = hip.Context.frame_array(frames)
+        for k in range(6):                                              # six batches of four frames, nothing waited for in between
+            comm.submit(arr4, out[k].data_ptr(), out.stride(1) * 4)
+        comm.flush()
+        for k in range(6):
+            for i in range(4):
+                assert_bit_exact(out[k, i].cpu().numpy(), wants[i], f"comm batch {k} frame {i}")
+        one = torch.full((H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+        for i in (2, 0, 3):                                             # batch size changes: buffers are re-made after a drain
+            comm.submit(hip.Context.frame_array([frames[i]]), one.data_ptr(), one.stride(0) * 4 * H)
+            comm.flush()
+            assert_bit_exact(one.cpu().numpy(), wants[i], f"comm single frame {i}")
+        # config 5's path through the same pipe
+        wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
+        ctx.build_leaf_triangles(s.grid.data)
+        for mode, shadow in ((hip.RESIDENT_TRIANGLES, False), (hip.RESIDENT_TRIANGLES_SHADOW, True)):
+            wtri, _ = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, cams[1].get_view(), cams[1].get_pos(), W / H, 45.0, W, H, shadow=shadow)
+            one.fill_(7.0)
+            comm.submit(hip.Context.frame_array([frames[1]]), one.data_ptr(), 0, mode)
+            comm.flush()
+            assert_bit_exact(one.cpu().numpy(), wtri, f"comm triangles mode {mode}")
+        with pytest.raises(rto.RtoError):
+            comm.submit(arr4, 0, 0)                                     # rank 0 without a frame buffer
+    finally:
+        comm.close()
+
+
+def test_comm_group_of_one_gpu_renders_into_the_resident_frame(ctx, orc, scenes, camera):
+    """rto_comm_create_all / rto_comm_render_resident_all (what RayTracerBVH::setDevices(n) drives) with the one GPU of
+    this box: the frame lands in rank 0's resident framebuffer; a second context on the same device is refused."""
+    s = scenes("sphere32")
+    view, pos = camera("sphere")
+    upload(ctx, s)
+    W, H = 320, 200
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, _ = oracle_frame(orc, s, view, pos, W, H)
+    grp = hip.CommGroup([ctx], band_rows=8)
+    try:
+        for _ in range(3):
+            grp.render_resident(f)
+        assert_bit_exact(ctx.download_resident(), want, "comm group, resident frame")
+    finally:
+        grp.close()
+    other = rto.Context(0)
+    try:
+        with pytest.raises(rto.RtoError):
+            hip.CommGroup([ctx, other])                                 # one context per GPU
+    finally:
+        other.close()
+
+
+def test_cpp_class_set_devices(orc, scenes):
+    """RayTracerBVH::setDevices: with one device the reference call sequence is unchanged; asking for more GPUs than the
+    box has fails loudly (no silent single-GPU fallback)."""
+    W, H = 200, 120
+    g = rto.VoxelGrid.test_sphere(32)
+    root = rto.createOctreeFromVoxelGrid(g)
+    cam = rto.Camera(0.5, 0.7, 1.8)
+    s = scenes("sphere32")
+    oc = orc.Camera(0.5, 0.7, 1.8)
+    want, _ = oracle_frame(orc, s, oc.get_view(), oc.get_pos(), W, H)
+    rt = rto.RayTracerBVH()
+    rt.setDevices(1)
+    rt.ensureComputeInitialized()
+    rt.setOctree(root, g)
+    rt.renderSceneComputeWithCulling(cam, W, H, W / H, 45.0, True)
+    assert_bit_exact(rt.framebuffer(), want, "C++ class, setDevices(1)")
+    import torch
+    if torch.cuda.device_count() < 2:
+        rt2 = rto.RayTracerBVH()
+        rt2.setDevices(2)
+        rt2.ensureComputeInitialized()
+        rt2.setOctree(root, g)
+        rt2.renderSceneCompute(cam, W, H, W / H, 45.0)
+        assert rt2.framebuffer() is None or len(rt2.framebuffer()) == 0
+    rto.freeOctree(root)

@@ -186,6 +186,52 @@ def test_octree_ray_skip_returns_a_solid_leaf_entry(orc, scenes):
     assert hits > 50
 
 
+RAY_SKIP_CASES = ("probe", "random", "inside", "axis_inside", "axis_outside0", "axis_outside1", "axis_outside2", "narrow")
+
+
+@pytest.mark.parametrize("scene", ["sphere32", "odd", "calgary"])
+def test_octree_ray_skip_equals_the_reference(orc, scenes, golden, scene):
+    """N1 pinned: tests/golden/ref_ray_skip.npz holds the distances the reference's OWN compiled octreeRaySkip returned
+    (453-skeleton/VolumeRaycastRenderer.cpp:50-155 through oracle/ref_shim_vr.cpp): the 7x7 probe rays of drawRaycast,
+    random rays from outside and inside, axis-parallel and nearly axis-parallel rays (the 1e-10 clamp, :83-87, and -0.0),
+    a narrowed [tMin, tMax] and two random visibility maps (:64-67).  The oracle must return the same float bits."""
+    z = golden("ref_ray_skip.npz")
+    s = scenes(scene)
+    finite = 0
+    for tag in RAY_SKIP_CASES + ("vis0", "vis1"):
+        key = f"{scene}_{tag}"
+        ro, rd, (tmin, tmax), want = z[key + "_ro"], z[key + "_rd"], z[key + "_t"], z[key + "_out"]
+        vis = None
+        if tag.startswith("vis"):
+            vis = np.unpackbits(z[key + "_flags"])[: len(s.nodes)]
+        got = orc.octree_ray_skip_many(s.nodes, s.min, s.voxel, ro, rd, float(tmin), float(tmax), visible=vis)
+        assert got.tobytes() == want.tobytes(), f"{key}: {int((got.view(np.uint32) != want.view(np.uint32)).sum())} of {len(want)} distances differ"
+        finite += int((want < 1e30).sum())
+    assert finite > 100
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/453-skeleton"), reason="reference checkout not present")
+def test_octree_ray_skip_against_live_reference_random_grids(orc):
+    """Where the reference sources exist: the oracle against the compiled octreeRaySkip itself, on random grids and rays."""
+    if not orc.refvr_available():
+        pytest.skip("oracle/_ref/libref_vr.so not built (make -C oracle refvr)")
+    rng = np.random.default_rng(321)
+    for dims, p in (((7, 5, 3), 0.5), ((16, 16, 16), 0.1), ((33, 9, 20), 0.7), ((2, 3, 1), 1.0)):
+        data = (rng.random((dims[2], dims[1], dims[0])) < p).astype(np.uint8)
+        g = orc.Grid(dims, np.array([0.5, -2.0, 3.0], np.float32), np.float32(0.3), data)
+        nodes = orc.build_flat_octree(g)
+        ro = np.array([4.0, 1.5, -3.0], np.float32)
+        rd = rng.normal(size=(200, 3)).astype(np.float32)
+        rd /= np.linalg.norm(rd, axis=1, keepdims=True).astype(np.float32)
+        rd[:6] = np.array([[1, 0, 0], [0, -1, 0], [0, 0, 1], [1e-11, 1, 0], [-0.0, 0, -1], [1, 1e-9, -1e-11]], np.float32)
+        flags = (rng.random(len(nodes)) < 0.8).astype(np.uint8)
+        flags[0] = 1
+        for vis in (None, flags):
+            want = orc.ref_octree_ray_skip(g, ro, rd, 0.0, 1e30, visible=vis)
+            got = orc.octree_ray_skip_many(nodes, g.min, g.voxel_size, ro, rd, 0.0, 1e30, visible=vis)
+            assert got.tobytes() == want.tobytes(), (dims, vis is not None)
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/453-skeleton"), reason="reference checkout not present")
 def test_oracle_against_live_reference_random_grids(orc):
     """Where the reference sources exist, compare against their compiled code directly on random grids."""
