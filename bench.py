@@ -15,8 +15,11 @@ N = 1    : one kernel launch per frame into a device framebuffer, one frame stri
            event pair around every kernel).
 N > 1    : `python3 bench.py --gpus N` starts N fresh ranks itself (python -m torch.distributed.run, one per GPU; the
            parent process never touches a GPU) and relays rank 0's line; launched under torch.distributed.run it is a
-           rank.  Every rank holds the octree, renders its round-robin bands, ONE gather per batch of frames lands the
-           image on rank 0, which re-interleaves it (strong scaling: one frame split N ways).
+           rank.  Every rank holds the octree and renders its round-robin bands; ONE grouped RCCL send/recv per batch of
+           frames lands the parts on rank 0, which re-interleaves them -- all of it below the C boundary (rto_comm_* in
+           include/rto_hip.h; torch.distributed only carries the 128-byte communicator id, the barriers and the max over
+           ranks).  Strong scaling: one frame split N ways.  --dist-backend gloo (+ --share-gpu) is the rehearsal path
+           through ray_tracing_octrees_amd.tilesplit (gather staged through host memory).
 
 Prints ONE JSON line on rank 0.  `roofline` prices the traversal kernel against the bound that holds -- VALU issue
 (wave-level VALU instructions from the committed PMC pass x 2 cycles on 1,024 SIMD-32 at 2.4 GHz) -- and keeps SURVEY
@@ -94,6 +97,8 @@ def parse_args(argv=None):
     ap.add_argument("--orbit-frames", type=int, default=None,
                     help="N=1, octree configs: extra figure with the camera orbiting 0.01 rad per frame, plain launches, launch-order "
                          "table rebuilt every --order-period-th frame (default 240; 0 = skip)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="N=1: drive the frames through rto_comm_* with a one-rank RCCL communicator (rehearses the N>1 code path on one GPU)")
     ap.add_argument("--launcher-dry-run", action="store_true", help="--gpus N without WORLD_SIZE: print the child command line and exit")
     return ap.parse_args(argv)
 
@@ -277,10 +282,8 @@ def main(argv=None):
 
         # a rank that dies must not leave the others waiting for ten minutes in a collective
         tmo = datetime.timedelta(seconds=180)
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
-        else:
-            dist.init_process_group("gloo", timeout=tmo)
+        # control plane only (communicator id, barriers, max over ranks): the frames travel through rto_comm_* (RCCL)
+        dist.init_process_group("gloo", timeout=tmo)
 
     # ---- scene ------------------------------------------------------------------------------------
     cfg = CONFIGS[args.config]
@@ -299,8 +302,18 @@ def main(argv=None):
                     "packed_v3": rto.KERNEL_PACKED_V3, "packed_v1": rto.KERNEL_PACKED_V1, "generic": rto.KERNEL_GENERIC}[args.kernel])
     ctx.set_launch_order(1 if args.order == "temporal" else 0, args.order_period)
     info = ctx.info()
-    pipelined = world > 1 and not args.no_pipeline
-    npipe = max(1, args.pipelines) if pipelined else 1
+    use_comm = (world > 1 and args.dist_backend == "nccl") or (world == 1 and args.force_comm)
+    pipelined = (world > 1 or args.force_comm) and not args.no_pipeline
+    npipe = (max(1, args.pipelines) if pipelined else 1) if not use_comm else 1
+    comm = None
+    if use_comm:
+        from ray_tracing_octrees_amd import hip as _hip
+
+        ids = [_hip.comm_unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(ids, src=0)
+        comm = _hip.Comm(ctx, world, rank, ids[0], band_rows=args.band_rows)
+        comm_mode = _hip.RESIDENT_TRIANGLES_SHADOW if triangles else _hip.RESIDENT_OCTREE
 
     def backend():
         return tilesplit.HipBackend(ctx, triangles=triangles, shadow=True)
@@ -325,8 +338,7 @@ def main(argv=None):
             torch.cuda.synchronize()
 
     def max_over_ranks(x: float) -> float:
-        dev = "cuda" if args.dist_backend == "nccl" else "cpu"
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -336,11 +348,27 @@ def main(argv=None):
     torch.cuda.set_stream(stream)
 
     fpg = max(1, args.frames_per_gather) if pipelined else 1
+    comm_frames = torch.empty((fpg, H, W, 4), dtype=torch.float32, device="cuda") if (use_comm and rank == 0) else None
+    comm_arr = rto.Context.frame_array([frame] * fpg) if use_comm else None
 
     def run_frames(n):
         """n frames.  With pipelines, batch j (fpg consecutive frames, one gather) goes to pipeline j % npipe -- the same
         order on every rank, so the collectives match; every frame is assembled on rank 0 before this returns."""
         img_ = None
+        if use_comm:
+            # rto_comm: batch k's grouped send/recv + assembly overlap batch k+1's render (two buffer sets, two HIP streams per
+            # rank, no host wait until the flush); --no-pipeline flushes after every batch
+            full, rest = divmod(n, fpg)
+            ptr = comm_frames.data_ptr() if rank == 0 else 0
+            stride = H * W * 16
+            for _ in range(full):
+                comm.submit(comm_arr, ptr, stride, comm_mode)
+                if not pipelined:
+                    comm.flush()
+            if rest:
+                comm.submit(rto.Context.frame_array([frame] * rest), ptr, stride, comm_mode)
+            comm.flush()
+            return comm_frames[(rest or fpg) - 1] if rank == 0 else None
         if not pipelined:
             for _ in range(n):
                 img_ = renderer.render(frame)
@@ -361,7 +389,7 @@ def main(argv=None):
 
     # ---- untimed: clock ramp (disclosed), then the W warm-up frames ------------------------------------
     ramp_frames = 0
-    if world == 1 and args.ramp_ms > 0:
+    if world == 1 and args.ramp_ms > 0 and not use_comm:
         t_end = time.perf_counter() + args.ramp_ms * 1e-3
         while time.perf_counter() < t_end:
             for _ in range(20):
@@ -379,7 +407,7 @@ def main(argv=None):
         for i in range(fif):
             render_to(bufs[i].data_ptr(), streams[i].cuda_stream)
         sync_all()
-    use_graph = world == 1 and fif == 1 and args.graph_frames > 0
+    use_graph = world == 1 and fif == 1 and args.graph_frames > 0 and not use_comm
     graph = None
     gframes = 0
     if use_graph:
@@ -407,7 +435,7 @@ def main(argv=None):
                 renderer.render(frame)
             sync_all()
     if not use_graph:
-        ctx.timing_begin(args.steps if not triangles else 0)  # HIP event pair around every traversal kernel, on its launch stream, no syncs
+        ctx.timing_begin(args.steps if not (triangles or use_comm) else 0)  # HIP event pair around every traversal kernel, on its launch stream, no syncs
     sync_all()
     t0 = time.perf_counter()
     if use_graph:
@@ -424,11 +452,11 @@ def main(argv=None):
             render_to(bufs[k % fif].data_ptr(), s_.cuda_stream)
             img = bufs[k % fif]
     else:
-        if world == 1 and triangles:
+        if world == 1 and triangles and not use_comm:
             ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev_a.record(stream)
         img = run_frames(args.steps)
-        if world == 1 and triangles:
+        if world == 1 and triangles and not use_comm:
             ev_b.record(stream)
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -455,7 +483,7 @@ def main(argv=None):
             # kernel, so the figure below is a lower bound of the algorithmic bytes.
             tri_note = " (config 5: pops of the primary AND the shadow traversal; triangle bytes not included)"
         roofline = None
-        if world == 1:
+        if world == 1 and not use_comm:
             if use_graph or triangles:
                 # one HIP event pair around the whole timed region, on the launch stream: GPU time per frame = the
                 # traversal kernel + the gap between consecutive launches (an upper bound of the kernel's own duration)
@@ -512,7 +540,7 @@ def main(argv=None):
                 roofline["note"] = (f"no PMC entry for config {args.config} / {kernel_name} / {order_key} in profiles/pmc_counters.json: "
                                     "achieved and frac cannot be stated for this combination")
         orbit = None
-        if world == 1 and not triangles and fif == 1:
+        if world == 1 and not triangles and fif == 1 and not use_comm:
             n_orbit = 240 if args.orbit_frames is None else args.orbit_frames
             if n_orbit > 0:
                 # a camera that moves: theta advances 0.01 rad per frame, plain stream launches (no graph), the launch-order
@@ -585,11 +613,13 @@ def main(argv=None):
             "config": {
                 "workload": f"BASELINE config {args.config}: {what}, octree to min-leaf 1 ({info.num_nodes} nodes), "
                             f"{W}x{H} primary rays{', Marching-Cubes leaf triangles + 1 shadow ray per hit' if triangles else ''}, {camtxt}, fov 45",
-                "parallelism": (("1 GPU" + (f", frames replayed from a HIP graph of {gframes} consecutive frames" if use_graph else ", plain stream launches")) if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else f"screen split over {world} GPUs, {args.band_rows}-row bands "
+                "parallelism": (("1 GPU" + (f", frames replayed from a HIP graph of {gframes} consecutive frames" if use_graph else ", plain stream launches")) if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else
+                               (f"screen split over {world} GPUs, {args.band_rows}-row bands round-robin, rto_comm_submit: ONE grouped RCCL send/recv per {'frame' if fpg == 1 else f'{fpg} frames'} "
+                                f"into rank 0 (4-byte Lambert term per pixel), batch k's gather overlaps batch k+1's render" if use_comm else "") + ("" if use_comm else f"screen split over {world} GPUs, {args.band_rows}-row bands "
                                                           f"round-robin, 1 RCCL gather per {'frame' if fpg == 1 else f'{fpg} frames'} ({'4-byte Lambert term' if args.payload == 'shade' else 'RGBA32F'} per pixel"
                                                           f"{', gather k overlaps render k+1' if pipelined else ''}"
                                                           f"{f', {fpg} consecutive frames per gather' if fpg > 1 else ''}"
-                                                          f"{f', {npipe} such pipelines on {npipe} HIP streams take the batches in turn' if npipe > 1 else ''})",
+                                                          f"{f', {npipe} such pipelines on {npipe} HIP streams take the batches in turn' if npipe > 1 else ''})"),
                 "kernel": args.kernel,
                 "clock_ramp": (f"{ramp_frames} untimed frames of the same workload ({args.ramp_ms:.0f} ms) before the {args.warmup} warm-up frames, "
                                "so that a cold GPU has reached its working clock") if ramp_frames else "none",
@@ -609,6 +639,8 @@ def main(argv=None):
             result["speedup_vs_cpu_all_cores"] = round(result["value"] / cpu["value"], 1)
         print(json.dumps(result), flush=True)
 
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -530,10 +530,15 @@ int rto_debug_set_tile_order(rto_context* c, const int32_t* host_order, int64_t 
     }
     if (it == c->orders.end() || n != it->second.tiles || !it->second.d_tileOrder)
         return fail(c, RTO_E_INVALID, "rto_debug_set_tile_order: render one frame first; n must equal the tile count");
-    for (int64_t i = 0; i < n; i++)
+    const int tilesX = (int)((it->second.key[0] + 7) / 8);                 // key[0] = W of the frames the tables belong to
+    if (tilesX <= 0 || tilesX > 0xffff || n / tilesX > 0xffff) return fail(c, RTO_E_INVALID, "rto_debug_set_tile_order: frame too large for packed entries");
+    std::vector<int> packed((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
         if (host_order[i] < 0 || host_order[i] >= n) return fail(c, RTO_E_INVALID, "rto_debug_set_tile_order: entry out of range");
+        packed[(size_t)i] = (host_order[i] % tilesX) | ((host_order[i] / tilesX) << 16);      // the kernels' slot table holds tx | ty << 16
+    }
     RTO_HIP(c, hipDeviceSynchronize());
-    RTO_HIP(c, hipMemcpy(it->second.d_tileOrder, host_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    RTO_HIP(c, hipMemcpy(it->second.d_tileOrder, packed.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
     it->second.fixed = true; it->second.valid = true;
     return RTO_OK;
 }
@@ -933,7 +938,8 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             const bool frameMode = MODE == kModeColor || MODE == kModeShade;
             const long key[6] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles };
             rto_context::OrderState* st = order_state(c, s, capturing);      // this stream's scheduling state
-            rto_context::OrderState* o = (c->orderPolicy == RTO_ORDER_TEMPORAL && (frameMode || MODE == kModeTimeline)) ? st : nullptr;
+            rto_context::OrderState* o = (c->orderPolicy == RTO_ORDER_TEMPORAL && (frameMode || MODE == kModeTimeline) &&
+                                          P.tilesX <= 0xffff && P.tilesY <= 0x7fff) ? st : nullptr;      // table entries are tx | ty << 16
             if (o) {
                 c->lastOrderStream = s;
                 if (o->tiles != tiles) {

@@ -70,8 +70,8 @@ struct RenderParams {
     int orderCx, orderCy;           // tile nearest the projected scene centre: tiles launch centre-out (heavy first)
     int rootX0, rootY0, rootX1, rootY1;   // pixel rectangle (inclusive, GLOBAL rows) outside of which no ray can meet the root box
     int solidX0, solidY0, solidX1, solidY1;   // the same for the bounding box of the solid leaves (host side: replaces root* for colour / shade frames)
-    const int* tileOrder;           // launch slot -> tile (row-major id over tilesX x tilesY): the tiles of the box below, costliest
-                                    // tiles of an EARLIER frame first (null: centre-out over the box)
+    const int* tileOrder;           // launch slot -> tile as tx | ty << 16: the tiles of the box below, costliest tiles of an EARLIER
+                                    // frame first (null: centre-out over the box)
     int* tileCost;                  // tile -> loop trip count of its wave in THIS frame (null: not recorded)
     // Launch geometry of the packed kernels.  Only tiles of the box [boxX0, boxX0+boxW) x [boxY0, boxY0+boxH) -- the tile
     // bounding box of the root rectangle, rounded outwards -- get a wave (traceWaves = boxW*boxH).  With skipOutside
@@ -521,12 +521,15 @@ __device__ __forceinline__ void tile_of(const RenderParams& P, int t, int& tx, i
     tx = P.boxX0 + unrank_centre_out(colRank, min(max(P.orderCx - P.boxX0, 0), P.boxW - 1), P.boxW);
 }
 
-// Launch slot -> tile.  Slots >= traceWaves exist only to share the fill duty (tiny boxes): no tile.
+// Launch slot -> tile.  Slots >= traceWaves exist only to share the fill duty (tiny boxes): no tile.  `slot` must be
+// wave-uniform in a scalar register (the kernels pass it through readfirstlane): the table entry is then a scalar load and
+// none of this costs VALU issue (as a per-lane value the old `tile / tilesX` was a 30-instruction VALU division per wave).
 __device__ __forceinline__ bool resolve_slot(const RenderParams& P, int slot, int& tx, int& ty, int& tile) {
     tx = 0; ty = P.tilesY; tile = 0;
     if (slot >= P.traceWaves) return false;
-    if (P.tileOrder) { tile = P.tileOrder[slot]; ty = tile / P.tilesX; tx = tile - ty * P.tilesX; }
-    else { tile_of(P, slot, tx, ty); tile = ty * P.tilesX + tx; }
+    if (P.tileOrder) { const unsigned e = (unsigned)P.tileOrder[slot]; tx = (int)(e & 0xffffu); ty = (int)(e >> 16); }   // entries are tx | ty << 16
+    else tile_of(P, slot, tx, ty);
+    tile = ty * P.tilesX + tx;
     return true;
 }
 
@@ -794,7 +797,7 @@ __global__ __launch_bounds__(kBlock, RTO_PACKED3_WAVES) void k_trace_packed3(Ren
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint2* stk = lds_stack + (size_t)wave * P.depth * kWave + lane;
-    const int slot = blockIdx.x * (kBlock / kWave) + wave;
+    const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
     if (slot >= P.launchWaves) return;
     trace_tile_packed3<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
 }
@@ -1060,7 +1063,7 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean(RenderPar
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64], b in [0, depth]
-    const int slot = blockIdx.x * (kBlock / kWave) + wave;
+    const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
     if (slot >= P.launchWaves) return;
     trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
 }
@@ -1079,7 +1082,7 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_persisten
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;
     const int tiles = P.launchWaves;
     const int firstFree = gridDim.x * (kBlock / kWave);
-    int slot = blockIdx.x * (kBlock / kWave) + wave;
+    int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
     int left = 1;                                              // slots of the current chunk still to render
     while (slot < tiles) {                                     // wave-uniform; ends once the counter has run past the last slot
         trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
@@ -1098,7 +1101,7 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_persisten
 // Launch order of the box's tiles: a counting sort by descending cost (trip count an earlier frame recorded, 64
 // buckets of min(trips, 63)) done by ONE 1,024-thread block -- a few thousand tiles, no inter-block state: whatever the
 // cost array holds (stale values, tiles that were outside the box when it was written), the result is a permutation of
-// the box's tiles, so every tile is rendered exactly once.  The buckets are staged in LDS first (one pass of independent,
+// the box's tiles (entries tx | ty << 16), so every tile is rendered exactly once.  The buckets are staged in LDS first (one pass of independent,
 // coalesced loads: reading the costs inside the counting loops cost a dependent global load per step, 80 us per build);
 // wave w then owns the id range [w*chunk, (w+1)*chunk) of the box (ids row-major over boxW x boxH) and counts / places
 // its tiles with LDS atomics.  Tiles of one bucket keep their wave order; within a wave the order is the atomics'.
@@ -1143,7 +1146,7 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_build(const int* __restri
         const int pos = atomicAdd(&cnt[wave][bucket_of(i)], 1);
         // cannot fall outside by construction (both passes see the same buckets: the kernel that writes the costs runs
         // before or after this one on the stream, never beside it); refused writes are counted and tests assert 0
-        if (pos >= 0 && pos < n) order[pos] = tile_of_id(i);
+        if (pos >= 0 && pos < n) { const int ry = i / boxW, rx = i - ry * boxW; order[pos] = (boxX0 + rx) | ((boxY0 + ry) << 16); }
         else atomicAdd(violations, 1);
     }
 }

@@ -1,0 +1,40 @@
+"""bench.py --gpus N as the driver types it: the parent process touches no GPU, starts N fresh ranks as CHILD processes
+(python -m torch.distributed.run, rendezvous on 127.0.0.1), relays rank 0's single JSON line and exits with the
+children's status -- loudly non-zero on any failure (here: no GPU in this container)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def test_parent_builds_the_torchrun_command_line():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "20", "--warmup", "5", "--launcher-dry-run"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr
+    cmd = json.loads(p.stdout.strip().splitlines()[-1])["launcher"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 <= int(cmd[cmd.index("--master-port") + 1]) <= 65535
+    i = cmd.index(BENCH)
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5", "--launcher-dry-run"]     # the ranks get the caller's arguments
+
+
+def test_a_rank_under_torchrun_does_not_launch_again():
+    """WORLD_SIZE set => this process IS a rank: it must not start another job (it fails later for lack of a GPU)."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launcher-dry-run"], capture_output=True, text=True, env=env, timeout=300)
+    assert "launcher" not in p.stdout
+    assert p.returncode != 0 and "no GPU visible" in (p.stderr + p.stdout)
+
+
+def test_failing_ranks_give_a_loud_non_zero_exit():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode != 0
+    assert "2-rank job failed" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]        # no result line on failure
