@@ -101,6 +101,8 @@ def lib():
     L.orc_cull_compact.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, C.c_float, C.c_float,
                                    C.c_void_p, C.c_void_p]
     L.orc_cull_compact.restype = C.c_int64
+    L.orc_cull_compact_planes.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_cull_compact_planes.restype = C.c_int64
     L.orc_render.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float,
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_Stats), C.c_int]
     L.orc_render_steps.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float,
@@ -231,6 +233,16 @@ def cull_compact(nodes, grid_min, voxel_size, view, fov_deg, aspect):
     vis = np.zeros(len(nodes), np.uint8)
     n = lib().orc_cull_compact(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size), _f32(view),
                                float(fov_deg), float(aspect), out.ctypes.data, vis.ctypes.data)
+    return out[:n].copy(), vis.astype(bool)
+
+
+def cull_compact_planes(nodes, grid_min, voxel_size, planes, margin):
+    """The reference's visibility loop + compaction (RayTracerBVH.cpp:743-802) for caller-supplied planes and margin."""
+    nodes = np.ascontiguousarray(nodes)
+    out = np.zeros(len(nodes), NODE_DTYPE)
+    vis = np.zeros(len(nodes), np.uint8)
+    n = lib().orc_cull_compact_planes(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size), _f32(planes).reshape(24),
+                                      float(margin), out.ctypes.data, vis.ctypes.data)
     return out[:n].copy(), vis.astype(bool)
 
 

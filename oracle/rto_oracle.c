@@ -434,13 +434,9 @@ void orc_free(void* p) { free(p); }
 /* ------------------------------------------------------------------ */
 /* Frustum-culling compaction (S/RayTracerBVH.cpp:731-802)              */
 /* ------------------------------------------------------------------ */
-int64_t orc_cull_compact(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
-                         const float view[16], float fovDeg, float aspect,
-                         orc_node* out, uint8_t* visible) {
-    float proj[16], vp[16], planes[24];
-    orc_perspective(orc_radians(fovDeg), aspect, 0.01f, 5000.f, proj);   /* :733 */
-    orc_mat4_mul(proj, view, vp);                                          /* :734 */
-    orc_frustum_planes(vp, planes);
+/* the loop + compaction for given planes and margin (the reference derives them at :731-734, :755) */
+int64_t orc_cull_compact_planes(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                                const float planes[24], float margin, orc_node* out, uint8_t* visible) {
     uint8_t* vis = visible ? visible : (uint8_t*)malloc((size_t)n);
     int32_t* remap = (int32_t*)malloc((size_t)n * sizeof(int32_t));
     int64_t count = 0;
@@ -450,7 +446,7 @@ int64_t orc_cull_compact(const orc_node* nodes, int64_t n, const float gridMin[3
         float mn[3] = { gridMin[0] + nd->x * voxelSize, gridMin[1] + nd->y * voxelSize, gridMin[2] + nd->z * voxelSize };
         float ext = nd->size * voxelSize;
         float mx[3] = { mn[0] + ext, mn[1] + ext, mn[2] + ext };
-        vis[i] = orc_frustum_test_aabb(planes, mn, mx, 150.0f) != -1;     /* :755-761 */
+        vis[i] = orc_frustum_test_aabb(planes, mn, mx, margin) != -1;     /* :755-761 */
     }
     for (int64_t i = 0; i < n; i++) remap[i] = vis[i] ? (int32_t)count++ : -1;   /* :765-772 */
     for (int64_t i = 0; i < n; i++) {                                              /* :778-802 */
@@ -467,6 +463,16 @@ int64_t orc_cull_compact(const orc_node* nodes, int64_t n, const float gridMin[3
     free(remap);
     if (!visible) free(vis);
     return count;
+}
+
+int64_t orc_cull_compact(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                         const float view[16], float fovDeg, float aspect,
+                         orc_node* out, uint8_t* visible) {
+    float proj[16], vp[16], planes[24];
+    orc_perspective(orc_radians(fovDeg), aspect, 0.01f, 5000.f, proj);   /* :733 */
+    orc_mat4_mul(proj, view, vp);                                          /* :734 */
+    orc_frustum_planes(vp, planes);
+    return orc_cull_compact_planes(nodes, n, gridMin, voxelSize, planes, 150.0f, out, visible);   /* margin: :755 */
 }
 
 /* ------------------------------------------------------------------ */

@@ -90,6 +90,8 @@ int  orc_frustum_test_aabb(const float planes[24], const float bmin[3], const fl
 /* ---- culling compaction (S/RayTracerBVH.cpp:731-802) -------------------- */
 /* out must hold n nodes; visible[] (n bytes, optional) gets the per-node flag.
  * Returns the visible count. */
+int64_t orc_cull_compact_planes(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                                const float planes[24], float margin, orc_node* out, uint8_t* visible);
 int64_t orc_cull_compact(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
                          const float view[16], float fovDeg, float aspect,
                          orc_node* out, uint8_t* visible);

@@ -370,6 +370,103 @@ def test_frustum_update_equals_reference_compaction(ctx, orc, scenes, camera, ca
         assert_bit_exact(ctx.render_host(f2), full, f"culling off {kname}")
 
 
+def test_culled_root_with_surviving_descendants_follows_the_reference(ctx, orc):
+    """A7, literally (RayTracerBVH.cpp:765-812): when the frustum test drops the ROOT but keeps descendants, the reference's
+    compacted array starts with whatever visible node comes first, and its traversal starts there.  Nested boxes make that
+    impossible in exact arithmetic; in float it needs a plane through a corner where the root's nodeMax and a child's differ
+    by an ulp (gridMin + 0*vs + size*vs vs (gridMin + x*vs) + half*vs).  The debug hook injects such a plane; every
+    kernel choice must then render what the oracle renders from the compacted array (the packed kernels hand the frame to
+    the generic kernel over the compacted array)."""
+    rng = np.random.default_rng(4)
+    found = None
+    for _ in range(4000):
+        dim = 16
+        gmin = rng.uniform(-60, 60, 3).astype(np.float32)
+        vs = np.float32(rng.choice([0.7, 3.3, 0.37, 1.9]))
+        for a in range(3):
+            root_mx = np.float32(np.float32(gmin[a] + np.float32(0) * vs) + np.float32(dim) * vs)
+            child_mx = np.float32(np.float32(gmin[a] + np.float32(dim // 2) * vs) + np.float32(dim // 2) * vs)
+            if child_mx > root_mx:
+                found = (gmin, vs, a, root_mx, child_mx)
+                break
+        if found:
+            break
+    assert found, "no grid origin / voxel size with the rounding difference found"
+    gmin, vs, a, root_mx, child_mx = found
+    data = (rng.random((16, 16, 16)) < 0.35).astype(np.uint8)
+    # the survivors are the root's children on the far side of `a`; the first of them in BFS order (octant 1 << a) becomes
+    # index 0 of the compacted array, where the reference's traversal starts: make it a solid leaf so that there is something to see
+    sl = [slice(0, 8)] * 3                               # data is [z][y][x]
+    sl[2 - a] = slice(8, 16)
+    data[tuple(sl)] = 1
+    g = orc.Grid((16, 16, 16), gmin, vs, data)
+    nodes = orc.build_flat_octree(g)
+    s = Scene(g, nodes)
+    upload(ctx, s)
+    planes = np.zeros((6, 4), np.float32)
+    planes[:, 3] = 1.0                                  # five planes that keep everything: 0*x + 0*y + 0*z + 1 >= 0
+    planes[0, :3] = 0.0
+    planes[0, a] = 1.0
+    planes[0, 3] = -child_mx                            # n = +axis: the positive vertex is nodeMax[a] (+ margin 0)
+    want_nodes, vis = orc.cull_compact_planes(nodes, gmin, vs, planes, 0.0)
+    assert not vis[0] and vis.any(), "the construction must cull the root and keep descendants"
+    ctx.debug_update_frustum_planes(planes, 0.0)
+    assert ctx.info().visible_nodes == len(want_nodes)
+    assert ctx.download_visible_nodes().tobytes() == want_nodes.tobytes()
+    ext = np.float32(16) * vs
+    cam = orc.Camera(0.6, 0.8, float(2.2 * ext))
+    cam.set_target(*[float(x) for x in (gmin + np.float32(0.5) * ext)])
+    W, H = 200, 150
+    view, pos = cam.get_view(), cam.get_pos()
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, st = orc.render(want_nodes, gmin, vs, view, pos, W / H, 45.0, W, H)
+    assert st["hits"] > 0, "the surviving subtree must be visible from this camera"
+    try:
+        for kname, kernel in KERNELS:
+            ctx.set_kernel(kernel)
+            assert_bit_exact(ctx.render_host(f), want, f"culled root, {kname}")
+            gs = ctx.frame_stats(f)
+            assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"]), kname
+    finally:
+        ctx.set_kernel(rto.KERNEL_AUTO)
+        ctx.update_frustum(view, 45.0, W / H, enable=False)
+
+
+def test_persistent_kernel_in_a_graph_with_an_odd_frame_count(ctx, orc, scenes):
+    """The persistent-threads kernel takes launch slots from a global counter; every launch zeroes its own counter with a
+    memset node, so a captured sequence of ANY length replays exactly (an odd number of frames used to leave the next
+    replay an exhausted counter).  Buffers are poisoned between replays."""
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere64")
+    upload(ctx, s)
+    W, H = 640, 360
+    cams = [orc.Camera(0.5 + 0.25 * i, 0.7, 1.8) for i in range(3)]
+    frames = [rto.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H) for c in cams]
+    wants = [oracle_frame(orc, s, c.get_view(), c.get_pos(), W, H)[0] for c in cams]
+    bufs = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
+    stream = torch.cuda.Stream()
+    try:
+        ctx.set_kernel(rto.KERNEL_PACKED_PERSISTENT)
+        for _ in range(3):
+            ctx.render_device(frames[0], bufs[0].data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            with torch.cuda.graph(g, stream=stream):
+                for k in range(7):                                   # odd
+                    ctx.render_device(frames[k % 3], bufs[k % 3].data_ptr(), None, stream.cuda_stream)
+            for rep in range(3):
+                for b in bufs:
+                    b.fill_(7.0)
+                g.replay()
+                torch.cuda.synchronize()
+                for i in range(3):
+                    assert_bit_exact(bufs[i].cpu().numpy(), wants[i], f"persistent kernel, replay {rep}, camera {i}")
+        assert ctx.debug_sort_violations() == 0
+    finally:
+        ctx.set_kernel(rto.KERNEL_AUTO)
+
+
 def test_frustum_update_that_culls_nothing_and_everything(ctx, orc, scenes, camera):
     s = scenes("sphere32")
     view, pos = camera("sphere")
@@ -571,6 +668,7 @@ def test_frames_in_flight_on_several_streams_of_one_context(ctx, orc, scenes):
             torch.cuda.synchronize()
             for i in range(3):
                 assert_bit_exact(bufs[i].cpu().numpy(), wants[i], f"stream {i}, period {period}")
+            assert ctx.debug_sort_violations() == 0
     finally:
         ctx.set_launch_order(1, 8)
 
@@ -644,6 +742,7 @@ def test_frames_captured_in_a_hip_graph_replay_exactly(ctx, orc, scenes):
             ctx.render_device(frames[1], bufs[1].data_ptr(), None, stream.cuda_stream)
         torch.cuda.synchronize()
         assert_bit_exact(bufs[1].cpu().numpy(), wants[1], "plain launches after the graph")
+        assert ctx.debug_sort_violations() == 0
     finally:
         ctx.set_launch_order(1, 8)
 
