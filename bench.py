@@ -466,6 +466,24 @@ def main(argv=None):
     # ---- everything below is outside the timed region ---------------------------------------------
     rays = W * H
     result = None
+    latency = None
+    if use_comm:
+        # single-frame latency of the split: one frame per collective, the host waits for the assembled frame before it
+        # submits the next (what an interactive viewer sees); the timed region above is the batched, pipelined throughput
+        one = rto.Context.frame_array([frame])
+        ptr = comm_frames.data_ptr() if rank == 0 else 0
+        for _ in range(5):
+            comm.submit(one, ptr, H * W * 16, comm_mode); comm.flush()
+        sync_all()
+        n_lat = 40
+        t_l = time.perf_counter()
+        for _ in range(n_lat):
+            comm.submit(one, ptr, H * W * 16, comm_mode); comm.flush()
+        lat = (time.perf_counter() - t_l) / n_lat
+        if dist is not None:
+            lat = max_over_ranks(lat)
+        latency = {"ms_per_frame": round(lat * 1e3, 5), "frames": n_lat,
+                   "what": "rto_comm_submit of ONE frame + rto_comm_flush per frame: render part -> grouped send/recv -> assemble, host waits for each frame"}
     if rank == 0:
         kernel_name = KERNEL_NAMES[args.kernel] if info.canonical else "k_trace_generic"
         if triangles:
@@ -499,7 +517,7 @@ def main(argv=None):
             torch.cuda.synchronize()
             pair_overhead = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
             hbm_alg = rays * bytes_per_ray / (k_avg * 1e-3) / 1e9
-            order_key = "centre-out" if (args.order != "temporal" or triangles) else "temporal"
+            order_key = "centre-out" if args.order != "temporal" else "temporal"
             pmc = pmc_entry(args.config, kernel_name, order_key)
             roofline = {
                 "bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s", "frac": None,
@@ -632,6 +650,8 @@ def main(argv=None):
             result["roofline"] = roofline
         if orbit is not None:
             result["orbit"] = orbit
+        if latency is not None:
+            result["single_frame_latency"] = latency
         if pcie is not None:
             result["pcie_inclusive"] = pcie
         if cpu is not None:

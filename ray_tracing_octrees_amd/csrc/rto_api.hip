@@ -60,7 +60,7 @@ struct rto_context {
         int* d_tileCost = nullptr;      // tile -> trip count of the last colour / shade frame that rendered it (row-major over all tiles)
         int* d_tileOrder = nullptr;     // launch slot -> tile: a permutation of the tiles of `box`
         int tiles = 0;                  // tile count the buffers are sized for
-        long key[6] = { 0, 0, 0, 0, 0, 0 };   // W, H, numParts, part, bandRows, tiles of the frames the history belongs to
+        long key[7] = { 0, 0, 0, 0, 0, 0, 0 };   // W, H, numParts, part, bandRows, tiles, path (0 octree / 1 triangles) of the frames the history belongs to
         bool costValid = false;         // a frame of this geometry has recorded its costs
         bool valid = false;             // d_tileOrder holds a table for `box`
         int box[4] = { 0, 0, 0, 0 };    // the tile box the table enumerates
@@ -851,8 +851,10 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
         else {
             double slo[3], shi[3];
             for (int a = 0; a < 3; a++) {
-                slo[a] = (double)c->gridMin[a] + (double)c->solidLo[a] * (double)c->voxelSize;
-                shi[a] = (double)c->gridMin[a] + (double)c->solidHi[a] * (double)c->voxelSize;
+                // widened by one voxel: the Marching-Cubes triangles of the surface cells (config 5) reach half a voxel beyond
+                // the solid leaves; one rectangle serves both paths
+                slo[a] = (double)c->gridMin[a] + (double)(c->solidLo[a] - 1) * (double)c->voxelSize;
+                shi[a] = (double)c->gridMin[a] + (double)(c->solidHi[a] + 1) * (double)c->voxelSize;
             }
             screen_rectangle(f, P, slo, shi, r);
             P.solidX0 = std::max(r[0], P.rootX0); P.solidY0 = std::max(r[1], P.rootY0);
@@ -910,6 +912,64 @@ static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, bool 
     return st;
 }
 
+// Launch geometry + launch order of one frame of the packed kernels on stream `s` (shared by the octree and the triangle
+// path): waves for the tiles of `rect`'s box only, the outside shared out as fill chunks, the box's tiles in the order of
+// the costs earlier frames recorded.  frameMode: a colour / shade frame (records costs); otherwise (instrumentation) the
+// whole image keeps one wave per tile.  On return Q holds the geometry, the table and the cost pointer.
+static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool frameMode, bool timelineMode, int path, const int rect[4],
+                            RenderParams& Q, rto_context::OrderState** stOut) {
+    const RenderParams& P = Q;
+    const int tiles = P.tilesX * P.tilesY;
+    Q.tileOrder = nullptr; Q.tileCost = nullptr;
+    const long key[7] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles, path };
+    rto_context::OrderState* st = order_state(c, s, capturing);      // this stream's scheduling state
+    *stOut = st;
+    rto_context::OrderState* o = (c->orderPolicy == RTO_ORDER_TEMPORAL && (frameMode || timelineMode) &&
+                                  P.tilesX <= 0xffff && P.tilesY <= 0x7fff) ? st : nullptr;      // table entries are tx | ty << 16
+    if (o) {
+        c->lastOrderStream = s;
+        if (o->tiles != tiles) {
+            if (capturing)
+                return fail(c, RTO_E_UNSUPPORTED, "render: the first frame of a new size on a stream allocates its launch-order "
+                                                  "tables; render one such frame before hipStreamBeginCapture");
+            // hipFree waits for the device: no kernel still reads the old tables
+            (void)hipFree(o->d_tileCost); (void)hipFree(o->d_tileOrder);
+            o->d_tileCost = o->d_tileOrder = nullptr; o->tiles = 0;
+            RTO_HIP(c, hipMalloc(&o->d_tileCost, (size_t)tiles * sizeof(int)));
+            RTO_HIP(c, hipMalloc(&o->d_tileOrder, (size_t)tiles * sizeof(int)));
+            o->tiles = tiles; o->valid = false; o->costValid = false; o->fixed = false;
+        }
+        if (std::memcmp(key, o->key, sizeof key) != 0) { o->valid = false; o->costValid = false; o->fixed = false; std::memcpy(o->key, key, sizeof key); }
+    }
+    // launch geometry: frames get waves for the rectangle's tiles only and share the outside region out as wide stores;
+    // instrumentation modes and caller-supplied orders keep one wave per tile of the image
+    if ((frameMode || timelineMode) && !(o && o->fixed)) {
+        // a frame only needs the pixels that can meet SOLID geometry: every other ray is black whatever it pops on the way
+        // (S/RT:363), so the rectangle of the solid leaves' bounding box replaces the root box's
+        Q.rootX0 = rect[0]; Q.rootY0 = rect[1]; Q.rootX1 = rect[2]; Q.rootY1 = rect[3];
+        root_rectangle_box(Q, 8 * c->numCUs);
+    }
+    if (o) {
+        const int box[4] = { Q.boxX0, Q.boxY0, Q.boxW, Q.boxH };
+        // The table is a scheduling hint rebuilt from the costs the previous frames recorded: when the box moved
+        // (camera) or every orderPeriod-th frame.  k_order_build emits a permutation of the box's tiles whatever the
+        // cost array holds and keeps no state between calls, so rebuilding inside a stream capture is safe too.
+        if (!o->fixed && Q.traceWaves > 0 && (!o->valid || std::memcmp(box, o->box, sizeof box) != 0 || o->age >= c->orderPeriod)) {
+            if (o->costValid) {
+                const int staged = Q.traceWaves <= kOrderLdsTiles ? 1 : 0;
+                hipLaunchKernelGGL(k_order_build, dim3(1), dim3(kOrderBlock), staged ? (size_t)((Q.traceWaves + 15) & ~15) : 0, s, o->d_tileCost, Q.tilesX,
+                                   Q.boxX0, Q.boxY0, Q.boxW, Q.boxH, staged, o->d_tileOrder, c->d_sortViolations);
+                std::memcpy(o->box, box, sizeof box);
+                o->valid = true; o->age = 0;
+            } else o->valid = false;
+        }
+        Q.tileOrder = (o->valid && Q.traceWaves > 0) ? o->d_tileOrder : nullptr;
+        if (frameMode && !o->fixed) { Q.tileCost = o->d_tileCost; o->costValid = true; }
+        if (frameMode) o->age++;
+    }
+    return RTO_OK;
+}
+
 template <int MODE>
 static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hipStream_t s) {
     const int tiles = P.tilesX * P.tilesY;
@@ -934,52 +994,12 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
         } else {
             RenderParams Q = P;
-            Q.tileOrder = nullptr; Q.tileCost = nullptr;
             const bool frameMode = MODE == kModeColor || MODE == kModeShade;
-            const long key[6] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles };
-            rto_context::OrderState* st = order_state(c, s, capturing);      // this stream's scheduling state
-            rto_context::OrderState* o = (c->orderPolicy == RTO_ORDER_TEMPORAL && (frameMode || MODE == kModeTimeline) &&
-                                          P.tilesX <= 0xffff && P.tilesY <= 0x7fff) ? st : nullptr;      // table entries are tx | ty << 16
-            if (o) {
-                c->lastOrderStream = s;
-                if (o->tiles != tiles) {
-                    if (capturing)
-                        return fail(c, RTO_E_UNSUPPORTED, "render: the first frame of a new size on a stream allocates its launch-order "
-                                                          "tables; render one such frame before hipStreamBeginCapture");
-                    // hipFree waits for the device: no kernel still reads the old tables
-                    (void)hipFree(o->d_tileCost); (void)hipFree(o->d_tileOrder);
-                    o->d_tileCost = o->d_tileOrder = nullptr; o->tiles = 0;
-                    RTO_HIP(c, hipMalloc(&o->d_tileCost, (size_t)tiles * sizeof(int)));
-                    RTO_HIP(c, hipMalloc(&o->d_tileOrder, (size_t)tiles * sizeof(int)));
-                    o->tiles = tiles; o->valid = false; o->costValid = false; o->fixed = false;
-                }
-                if (std::memcmp(key, o->key, sizeof key) != 0) { o->valid = false; o->costValid = false; o->fixed = false; std::memcpy(o->key, key, sizeof key); }
-            }
-            // launch geometry: frames get waves for the root rectangle's tiles only and share the outside region out
-            // as wide stores; instrumentation modes and caller-supplied orders keep one wave per tile of the image
-            if ((frameMode || MODE == kModeTimeline) && !(o && o->fixed)) {
-                // a frame only needs the pixels that can meet a SOLID leaf: every other ray is black whatever it pops on the
-                // way (S/RT:363), so the rectangle of the solid leaves' bounding box replaces the root box's
-                Q.rootX0 = P.solidX0; Q.rootY0 = P.solidY0; Q.rootX1 = P.solidX1; Q.rootY1 = P.solidY1;
-                root_rectangle_box(Q, 8 * c->numCUs);
-            }
-            if (o) {
-                const int box[4] = { Q.boxX0, Q.boxY0, Q.boxW, Q.boxH };
-                // The table is a scheduling hint rebuilt from the costs the previous frames recorded: when the box moved
-                // (camera) or every orderPeriod-th frame.  k_order_build emits a permutation of the box's tiles whatever the
-                // cost array holds and keeps no state between calls, so rebuilding inside a stream capture is safe too.
-                if (!o->fixed && Q.traceWaves > 0 && (!o->valid || std::memcmp(box, o->box, sizeof box) != 0 || o->age >= c->orderPeriod)) {
-                    if (o->costValid) {
-                        const int staged = Q.traceWaves <= kOrderLdsTiles ? 1 : 0;
-                        hipLaunchKernelGGL(k_order_build, dim3(1), dim3(kOrderBlock), staged ? (size_t)((Q.traceWaves + 15) & ~15) : 0, s, o->d_tileCost, Q.tilesX,
-                                           Q.boxX0, Q.boxY0, Q.boxW, Q.boxH, staged, o->d_tileOrder, c->d_sortViolations);
-                        std::memcpy(o->box, box, sizeof box);
-                        o->valid = true; o->age = 0;
-                    } else o->valid = false;
-                }
-                Q.tileOrder = (o->valid && Q.traceWaves > 0) ? o->d_tileOrder : nullptr;
-                if (frameMode && !o->fixed) { Q.tileCost = o->d_tileCost; o->costValid = true; }
-                if (frameMode) o->age++;
+            rto_context::OrderState* st = nullptr;
+            const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
+            {
+                const int rc = prepare_schedule(c, s, capturing, frameMode, MODE == kModeTimeline, 0, solidRect, Q, &st);
+                if (rc != RTO_OK) return rc;
             }
             const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
             if (!capturing) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
@@ -1351,20 +1371,28 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
     if (!c->d_triOffset) return fail(c, RTO_E_NO_OCTREE, "render_triangles: no leaf triangles uploaded");
     if (c->culling) return fail(c, RTO_E_UNSUPPORTED, "render_triangles: not available while frustum culling is active");
     RenderParams P;
-    int rc = fill_params(c, f, p, P);
+    int rc = fill_params(c, f, p, P, s);
     if (rc != RTO_OK) return rc;
     const int tiles = P.tilesX * P.tilesY;
     if (tiles <= 0) return RTO_OK;
     const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
     const bool packed = c->canonical && c->numInternal > 0 && c->kernelMode != RTO_KERNEL_GENERIC;
     const bool capturing = stream_is_capturing(s);
+    if (packed) {
+        // same launch geometry and launch order as the octree frames: waves for the geometry's rectangle only, wide stores
+        // for the rest, costliest tiles of earlier frames first (the instrumented frame keeps one wave per tile)
+        rto_context::OrderState* st = nullptr;
+        const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
+        if ((rc = prepare_schedule(c, s, capturing, !count, false, 1, solidRect, P, &st)) != RTO_OK) return rc;
+    }
     if (!capturing) RTO_HIP(c, hipEventRecord(c->ev0, s));
     if (packed) {
         PackedTriScene S{ c->d_desc, c->d_descFirstChild, c->d_tris, c->d_triOffset };
         const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint4);
-        if (shadeOut) hipLaunchKernelGGL((k_trace_packed_triangles<kModeColor, true>), dim3(blocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
-        else if (count) hipLaunchKernelGGL((k_trace_packed_triangles<kModeSteps, false>), dim3(blocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
-        else hipLaunchKernelGGL((k_trace_packed_triangles<kModeColor, false>), dim3(blocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+        const int lblocks = (P.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
+        if (shadeOut) hipLaunchKernelGGL((k_trace_packed_triangles<kModeColor, true>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+        else if (count) hipLaunchKernelGGL((k_trace_packed_triangles<kModeSteps, false>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+        else hipLaunchKernelGGL((k_trace_packed_triangles<kModeColor, false>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
     } else {
         TriScene S{ c->d_nodes, c->d_tris, c->d_triOffset };
         if (shadeOut) hipLaunchKernelGGL((k_trace_triangles<kModeColor, true>), dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);

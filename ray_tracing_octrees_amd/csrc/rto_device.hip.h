@@ -1525,18 +1525,23 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed_triangles(RenderParams 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint4* stk = lds_stack4 + (size_t)wave * P.depth * kWave + lane;
-    const int slot = blockIdx.x * (kBlock / kWave) + wave;
-    int tx = 0, ty = P.tilesY;
-    if (slot < P.tilesX * P.tilesY) tile_of(P, slot, tx, ty);
+    const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    if (slot >= P.launchWaves) return;
+    int tile, tx, ty;
+    resolve_slot(P, slot, tx, ty, tile);
     const int px = tx * 8 + (lane & 7);
     const int ly = ty * 8 + (lane >> 3);
     const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
     const int py = global_row(P, ly);
     const bool inImage = valid && (py < P.H);
+    // outside this rectangle no ray can meet the geometry (instrumented frames: the root box, whose miss costs exactly the
+    // root's pop; colour / shade frames: the solid leaves' box widened by a voxel, which holds every triangle)
+    const bool outside = px < P.rootX0 || px > P.rootX1 || py < P.rootY0 || py > P.rootY1;
     float shade = kShadeMiss;
     int steps = 0;
     bool hit = false;
-    if (inImage) {
+    if (inImage && outside) steps = 1;
+    if (inImage && !outside) {
         const Ray r = generate_ray_tab(P, px, py);
         const PTriHit h = trace_packed_triangles(P, S, r, stk);
         steps = h.steps;
@@ -1559,10 +1564,17 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed_triangles(RenderParams 
             shade = ndotl;
         }
     }
-    if (valid) {
+    if (P.tileCost) {
+        // this tile's cost for the launch order: the pops of its busiest ray (primary + shadow), 16 per bucket
+        int cst = steps;
+        for (int off = 32; off > 0; off >>= 1) cst = max(cst, __shfl_xor(cst, off));
+        if (lane == 0 && ty < P.tilesY) P.tileCost[tile] = cst >> 4;
+    }
+    if (valid && !(P.skipOutside && outside)) {
         if (SHADE) __builtin_nontemporal_store(shade, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);
         else store_pixel(out + (size_t)ly * P.W + px, shade_color(shade));
     }
+    if (MODE == kModeColor) fill_outside<SHADE ? kModeShade : kModeColor>(P, out, lane, slot);
     if (MODE == kModeSteps) {
         unsigned long long pops = inImage ? (unsigned long long)steps : 0ull, hits = (inImage && hit) ? 1ull : 0ull;
         for (int off = 32; off > 0; off >>= 1) { pops += __shfl_down(pops, off); hits += __shfl_down(hits, off); }
