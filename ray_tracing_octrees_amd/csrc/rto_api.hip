@@ -104,6 +104,9 @@ struct rto_context {
     size_t ringUsed = 0;
     hipEvent_t lastA = nullptr, lastB = nullptr;
     float buildMs = -1.f;      // device time of the last rto_build_octree (pyramid + emission kernels)
+    bool descPooled = false;   // d_descFirstChild lives in d_desc's allocation (Morton-order build)
+    bool asyncPooled = false;  // d_nodes / d_desc come from the stream-ordered memory pool (hipMallocAsync): a rebuild reuses them without hipMalloc
+    int buildPath = 0;         // 0 = automatic (Morton-order build where it applies), 1 = level-by-level build (rto_debug_set_build_path)
     float buildUploadMs = -1.f;
 };
 
@@ -122,9 +125,15 @@ static int fail(rto_context* ctx, int code, const std::string& msg) {
     } while (0)
 
 static void free_octree(rto_context* c) {
-    (void)hipFree(c->d_nodes); c->d_nodes = nullptr;
-    (void)hipFree(c->d_desc); c->d_desc = nullptr;
-    (void)hipFree(c->d_descFirstChild); c->d_descFirstChild = nullptr;
+    if (c->asyncPooled) {
+        (void)hipDeviceSynchronize();          // like hipFree: frames on caller streams may still read the arrays
+        if (c->d_nodes) (void)hipFreeAsync(c->d_nodes, c->stream);
+        if (c->d_desc) (void)hipFreeAsync(c->d_desc, c->stream);
+    }
+    else { (void)hipFree(c->d_nodes); (void)hipFree(c->d_desc); }
+    c->d_nodes = nullptr; c->d_desc = nullptr; c->asyncPooled = false;
+    if (!c->descPooled) (void)hipFree(c->d_descFirstChild);
+    c->d_descFirstChild = nullptr; c->descPooled = false;
     (void)hipFree(c->d_vis); c->d_vis = nullptr;
     (void)hipFree(c->d_remap); c->d_remap = nullptr;
     (void)hipFree(c->d_blockCount); c->d_blockCount = nullptr;
@@ -343,6 +352,78 @@ struct BuildScratch {
 };
 }  // namespace
 
+// The seven-launch build (k_mb_*): fills c->d_nodes / d_desc / d_descFirstChild from c->d_vox.  *total / *internal: sizes;
+// solidBox: lo[3], hi[3] of the cells that hold FILLED voxels (level-1 cell precision; lo > hi: nothing solid).
+static int build_octree_morton(rto_context* c, hipStream_t s, BuildScratch& scratch, int R, int dimX, int dimY, int dimZ,
+                               int64_t* total, int64_t* internal, int solidBox[6]) {
+    MbLevels Lv;
+    std::memset(&Lv, 0, sizeof Lv);
+    Lv.R = R; Lv.dimX = dimX; Lv.dimY = dimY; Lv.dimZ = dimZ;
+    const int B = R < kMbBrickLevels ? R : kMbBrickLevels;
+    const int bricksX = (dimX + 31) / 32, bricksY = (dimY + 31) / 32, bricksZ = (dimZ + 31) / 32;
+    // bricks that do not touch the grid are never computed: their cells must read EMPTY with no mixed children
+    const bool allBricks = R < kMbBrickLevels || ((long long)bricksX << 5 >= (1ll << R) && (long long)bricksY << 5 >= (1ll << R) && (long long)bricksZ << 5 >= (1ll << R));
+    long long scanCells = 0, emitCells = 0;
+    for (int l = 1; l <= R; l++) {
+        const size_t cells = (size_t)1 << (3 * (R - l));
+        RTO_HIP(c, scratch.alloc(&Lv.state[l], cells));
+        if (!allBricks && l <= B) RTO_HIP(c, hipMemsetAsync(Lv.state[l], 0, cells, s));
+        Lv.emitOffset[l] = emitCells; emitCells += l == R ? 1 : (long long)(cells / 8);      // k_mb_emit: one thread per group of 8 siblings
+        if (l >= 2) {
+            RTO_HIP(c, scratch.alloc(&Lv.cnt[l], cells));
+            RTO_HIP(c, scratch.alloc(&Lv.group[l], cells));
+            if (!allBricks && l <= B) RTO_HIP(c, hipMemsetAsync(Lv.cnt[l], 0, cells, s));
+            Lv.cntOffset[l] = scanCells;
+            scanCells += (long long)((cells + kMbChunk - 1) / kMbChunk) * kMbChunk;
+        }
+    }
+    Lv.cntOffset[R + 1] = scanCells; Lv.emitOffset[R + 1] = emitCells;
+    if (R >= 2) Lv.cntOffset[1] = 0;
+    const unsigned chunks = (unsigned)(scanCells / kMbChunk);
+    int* d_chunk = nullptr;
+    int* d_brickBox = nullptr;
+    MbTables* d_tab = nullptr;
+    const int runsX = (bricksX + kMbRun - 1) / kMbRun;              // a block takes kMbRun bricks along x
+    const int numBricks = runsX * bricksY * bricksZ;                // = blocks of k_mb_bricks
+    RTO_HIP(c, scratch.alloc(&d_chunk, (size_t)chunks + 1));
+    RTO_HIP(c, scratch.alloc(&d_brickBox, (size_t)numBricks * 6));
+    RTO_HIP(c, scratch.alloc(&d_tab, 1));
+    hipLaunchKernelGGL(k_mb_bricks, dim3((unsigned)numBricks), dim3(kBlock), 0, s, c->d_vox, Lv, bricksX, runsX, bricksY, d_brickBox);
+    hipLaunchKernelGGL(k_mb_top, dim3(1), dim3(1024), 0, s, Lv, d_brickBox, numBricks, d_tab);
+    if (chunks) hipLaunchKernelGGL(k_mb_chunk_sums, dim3(chunks), dim3(kBlock), 0, s, Lv, d_chunk);
+    hipLaunchKernelGGL(k_mb_scan_chunks, dim3(1), dim3(1024), 0, s, Lv, d_chunk, d_tab);
+    RTO_HIP(c, hipGetLastError());
+    MbTables tab;
+    RTO_HIP(c, hipMemcpyAsync(&tab, d_tab, sizeof tab, hipMemcpyDeviceToHost, s));
+    RTO_HIP(c, hipStreamSynchronize(s));          // the only read-back before the tree is complete: it sizes the outputs
+    if (tab.total > 0x7fffffff) return fail(c, RTO_E_UNSUPPORTED, "rto_build_octree: node indices are int32 (GPUNodes.child)");
+    *total = tab.total; *internal = tab.internal;
+    {   // level-1 cells on the grid's boundary stick out of it: clip
+        const int dims[3] = { dimX, dimY, dimZ };
+        for (int a = 0; a < 3; a++) { solidBox[a] = tab.solidLo[a]; solidBox[3 + a] = std::min(tab.solidHi[a], dims[a]); }
+    }
+    // result arrays from the stream-ordered pool (its release threshold is raised in rto_create): the first build pays the
+    // allocation, a rebuild of a similar scene gets the memory back without a hipMalloc (~0.1 ms each)
+    c->asyncPooled = true;
+    RTO_HIP(c, hipMallocAsync(reinterpret_cast<void**>(&c->d_nodes), (size_t)tab.total * sizeof(rto_node), s));
+    if (tab.internal > 0) {
+        // one allocation for both descriptor arrays: d_descFirstChild lives behind d_desc
+        const size_t descBytes = ((size_t)tab.internal * sizeof(uint2) + 255) & ~(size_t)255;
+        char* both = nullptr;
+        RTO_HIP(c, hipMallocAsync(reinterpret_cast<void**>(&both), descBytes + (size_t)tab.internal * sizeof(int), s));
+        c->d_desc = reinterpret_cast<uint2*>(both);
+        c->d_descFirstChild = reinterpret_cast<int*>(both + descBytes);
+        c->descPooled = true;
+    }
+    unsigned* d_cellOf = nullptr;                                  // descriptor index -> Morton index of the cell (its level follows from the bases)
+    RTO_HIP(c, scratch.alloc(&d_cellOf, (size_t)tab.internal + 1));
+    if (chunks) hipLaunchKernelGGL(k_mb_group_ranks, dim3(chunks), dim3(kBlock), 0, s, Lv, d_chunk, d_tab, d_cellOf);
+    hipLaunchKernelGGL(k_mb_emit, dim3((unsigned)((tab.internal + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, c->d_vox, Lv, d_tab, d_cellOf,
+                       c->d_nodes, c->d_desc, c->d_descFirstChild);
+    RTO_HIP(c, hipGetLastError());
+    return RTO_OK;
+}
+
 extern "C" {
 
 int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, int dimZ, const float grid_min[3], float voxel_size) {
@@ -374,106 +455,117 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     RTO_HIP(c, hipMemcpyAsync(d_vox, voxels, nvox, hipMemcpyHostToDevice, s));
     RTO_HIP(c, hipEventRecord(e1, s));
 
-    // ---- occupancy pyramid, bottom-up; every level also leaves its number of mixed cells = internal nodes
-    PyramidView V;
-    std::memset(&V, 0, sizeof V);
-    V.level[0] = d_vox; V.nx[0] = dimX; V.ny[0] = dimY; V.nz[0] = dimZ;
-    LevelCountView LC;
-    std::memset(&LC, 0, sizeof LC);
-    for (int l = 1; l <= R; l++) {
-        V.nx[l] = (V.nx[l - 1] + 1) / 2; V.ny[l] = (V.ny[l - 1] + 1) / 2; V.nz[l] = (V.nz[l - 1] + 1) / 2;
-        const size_t cells = (size_t)V.nx[l] * V.ny[l] * V.nz[l];
-        const bool wide = l == 1 && dimX % 16 == 0;         // level 1 reads the voxels 16 B at a time when rows stay aligned
-        const unsigned nbl = (unsigned)(((wide ? cells / 8 : cells) + kBlock - 1) / kBlock);
-        uint8_t* d = nullptr;
-        int* d_bm = nullptr;
-        RTO_HIP(c, scratch.alloc(&d, cells));
-        RTO_HIP(c, scratch.alloc(&d_bm, (size_t)nbl));
-        V.level[l] = d;
-        LC.blockMixed[l] = d_bm; LC.numBlocks[l] = (int)nbl;
-        if (wide)
-            hipLaunchKernelGGL(k_pyramid_level1_wide, dim3(nbl), dim3(kBlock), 0, s, d_vox, dimX, dimY, dimZ, d, V.nx[l], V.ny[l], V.nz[l], d_bm);
-        else
-            hipLaunchKernelGGL(k_pyramid_level, dim3(nbl), dim3(kBlock), 0, s,
-                               V.level[l - 1], V.nx[l - 1], V.ny[l - 1], V.nz[l - 1], d, V.nx[l], V.ny[l], V.nz[l], 1 << l, dimX, dimY, dimZ, d_bm);
-    }
-    RTO_HIP(c, hipGetLastError());
-    std::vector<long long> mixed((size_t)R + 1, 0);
-    if (R > 0) {
-        long long* d_mixed = nullptr;
-        RTO_HIP(c, scratch.alloc(&d_mixed, (size_t)R + 1));
-        hipLaunchKernelGGL(k_sum_level_counts, dim3((unsigned)R), dim3(1024), 0, s, LC, d_mixed);
-        RTO_HIP(c, hipGetLastError());
-        RTO_HIP(c, hipMemcpyAsync(mixed.data() + 1, d_mixed + 1, (size_t)R * sizeof(long long), hipMemcpyDeviceToHost, s));
-        RTO_HIP(c, hipStreamSynchronize(s));      // the only read-back before the tree is complete
-    }
-
-    // ---- pass 1: level-order node lists, internal flags and ranks.  Tree level L holds the cells of pyramid level
-    //      R - L; its internal nodes are that level's mixed cells, so every size is known up front and the loop
-    //      below runs without touching the host.
-    std::vector<LevelBuf> levels;
-    {
-        int64_t m = 1;
-        for (int L = 0; L <= R && m > 0; L++) {
-            LevelBuf lb; lb.m = m;
-            lb.k = (L < R) ? (int64_t)mixed[(size_t)(R - L)] : 0;
-            if (lb.m > 0x7fffffff) return fail(c, RTO_E_UNSUPPORTED, "rto_build_octree: more than 2^31 nodes on one level");
-            levels.push_back(lb);
-            m = lb.k * 8;
-        }
-    }
     int64_t total = 0, internal = 0;
-    for (const LevelBuf& lb : levels) { total += lb.m; internal += lb.k; }
-    if (total > 0x7fffffff) return fail(c, RTO_E_UNSUPPORTED, "rto_build_octree: node indices are int32 (GPUNodes.child)");
-    // every allocation first (the result arrays are real hipMallocs, ~0.1 ms each), then all kernels back to back
-    RTO_HIP(c, hipMalloc(&c->d_nodes, (size_t)total * sizeof(rto_node)));
-    if (internal > 0) {
-        RTO_HIP(c, hipMalloc(&c->d_desc, (size_t)internal * sizeof(uint2)));
-        RTO_HIP(c, hipMalloc(&c->d_descFirstChild, (size_t)internal * sizeof(int)));
-    }
-    std::vector<int*> d_bc(levels.size(), nullptr), d_bb(levels.size(), nullptr);
-    for (size_t L = 0; L < levels.size(); L++) {
-        LevelBuf& lb = levels[L];
-        const size_t nb = (size_t)((lb.m + kBlock - 1) / kBlock);
-        RTO_HIP(c, scratch.alloc(&lb.coords, (size_t)lb.m));
-        RTO_HIP(c, scratch.alloc(&lb.state, (size_t)lb.m)); RTO_HIP(c, scratch.alloc(&lb.flag, (size_t)lb.m));
-        RTO_HIP(c, scratch.alloc(&lb.rank, (size_t)lb.m));
-        RTO_HIP(c, scratch.alloc(&d_bc[L], nb)); RTO_HIP(c, scratch.alloc(&d_bb[L], nb));
-    }
+    int box[6];
+    bool haveBox = false;              // the Morton-order build delivers the solid box with its one read-back
     int* d_bbox = nullptr;
     RTO_HIP(c, scratch.alloc(&d_bbox, 6));
-    RTO_HIP(c, hipMemsetAsync(levels[0].coords, 0, sizeof(int4), s));     // the root: (0, 0, 0)
-    for (size_t L = 0; L < levels.size(); L++) {
-        LevelBuf& lb = levels[L];
-        const int lv = R - (int)L;
-        const int nb = (int)((lb.m + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_build_classify, dim3(nb), dim3(kBlock), 0, s, V, lb.coords, lb.m, lv, lb.state, lb.flag, d_bc[L]);
-        hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, s, d_bc[L], nb, d_bb[L], c->d_visibleCount);
-        hipLaunchKernelGGL(k_build_rank_children, dim3(nb), dim3(kBlock), 0, s, lb.flag, lb.coords, lb.m, d_bb[L], (1 << lv) / 2, lb.rank,
-                           L + 1 < levels.size() ? levels[L + 1].coords : (int4*)nullptr);
-    }
-    RTO_HIP(c, hipGetLastError());
+    if (R >= 1 && R <= kMbMaxDepth && c->buildPath == 0) {
+        // seven launches whatever the depth: every level ranked and emitted at once (Morton order == BFS order within a level)
+        const int rc = build_octree_morton(c, s, scratch, R, dimX, dimY, dimZ, &total, &internal, box);
+        if (rc != RTO_OK) return rc;
+        haveBox = true;
+    } else {
+        // level-by-level form (any depth up to kMaxDepth; also the cross-check of the other: rto_debug_set_build_path)
+        // ---- occupancy pyramid, bottom-up; every level also leaves its number of mixed cells = internal nodes
+        PyramidView V;
+        std::memset(&V, 0, sizeof V);
+        V.level[0] = d_vox; V.nx[0] = dimX; V.ny[0] = dimY; V.nz[0] = dimZ;
+        LevelCountView LC;
+        std::memset(&LC, 0, sizeof LC);
+        for (int l = 1; l <= R; l++) {
+            V.nx[l] = (V.nx[l - 1] + 1) / 2; V.ny[l] = (V.ny[l - 1] + 1) / 2; V.nz[l] = (V.nz[l - 1] + 1) / 2;
+            const size_t cells = (size_t)V.nx[l] * V.ny[l] * V.nz[l];
+            const bool wide = l == 1 && dimX % 16 == 0;         // level 1 reads the voxels 16 B at a time when rows stay aligned
+            const unsigned nbl = (unsigned)(((wide ? cells / 8 : cells) + kBlock - 1) / kBlock);
+            uint8_t* d = nullptr;
+            int* d_bm = nullptr;
+            RTO_HIP(c, scratch.alloc(&d, cells));
+            RTO_HIP(c, scratch.alloc(&d_bm, (size_t)nbl));
+            V.level[l] = d;
+            LC.blockMixed[l] = d_bm; LC.numBlocks[l] = (int)nbl;
+            if (wide)
+                hipLaunchKernelGGL(k_pyramid_level1_wide, dim3(nbl), dim3(kBlock), 0, s, d_vox, dimX, dimY, dimZ, d, V.nx[l], V.ny[l], V.nz[l], d_bm);
+            else
+                hipLaunchKernelGGL(k_pyramid_level, dim3(nbl), dim3(kBlock), 0, s,
+                                   V.level[l - 1], V.nx[l - 1], V.ny[l - 1], V.nz[l - 1], d, V.nx[l], V.ny[l], V.nz[l], 1 << l, dimX, dimY, dimZ, d_bm);
+        }
+        RTO_HIP(c, hipGetLastError());
+        std::vector<long long> mixed((size_t)R + 1, 0);
+        if (R > 0) {
+            long long* d_mixed = nullptr;
+            RTO_HIP(c, scratch.alloc(&d_mixed, (size_t)R + 1));
+            hipLaunchKernelGGL(k_sum_level_counts, dim3((unsigned)R), dim3(1024), 0, s, LC, d_mixed);
+            RTO_HIP(c, hipGetLastError());
+            RTO_HIP(c, hipMemcpyAsync(mixed.data() + 1, d_mixed + 1, (size_t)R * sizeof(long long), hipMemcpyDeviceToHost, s));
+            RTO_HIP(c, hipStreamSynchronize(s));      // the only read-back before the tree is complete
+        }
 
-    // ---- pass 2: node records + descriptors
-    int64_t levelBase = 0, internalBase = 0;
-    for (size_t L = 0; L < levels.size(); L++) {
-        const LevelBuf& lb = levels[L];
-        const bool hasNext = L + 1 < levels.size();
-        const int nb = (int)((lb.m + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(kBlock), 0, s, lb.coords, lb.state, lb.rank, lb.m, 1 << (R - (int)L),
-                           levelBase, internalBase, hasNext ? levels[L + 1].state : nullptr, hasNext ? levels[L + 1].rank : nullptr,
-                           internalBase + lb.k, c->d_nodes, c->d_desc, c->d_descFirstChild);
-        levelBase += lb.m; internalBase += lb.k;
+        // ---- pass 1: level-order node lists, internal flags and ranks.  Tree level L holds the cells of pyramid level
+        //      R - L; its internal nodes are that level's mixed cells, so every size is known up front and the loop
+        //      below runs without touching the host.
+        std::vector<LevelBuf> levels;
+        {
+            int64_t m = 1;
+            for (int L = 0; L <= R && m > 0; L++) {
+                LevelBuf lb; lb.m = m;
+                lb.k = (L < R) ? (int64_t)mixed[(size_t)(R - L)] : 0;
+                if (lb.m > 0x7fffffff) return fail(c, RTO_E_UNSUPPORTED, "rto_build_octree: more than 2^31 nodes on one level");
+                levels.push_back(lb);
+                m = lb.k * 8;
+            }
+        }
+        for (const LevelBuf& lb : levels) { total += lb.m; internal += lb.k; }
+        if (total > 0x7fffffff) return fail(c, RTO_E_UNSUPPORTED, "rto_build_octree: node indices are int32 (GPUNodes.child)");
+        // every allocation first (the result arrays are real hipMallocs, ~0.1 ms each), then all kernels back to back
+        RTO_HIP(c, hipMalloc(&c->d_nodes, (size_t)total * sizeof(rto_node)));
+        if (internal > 0) {
+            RTO_HIP(c, hipMalloc(&c->d_desc, (size_t)internal * sizeof(uint2)));
+            RTO_HIP(c, hipMalloc(&c->d_descFirstChild, (size_t)internal * sizeof(int)));
+        }
+        std::vector<int*> d_bc(levels.size(), nullptr), d_bb(levels.size(), nullptr);
+        for (size_t L = 0; L < levels.size(); L++) {
+            LevelBuf& lb = levels[L];
+            const size_t nb = (size_t)((lb.m + kBlock - 1) / kBlock);
+            RTO_HIP(c, scratch.alloc(&lb.coords, (size_t)lb.m));
+            RTO_HIP(c, scratch.alloc(&lb.state, (size_t)lb.m)); RTO_HIP(c, scratch.alloc(&lb.flag, (size_t)lb.m));
+            RTO_HIP(c, scratch.alloc(&lb.rank, (size_t)lb.m));
+            RTO_HIP(c, scratch.alloc(&d_bc[L], nb)); RTO_HIP(c, scratch.alloc(&d_bb[L], nb));
+        }
+        RTO_HIP(c, hipMemsetAsync(levels[0].coords, 0, sizeof(int4), s));     // the root: (0, 0, 0)
+        for (size_t L = 0; L < levels.size(); L++) {
+            LevelBuf& lb = levels[L];
+            const int lv = R - (int)L;
+            const int nb = (int)((lb.m + kBlock - 1) / kBlock);
+            hipLaunchKernelGGL(k_build_classify, dim3(nb), dim3(kBlock), 0, s, V, lb.coords, lb.m, lv, lb.state, lb.flag, d_bc[L]);
+            hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, s, d_bc[L], nb, d_bb[L], c->d_visibleCount);
+            hipLaunchKernelGGL(k_build_rank_children, dim3(nb), dim3(kBlock), 0, s, lb.flag, lb.coords, lb.m, d_bb[L], (1 << lv) / 2, lb.rank,
+                               L + 1 < levels.size() ? levels[L + 1].coords : (int4*)nullptr);
+        }
+        RTO_HIP(c, hipGetLastError());
+
+        // ---- pass 2: node records + descriptors
+        int64_t levelBase = 0, internalBase = 0;
+        for (size_t L = 0; L < levels.size(); L++) {
+            const LevelBuf& lb = levels[L];
+            const bool hasNext = L + 1 < levels.size();
+            const int nb = (int)((lb.m + kBlock - 1) / kBlock);
+            hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(kBlock), 0, s, lb.coords, lb.state, lb.rank, lb.m, 1 << (R - (int)L),
+                               levelBase, internalBase, hasNext ? levels[L + 1].state : nullptr, hasNext ? levels[L + 1].rank : nullptr,
+                               internalBase + lb.k, c->d_nodes, c->d_desc, c->d_descFirstChild);
+            levelBase += lb.m; internalBase += lb.k;
+        }
+        RTO_HIP(c, hipGetLastError());
     }
-    RTO_HIP(c, hipGetLastError());
-    // ---- where the solid geometry is (launch-order heuristic)
-    const int initBox[6] = { 0x7fffffff, 0x7fffffff, 0x7fffffff, -0x7fffffff, -0x7fffffff, -0x7fffffff };
-    RTO_HIP(c, hipMemcpyAsync(d_bbox, initBox, sizeof initBox, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_solid_bbox, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 512)), dim3(kBlock), 0, s, c->d_nodes, total, d_bbox);
-    RTO_HIP(c, hipGetLastError());
-    RTO_HIP(c, hipEventRecord(e2, s));
-    int box[6];
-    RTO_HIP(c, hipMemcpyAsync(box, d_bbox, sizeof box, hipMemcpyDeviceToHost, s));
+    // ---- where the solid geometry is (launch order, screen rectangle of the frames)
+    if (!haveBox) {
+        const int initBox[6] = { 0x7fffffff, 0x7fffffff, 0x7fffffff, -0x7fffffff, -0x7fffffff, -0x7fffffff };
+        RTO_HIP(c, hipMemcpyAsync(d_bbox, initBox, sizeof initBox, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_solid_bbox, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 512)), dim3(kBlock), 0, s, c->d_nodes, total, d_bbox);
+        RTO_HIP(c, hipGetLastError());
+        RTO_HIP(c, hipEventRecord(e2, s));
+        RTO_HIP(c, hipMemcpyAsync(box, d_bbox, sizeof box, hipMemcpyDeviceToHost, s));
+    } else RTO_HIP(c, hipEventRecord(e2, s));
     RTO_HIP(c, hipStreamSynchronize(s));
     for (int a = 0; a < 3; a++) {
         c->solidCentre[a] = box[a] <= box[3 + a] ? 0.5f * (float)(box[a] + box[3 + a]) : 0.5f * (float)(1 << R);
@@ -481,10 +573,19 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     }
     RTO_HIP(c, hipEventElapsedTime(&c->buildUploadMs, e0, e1));
     RTO_HIP(c, hipEventElapsedTime(&c->buildMs, e1, e2));
+    if (std::getenv("RTO_DEBUG_BUILD"))
+        std::fprintf(stderr, "rto_build_octree: path %s, solid box lo (%d %d %d) hi (%d %d %d), nodes %lld internal %lld\n", haveBox ? "morton" : "levels",
+                     box[0], box[1], box[2], box[3], box[4], box[5], (long long)total, (long long)internal);
 
     c->numNodes = total; c->visibleNodes = total; c->numInternal = internal;
     c->rootSize = 1 << R; c->depth = R;
     c->canonical = internal > 0;                 // a one-node tree is rendered by the generic kernel
+    return RTO_OK;
+}
+
+int rto_debug_set_build_path(rto_context* c, int level_by_level) {
+    if (!c) return RTO_E_INVALID;
+    c->buildPath = level_by_level ? 1 : 0;
     return RTO_OK;
 }
 

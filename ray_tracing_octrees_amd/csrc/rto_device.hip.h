@@ -1930,6 +1930,394 @@ __global__ __launch_bounds__(kBlock) void k_build_emit(const int4* __restrict__ 
     nodes[levelBase + i] = nd;
 }
 
+// ---------------------------------------------------------------- N4, second form: the same tree in SEVEN launches
+// The level-by-level form above needs ~5 dependent launches per tree level (~50 at 512^3: launch-bound, 0.48 ms).  The BFS
+// numbering of setOctree has a closed form that removes the dependency between levels: children are appended in child
+// order k = x | y<<1 | z<<2 below parents that are themselves in that order, so WITHIN a tree level the nodes are sorted by
+// the Morton code of their cell (x bit lowest).  Hence, with every pyramid level stored in Morton order,
+//     rank of a mixed cell among the mixed cells of its level  =  an exclusive prefix sum over that level's array,
+//     node index of child k of mixed cell P (level l+1)         =  levelBase + 8 * rank(P) + k,
+// and every level can be ranked and emitted at once:
+//   k_mb_bricks      voxels -> pyramid levels 1..5 of one 32^3 brick (LDS), written in Morton order, with the number of
+//                    mixed children of every cell (cnt); one block per brick that touches the grid
+//   k_mb_top         levels 6..R from level 5 (one block)
+//   k_mb_chunk_sums / k_mb_scan_chunks / k_mb_group_ranks
+//                    exclusive scan of cnt over all levels: G[level][p] = mixed cells of the level below that precede
+//                    p's first child; per-level totals -> node / descriptor bases -> ONE read-back sizes the outputs
+//   k_mb_emit        one thread per pyramid cell: a mixed cell writes its descriptor and its 8 children's records
+// Bytes: voxels read once (1 B/voxel), pyramid + counts written and read once (2 x 2/7 B/voxel), 60 B per node written.
+constexpr int kMbBrickLevels = 5;                 // a brick is 32^3 voxels
+constexpr int kMbMaxDepth = 10;                   // Morton arrays of level 1 hold 8^(R-1) bytes: 134 MB at R = 10
+constexpr int kMbChunk = 1024;
+
+struct MbLevels {
+    uint8_t* state[kMbMaxDepth + 1];              // [l] Morton-ordered states of pyramid level l (1..R): 0 EMPTY, 1 FILLED, 2 mixed
+    uint8_t* cnt[kMbMaxDepth + 1];                // [l] mixed children (level l-1) of every cell of level l (2..R)
+    int* group[kMbMaxDepth + 1];                  // [l] exclusive scan of cnt[l]: rank of the first child among the mixed cells of level l-1
+    long long cntOffset[kMbMaxDepth + 2];         // [l] offset of cnt[l] in the concatenated scan domain (levels padded to kMbChunk)
+    long long emitOffset[kMbMaxDepth + 2];        // [l] offset of level l (1..R) in k_mb_emit's thread domain; [R+1] = its size
+    int R;
+    int dimX, dimY, dimZ;
+};
+
+struct MbTables {                                 // written by k_mb_scan_chunks, read by the host (sizes) and by k_mb_emit
+    long long levelBase[kMbMaxDepth + 2];         // [L] flat index of tree level L's first node
+    long long internalBase[kMbMaxDepth + 2];      // [L] descriptor index of tree level L's first internal node
+    long long total, internal;
+    int solidLo[3], solidHi[3];                   // voxel box of the level-1 cells that hold FILLED voxels (lo > hi: none)
+};
+
+__device__ __forceinline__ unsigned mb_spread3(unsigned v) {   // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ unsigned mb_compact3(unsigned v) {  // every third bit -> 10 bits
+    v &= 0x09249249u;
+    v = (v | (v >> 2)) & 0x030c30c3u;
+    v = (v | (v >> 4)) & 0x0300f00fu;
+    v = (v | (v >> 8)) & 0x030000ffu;
+    v = (v | (v >> 16)) & 0x3ffu;
+    return v;
+}
+__device__ __forceinline__ unsigned mb_morton(unsigned x, unsigned y, unsigned z) { return mb_spread3(x) | (mb_spread3(y) << 1) | (mb_spread3(z) << 2); }
+
+__device__ __forceinline__ int mb_voxel(const uint8_t* __restrict__ vox, int dimX, int dimY, int dimZ, int x, int y, int z) {
+    if (x >= dimX || y >= dimY || z >= dimZ) return 0;                     // getVoxelSafe: outside reads EMPTY
+    return vox[(size_t)x + (size_t)y * dimX + (size_t)z * dimX * dimY] == 1 ? 1 : 0;
+}
+
+// state of a cell from its 8 children states; *mixedChildren = how many of them are mixed
+__device__ __forceinline__ int mb_combine(const int s[8], int* mixedChildren) {
+    bool any0 = false, any1 = false;
+    int mixed = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { mixed += s[k] == 2; any1 |= s[k] == 1; any0 |= s[k] == 0; }
+    *mixedChildren = mixed;
+    return (mixed || (any0 && any1)) ? 2 : (any1 ? 1 : 0);
+}
+
+// One block per run of kMbRun 32^3-voxel bricks along x (a wave instruction then reads 128 contiguous bytes of a voxel
+// row instead of 32: the voxels are x-fastest and a single brick's rows are 32 bytes).  B = min(5, R) levels; a grid
+// smaller than a brick has one brick that reaches above the root: cells beyond the root's domain are not written.  LDS
+// holds each brick's levels in LOCAL MORTON order, so the 8 children of a cell are 8 consecutive bytes and the write-out is
+// a straight 16-byte copy.  blockBox: per block, the box (level-1 cell precision, voxel units) of its cells that hold
+// FILLED voxels.
+constexpr int kMbRun = 4;
+constexpr int kMbBrickLds = 4096 + 512 + 64 + 16 + 16;       // levels 1..5 of one brick, 16-byte aligned each
+
+__global__ __launch_bounds__(kBlock) void k_mb_bricks(const uint8_t* __restrict__ vox, MbLevels Lv, int bricksX, int runsX, int bricksY,
+                                                       int* __restrict__ blockBox /* [block][6] */) {
+    __shared__ __attribute__((aligned(16))) uint8_t st[kMbRun][kMbBrickLds];
+    __shared__ __attribute__((aligned(16))) uint8_t ct[kMbRun][kMbBrickLds];          // mixed-children counts (level 1: always 0)
+    __shared__ int box[6];
+    const int R = Lv.R;
+    const int B = R < kMbBrickLevels ? R : kMbBrickLevels;
+    const int rx = blockIdx.x % runsX, by = (blockIdx.x / runsX) % bricksY, bz = blockIdx.x / (runsX * bricksY);
+    const int bx0 = rx * kMbRun;                                                  // first brick of the run
+    const int nb = min(kMbRun, bricksX - bx0);                                    // bricks of this run that touch the grid
+    const int x0 = bx0 << kMbBrickLevels, y0 = by << kMbBrickLevels, z0 = bz << kMbBrickLevels;
+    if (threadIdx.x < 6) box[threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : -0x7fffffff;
+    __syncthreads();
+    // ---- level 1 from the voxels: one thread = 8 cells along x (16 voxels of four rows); 2 * nb such strips per cell row
+    int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
+    const int stripsX = 2 * nb;
+    for (int t = threadIdx.x; t < stripsX * 256; t += kBlock) {
+        const int s16 = t % stripsX, j = (t / stripsX) & 15, k = t / (stripsX * 16);   // 16-voxel strip along x, cell row, cell layer
+        const int sb = s16 >> 1, sx = (s16 & 1) * 8;                                   // brick of the run, strip origin in its level-1 cells
+        const int vx = x0 + s16 * 16, vy = y0 + j * 2, vz = z0 + k * 2;
+        uint4 row[4];
+        const bool vec = (Lv.dimX % 16 == 0) && vx + 16 <= Lv.dimX;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int y = vy + (r & 1), z = vz + (r >> 1);
+            row[r] = make_uint4(0, 0, 0, 0);
+            if (y < Lv.dimY && z < Lv.dimZ) {
+                if (vec) row[r] = *reinterpret_cast<const uint4*>(vox + ((size_t)z * Lv.dimY + y) * Lv.dimX + vx);
+                else {
+                    unsigned w[4] = { 0, 0, 0, 0 };
+                    for (int q = 0; q < 16; q++)
+                        if (vx + q < Lv.dimX) w[q >> 2] |= (unsigned)vox[((size_t)z * Lv.dimY + y) * Lv.dimX + vx + q] << ((q & 3) * 8);
+                    row[r] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+        }
+        const unsigned mjk = (mb_spread3((unsigned)j) << 1) | (mb_spread3((unsigned)k) << 2);
+        bool stripAny = false;
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            bool any0 = false, any1 = false;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const unsigned w = (o >> 1) == 0 ? row[r].x : (o >> 1) == 1 ? row[r].y : (o >> 1) == 2 ? row[r].z : row[r].w;
+                const unsigned a = (w >> ((o & 1) * 16)) & 0xffu, b = (w >> ((o & 1) * 16 + 8)) & 0xffu;
+                any1 |= (a == 1) | (b == 1); any0 |= (a != 1) | (b != 1);      // anything but FILLED (incl. outside the grid) is EMPTY
+            }
+            st[sb][mb_spread3((unsigned)(sx + o)) | mjk] = (any0 && any1) ? 2 : (any1 ? 1 : 0);
+            if (any1) { lo[0] = min(lo[0], vx + 2 * o); hi[0] = max(hi[0], vx + 2 * o + 2); stripAny = true; }
+        }
+        if (stripAny) { lo[1] = min(lo[1], vy); hi[1] = max(hi[1], vy + 2); lo[2] = min(lo[2], vz); hi[2] = max(hi[2], vz + 2); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], __shfl_down(lo[a], o)); hi[a] = max(hi[a], __shfl_down(hi[a], o)); }
+        if ((threadIdx.x & 63) == 0) { if (lo[a] != 0x7fffffff) atomicMin(&box[a], lo[a]); if (hi[a] != -0x7fffffff) atomicMax(&box[3 + a], hi[a]); }
+    }
+    for (int t = threadIdx.x; t < nb * (4096 / 4); t += kBlock) reinterpret_cast<unsigned*>(ct[t >> 10])[t & 1023] = 0;      // level 1 has no mixed children
+    __syncthreads();
+    if (threadIdx.x < 6) blockBox[(size_t)blockIdx.x * 6 + threadIdx.x] = box[threadIdx.x];    // the host clips the union to the grid
+    // ---- levels 2..B inside LDS: the children of cell m are bytes 8m .. 8m+7 of the level below
+    int off = 0, cells = 4096;
+    for (int l = 2; l <= B; l++) {
+        const int offN = off + (cells < 16 ? 16 : cells), cellsN = cells >> 3;
+        for (int t = threadIdx.x; t < cellsN * nb; t += kBlock) {
+            const int sb = t / cellsN, m = t - sb * cellsN;
+            const uint2 ch = *reinterpret_cast<const uint2*>(st[sb] + off + 8 * m);
+            int s8[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) s8[c] = (int)(((c < 4 ? ch.x : ch.y) >> ((c & 3) * 8)) & 0xffu);
+            int mixedChildren;
+            st[sb][offN + m] = (uint8_t)mb_combine(s8, &mixedChildren);
+            ct[sb][offN + m] = (uint8_t)mixedChildren;
+        }
+        __syncthreads();
+        off = offN; cells = cellsN;
+    }
+    // ---- write-out (16 bytes per thread where a level has them): level l holds 8^(5-l) cells of a brick at morton(brick) << 3*(5-l)
+    const bool whole = R >= kMbBrickLevels;                       // the bricks lie inside the root cube: every local cell exists
+    for (int sb = 0; sb < nb; sb++) {
+        const unsigned mb = mb_morton((unsigned)(bx0 + sb), (unsigned)by, (unsigned)bz);
+        off = 0; cells = 4096;
+        for (int l = 1; l <= B; l++) {
+            const unsigned domain = 1u << (R - l);                // cells per edge of level l's whole domain
+            const size_t base = (size_t)mb << (3 * (kMbBrickLevels - l));
+            if (whole && cells >= 16) {
+                for (int t = threadIdx.x; t < cells / 16; t += kBlock) {
+                    reinterpret_cast<uint4*>(Lv.state[l] + base)[t] = reinterpret_cast<const uint4*>(st[sb] + off)[t];
+                    if (l >= 2) reinterpret_cast<uint4*>(Lv.cnt[l] + base)[t] = reinterpret_cast<const uint4*>(ct[sb] + off)[t];
+                }
+            } else {
+                for (int t = threadIdx.x; t < cells; t += kBlock) {
+                    const unsigned i = mb_compact3((unsigned)t), j = mb_compact3((unsigned)t >> 1), k = mb_compact3((unsigned)t >> 2);
+                    if ((unsigned)(((bx0 + sb) << kMbBrickLevels) >> l) + i < domain && (unsigned)(y0 >> l) + j < domain && (unsigned)(z0 >> l) + k < domain) {
+                        Lv.state[l][base + t] = st[sb][off + t];
+                        if (l >= 2) Lv.cnt[l][base + t] = ct[sb][off + t];
+                    }
+                }
+            }
+            off += cells < 16 ? 16 : cells; cells >>= 3;
+        }
+    }
+}
+
+// levels B+1..R from level B, one block (at most 8^4 cells on level 6 of a 1024^3 grid); also the union of the brick boxes
+__global__ __launch_bounds__(1024) void k_mb_top(MbLevels Lv, const int* __restrict__ brickBox, int numBricks, MbTables* __restrict__ T) {
+    __shared__ int part[1024 / kWave][6];
+    const int R = Lv.R;
+    const int B = R < kMbBrickLevels ? R : kMbBrickLevels;
+    for (int l = B + 1; l <= R; l++) {
+        const long long cells = 1ll << (3 * (R - l));
+        for (long long p = threadIdx.x; p < cells; p += 1024) {
+            const uint2 ch = *reinterpret_cast<const uint2*>(Lv.state[l - 1] + 8 * p);
+            int s8[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) s8[c] = (int)(((c < 4 ? ch.x : ch.y) >> ((c & 3) * 8)) & 0xffu);
+            int mixedChildren;
+            Lv.state[l][p] = (uint8_t)mb_combine(s8, &mixedChildren);
+            Lv.cnt[l][p] = (uint8_t)mixedChildren;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
+    for (int b = threadIdx.x; b < numBricks; b += 1024)
+#pragma unroll
+        for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], brickBox[(size_t)b * 6 + a]); hi[a] = max(hi[a], brickBox[(size_t)b * 6 + 3 + a]); }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], __shfl_down(lo[a], o)); hi[a] = max(hi[a], __shfl_down(hi[a], o)); }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; a++) { part[threadIdx.x >> 6][a] = lo[a]; part[threadIdx.x >> 6][3 + a] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        int v = part[0][a];
+        for (int w = 1; w < 1024 / kWave; w++) v = a < 3 ? min(v, part[w][a]) : max(v, part[w][a]);
+        if (a < 3) T->solidLo[a] = v; else T->solidHi[a - 3] = v;
+    }
+}
+
+// scan domain: cnt[2], cnt[3], ..., cnt[R] back to back, each level padded to a multiple of kMbChunk
+__device__ __forceinline__ int mb_level_of(const MbLevels& Lv, long long idx) {
+    int l = 2;
+    while (l < Lv.R && idx >= Lv.cntOffset[l + 1]) l++;
+    return l;
+}
+
+__global__ __launch_bounds__(kBlock) void k_mb_chunk_sums(MbLevels Lv, int* __restrict__ chunkSum) {
+    __shared__ int waveTotal[kBlock / kWave];
+    const long long c0 = (long long)blockIdx.x * kMbChunk;
+    const int l = mb_level_of(Lv, c0);
+    const long long cells = 1ll << (3 * (Lv.R - l)), local0 = c0 - Lv.cntOffset[l];
+    int s = 0;
+    for (int t = threadIdx.x; t < kMbChunk; t += kBlock) { const long long p = local0 + t; s += p < cells ? Lv.cnt[l][p] : 0; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) waveTotal[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kBlock / kWave; w++) t += waveTotal[w]; chunkSum[blockIdx.x] = t; }
+}
+
+// one block: per level, exclusive scan of the chunk sums (in place) and the level totals -> bases of every tree level
+__global__ __launch_bounds__(1024) void k_mb_scan_chunks(MbLevels Lv, int* __restrict__ chunkSum, MbTables* __restrict__ T) {
+    __shared__ int waveTotal[1024 / kWave];
+    __shared__ long long mixedOf[kMbMaxDepth + 2];              // [l] mixed cells of pyramid level l
+    const int R = Lv.R, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) mixedOf[R] = Lv.state[R][0] == 2 ? 1 : 0;
+    for (int l = 2; l <= R; l++) {
+        const long long c0 = Lv.cntOffset[l] / kMbChunk, c1 = Lv.cntOffset[l + 1] / kMbChunk;    // this level's chunks
+        const int nb = (int)(c1 - c0);
+        const int per = (nb + 1023) / 1024;
+        const int lo = min(t * per, nb), hi = min(lo + per, nb);
+        int s = 0;
+        for (int i = lo; i < hi; i++) s += chunkSum[c0 + i];
+        int incl = s;
+        for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        if (lane == kWave - 1) waveTotal[wave] = incl;
+        __syncthreads();
+        int run = incl - s, all = 0;
+        for (int w = 0; w < 1024 / kWave; w++) { const int v = waveTotal[w]; if (w < wave) run += v; all += v; }
+        for (int i = lo; i < hi; i++) { const int v = chunkSum[c0 + i]; chunkSum[c0 + i] = run; run += v; }
+        if (t == 0) mixedOf[l - 1] = all;                        // cnt[l] counts the mixed cells of level l-1
+        __syncthreads();
+    }
+    if (t == 0) {
+        // tree level L = R - l: 1 node at L = 0, else 8 per mixed cell of pyramid level l+1; internal nodes = mixed cells (l >= 1)
+        long long nodes = 0, internal = 0;
+        for (int L = 0; L <= R; L++) {
+            const int l = R - L;
+            const long long m = L == 0 ? 1 : 8 * mixedOf[l + 1];
+            T->levelBase[L] = nodes; T->internalBase[L] = internal;
+            nodes += m; internal += l >= 1 ? mixedOf[l] : 0;
+            if (m == 0) { for (int q = L + 1; q <= R + 1; q++) { T->levelBase[q] = nodes; T->internalBase[q] = internal; } break; }
+            if (L == R) { T->levelBase[R + 1] = nodes; T->internalBase[R + 1] = internal; }
+        }
+        T->total = nodes; T->internal = internal;
+    }
+}
+
+// group[l][p] = chunk base + exclusive prefix of cnt[l] inside the chunk; and, for every mixed child of p (a cell of level
+// l-1 that becomes an internal node), cellOf[descriptor index] = its Morton index: the emission then runs one thread per
+// internal node with every lane busy (mixed cells are ~1 % of the level-1 cells of a surface scene).
+__global__ __launch_bounds__(kBlock) void k_mb_group_ranks(MbLevels Lv, const int* __restrict__ chunkBase, const MbTables* __restrict__ T,
+                                                            unsigned* __restrict__ cellOf) {
+    __shared__ int waveTotal[kBlock / kWave];
+    const long long c0 = (long long)blockIdx.x * kMbChunk;
+    const int l = mb_level_of(Lv, c0);
+    const long long cells = 1ll << (3 * (Lv.R - l)), local0 = c0 - Lv.cntOffset[l];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // each thread owns 4 consecutive cells
+    const long long p0 = local0 + (long long)threadIdx.x * 4;
+    int v[4], sum = 0;
+    if (p0 + 3 < cells) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(Lv.cnt[l] + p0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { v[q] = (int)((w >> (8 * q)) & 0xffu); sum += v[q]; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { v[q] = p0 + q < cells ? Lv.cnt[l][p0 + q] : 0; sum += v[q]; }
+    }
+    int incl = sum;
+    for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    if (lane == kWave - 1) waveTotal[wave] = incl;
+    __syncthreads();
+    int run = chunkBase[blockIdx.x] + incl - sum;
+    for (int w = 0; w < wave; w++) run += waveTotal[w];
+    const long long dBase = T->internalBase[Lv.R - (l - 1)];                // descriptors of tree level R-(l-1) = the mixed cells of level l-1
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (p0 + q >= cells) break;
+        Lv.group[l][p0 + q] = run;
+        if (v[q]) {
+            const uint2 ch = *reinterpret_cast<const uint2*>(Lv.state[l - 1] + 8 * (p0 + q));
+            int r = run;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((((j < 4 ? ch.x : ch.y) >> ((j & 3) * 8)) & 0xffu) == 2u) cellOf[dBase + r++] = (unsigned)(8 * (p0 + q) + j);
+        }
+        run += v[q];
+    }
+}
+
+// A mixed cell (Morton index p of pyramid level l, rank `rank` among the mixed cells of its level) is an internal node: it
+// writes its descriptor and the records of its 8 children (leaf or internal).
+__device__ __forceinline__ void mb_emit_cell(const uint8_t* __restrict__ vox, const MbLevels& Lv, const MbTables* __restrict__ T, int l, long long p,
+                                             long long rank, rto_node* __restrict__ nodes, uint2* __restrict__ desc, int* __restrict__ descFirstChild) {
+    const int R = Lv.R, L = R - l;
+    const unsigned cx = mb_compact3((unsigned)p), cy = mb_compact3((unsigned)(p >> 1)), cz = mb_compact3((unsigned)(p >> 2));
+    int cs[8];
+    if (l >= 2) {
+        const uint2 ch = *reinterpret_cast<const uint2*>(Lv.state[l - 1] + 8 * p);
+#pragma unroll
+        for (int k = 0; k < 8; k++) cs[k] = (int)(((k < 4 ? ch.x : ch.y) >> ((k & 3) * 8)) & 0xffu);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) cs[k] = mb_voxel(vox, Lv.dimX, Lv.dimY, Lv.dimZ, (int)(2 * cx + (k & 1)), (int)(2 * cy + ((k >> 1) & 1)), (int)(2 * cz + (k >> 2)));
+    }
+    const long long childNode0 = T->levelBase[L + 1] + 8 * rank;          // node index of child 0
+    const long long grandBase = l >= 2 ? T->levelBase[L + 2] : 0;          // tree level of the grandchildren
+    const long long childRank0 = l >= 2 ? (long long)Lv.group[l][p] : 0;   // rank of the first child among the mixed cells of level l-1
+    unsigned imask = 0, smask = 0;
+    int before = 0;                                                       // mixed children before child k
+    const int half = 1 << (l - 1);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        rto_node nd;
+        nd.x = (int)(2 * cx + (k & 1)) * half; nd.y = (int)(2 * cy + ((k >> 1) & 1)) * half; nd.z = (int)(2 * cz + (k >> 2)) * half;
+        nd.size = half;
+        const bool internal = cs[k] == 2;
+        nd.isLeaf = internal ? 0 : 1; nd.isUniform = nd.isLeaf;            // S/OctreeVoxel.cpp:716-745: leaf <=> uniform
+        nd.isSolid = (!internal && cs[k] == 1) ? 1 : 0;
+        const long long g0 = grandBase + 8 * (childRank0 + before);
+#pragma unroll
+        for (int j = 0; j < 8; j++) nd.child[j] = internal ? (int)(g0 + j) : -1;
+        nodes[childNode0 + k] = nd;
+        if (internal) { imask |= 1u << k; before++; }
+        else if (cs[k] == 1) smask |= 1u << k;
+    }
+    const long long d = T->internalBase[L] + rank;
+    desc[d] = make_uint2(smask | (imask << 8) | 0xff0000u, imask ? (unsigned)(T->internalBase[L + 1] + childRank0) : 0u);
+    descFirstChild[d] = (int)childNode0;
+}
+
+// One thread per internal node (descriptor index d; thread `internal` handles the root's own record): level from the
+// descriptor bases, cell from cellOf (the root is cell 0 of level R).
+__global__ __launch_bounds__(kBlock) void k_mb_emit(const uint8_t* __restrict__ vox, MbLevels Lv, const MbTables* __restrict__ T,
+                                                     const unsigned* __restrict__ cellOf, rto_node* __restrict__ nodes, uint2* __restrict__ desc,
+                                                     int* __restrict__ descFirstChild) {
+    const long long d = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int R = Lv.R;
+    const long long internal = T->internal;
+    if (d > internal) return;
+    if (d == internal) {                                           // the root's own record
+        const int state = Lv.state[R][0];
+        rto_node nd;
+        nd.x = nd.y = nd.z = 0; nd.size = 1 << R;
+        nd.isLeaf = state == 2 ? 0 : 1; nd.isUniform = nd.isLeaf; nd.isSolid = state == 1 ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) nd.child[k] = state == 2 ? 1 + k : -1;
+        nodes[0] = nd;
+        return;
+    }
+    int L = 0;
+    while (L < R && d >= T->internalBase[L + 1]) L++;
+    const long long p = L == 0 ? 0 : (long long)cellOf[d];
+    mb_emit_cell(vox, Lv, T, R - L, p, d - T->internalBase[L], nodes, desc, descFirstChild);
+}
+
 // bounding box of the solid leaves (voxel units) for the launch-order heuristic.  Grid-stride over the nodes with a
 // small grid, wave + block reduction, then at most 6 atomics per BLOCK: same-address atomics serialise at ~10 ns
 // each (one set per 64 nodes cost 1 ms at 1.5 M nodes, one set per wave of a 1024-block grid still 0.29 ms).

@@ -25,7 +25,7 @@ NODE_DTYPE = np.dtype(
 # every symbol include/rto_hip.h declares
 SYMBOLS = (
     "rto_create", "rto_destroy", "rto_last_error", "rto_device_name",
-    "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel", "rto_set_launch_order", "rto_forget_stream",
+    "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_debug_set_build_path", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel", "rto_set_launch_order", "rto_forget_stream",
     "rto_update_frustum", "rto_debug_update_frustum_planes", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
     "rto_render_shade_device", "rto_assemble_shade_device", "rto_assemble_batch_device", "rto_render_batch_device", "rto_assemble_batch_all_device", "rto_render_resident", "rto_resident_frame", "rto_download_resident",
@@ -98,6 +98,7 @@ def load():
     L.rto_octree_info_get.argtypes = [vp, C.POINTER(OctreeInfo)]
     L.rto_build_octree.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float]
     L.rto_download_nodes.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.rto_debug_set_build_path.argtypes = [vp, C.c_int]
     L.rto_last_build_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rto_set_kernel.argtypes = [vp, C.c_int]
     L.rto_set_launch_order.argtypes = [vp, C.c_int, C.c_int]
@@ -214,6 +215,10 @@ class Context:
         dz, dy, dx = v.shape
         gm = (C.c_float * 3)(*[_f(x) for x in grid_min])
         self._check(self._L.rto_build_octree(self._h, v.ctypes.data, dx, dy, dz, gm, _f(voxel_size)))
+
+    def debug_set_build_path(self, level_by_level: bool):
+        """Force rto_build_octree's level-by-level form (True) or restore the automatic choice (False)."""
+        self._check(self._L.rto_debug_set_build_path(self._h, 1 if level_by_level else 0))
 
     def download_nodes(self) -> np.ndarray:
         cnt = C.c_int64()

@@ -990,8 +990,16 @@ def test_octree_ray_skip_matches_oracle(ctx, orc, scenes, camera):
     ctx.update_frustum(view, 45.0, 16 / 9, enable=False)
 
 
+@pytest.fixture(params=["morton", "level_by_level"])
+def build_path(request, ctx):
+    """rto_build_octree's two forms (seven launches with Morton-ordered pyramid levels / level by level): same arrays."""
+    ctx.debug_set_build_path(request.param == "level_by_level")
+    yield request.param
+    ctx.debug_set_build_path(False)
+
+
 @pytest.mark.parametrize("name", ["sphere16", "sphere64", "sphere256", "calgary", "odd"])
-def test_gpu_octree_build_equals_reference_arrays(ctx, orc, scenes, camera, golden_meta, name):
+def test_gpu_octree_build_equals_reference_arrays(ctx, orc, scenes, camera, golden_meta, name, build_path):
     """N4: the flat array built on the GPU from the voxel grid is byte-identical to createOctreeFromVoxelGrid +
     setOctree (oracle == reference goldens), and renders identically through the packed kernel."""
     import hashlib
@@ -1027,12 +1035,14 @@ def test_gpu_octree_build_equals_reference_arrays(ctx, orc, scenes, camera, gold
         ctx.update_frustum(view, 45.0, W / H, enable=False)
 
 
-def test_gpu_octree_build_degenerate_and_random_grids(ctx, orc):
+def test_gpu_octree_build_degenerate_and_random_grids(ctx, orc, build_path):
     rng = np.random.default_rng(3)
     cases = [((1, 1, 1), 1.0), ((1, 1, 1), 0.0), ((4, 4, 4), 1.0), ((4, 4, 4), 0.0), ((3, 3, 3), 1.0), ((7, 5, 3), 0.5),
              ((33, 9, 20), 0.9), ((64, 1, 1), 0.5), ((2, 3, 1), 0.0), ((17, 17, 17), 0.02),
              # dimX % 16 == 0 takes the 16-byte level-1 pyramid kernel: odd / single rows and slices, all states
-             ((16, 5, 7), 0.5), ((32, 33, 2), 0.9), ((48, 1, 1), 0.5), ((16, 16, 16), 1.0), ((16, 2, 3), 0.0), ((80, 37, 11), 0.03)]
+             ((16, 5, 7), 0.5), ((32, 33, 2), 0.9), ((48, 1, 1), 0.5), ((16, 16, 16), 1.0), ((16, 2, 3), 0.0), ((80, 37, 11), 0.03),
+             # several 32^3 bricks, some of them outside the grid (their cells must read EMPTY), sparse and dense
+             ((65, 40, 33), 0.002), ((96, 64, 32), 0.4), ((33, 33, 33), 0.0), ((64, 64, 64), 1.0), ((100, 3, 70), 0.1), ((2, 2, 2), 0.5)]
     for dims, p in cases:
         data = (rng.random((dims[2], dims[1], dims[0])) < p).astype(np.uint8)
         mn = np.array([0.5, -2.0, 3.0], np.float32)
@@ -1045,11 +1055,13 @@ def test_gpu_octree_build_degenerate_and_random_grids(ctx, orc):
     assert e.value.code == hip.RTO_E_INVALID
 
 
-def test_gpu_octree_build_512(ctx, orc, scenes):
+def test_gpu_octree_build_512(ctx, orc, scenes, build_path):
     s = scenes("sphere512")
     ctx.build_octree(s.grid.data, s.min, s.voxel)
     assert ctx.download_nodes().tobytes() == s.nodes.tobytes()
+    ctx.build_octree(s.grid.data, s.min, s.voxel)                # second build: scratch comes from the pool
     k_ms, up_ms = ctx.last_build_ms()
+    print(f"rto_build_octree 512^3 [{build_path}]: kernels {k_ms:.3f} ms, upload {up_ms:.3f} ms")
     assert 0 < k_ms < 1000
 
 

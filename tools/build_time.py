@@ -1,4 +1,5 @@
-"""N4 measurement: GPU octree build time vs the host builders."""
+"""rto_build_octree timing at 256^3 / 512^3 (both forms).  Under rocprofv3 --kernel-trace --stats this is the command behind
+profiles/r02_build_kernel_stats.csv."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -6,20 +7,18 @@ import numpy as np
 import ray_tracing_octrees_amd as rto
 
 ctx = rto.Context(0)
-for dim in (64, 256, 512):
+for dim in (256, 512):
     g = rto.VoxelGrid.test_sphere(dim)
     data = g.data
-    t = time.perf_counter(); root = rto.createOctreeFromVoxelGrid(g); t_host_build = time.perf_counter() - t
-    t = time.perf_counter(); flat = root.flatten(); t_host_flat = time.perf_counter() - t
-    rto.freeOctree(root)
-    ks, us = [], []
-    for _ in range(5):
-        ctx.build_octree(data, g.min, g.voxelSize)
-        k, u = ctx.last_build_ms(); ks.append(k); us.append(u)
-    n = ctx.info().num_nodes
-    vox = dim ** 3
-    k = float(np.median(ks)); u = float(np.median(us))
-    # algorithmic bytes: every voxel read once + the pyramid written once and read once (1/7 of the voxels each) + 60 B/node
-    alg = vox + 2 * vox / 7 + n * 60
-    print(f"sphere {dim}^3: nodes {n}; GPU build kernels {k:.3f} ms (H2D of {vox/1e6:.1f} MB voxels {u:.3f} ms) -> {vox/k/1e6:.1f} Gvoxel/s, "
-          f"{alg/k/1e6:.1f} GB/s algorithmic; host C++ pyramid build {t_host_build*1e3:.1f} ms + flatten {t_host_flat*1e3:.1f} ms")
+    for legacy in (False, True):
+        ctx.debug_set_build_path(legacy)
+        ks, ws = [], []
+        for _ in range(6):
+            t = time.perf_counter()
+            ctx.build_octree(data, g.min, g.voxelSize)
+            ws.append(time.perf_counter() - t)
+            ks.append(ctx.last_build_ms())
+        k = sorted(x[0] for x in ks[1:])[len(ks) // 2 - 1]
+        u = sorted(x[1] for x in ks[1:])[len(ks) // 2 - 1]
+        print(f"{dim}^3 {'level-by-level' if legacy else 'morton':15s}: device span after the upload {k:.3f} ms, H2D {u:.3f} ms, wall {min(ws[1:])*1e3:.3f} ms, nodes {ctx.info().num_nodes}")
+ctx.debug_set_build_path(False)
