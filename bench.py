@@ -45,6 +45,8 @@ NODE_BYTES = 60                # struct GPUNodes, the reference's node record (S
 PIXEL_BYTES = 16               # RGBA32F
 SIMDS, CLOCK_GHZ, VALU_CYCLES_PER_WAVE_INST = 1024, 2.4, 2   # 256 CUs x 4 SIMD-32: a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
 VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INST   # 1228.8 G wave-instructions/s
+LEAN_LOOP_CYCLES_PER_INST = 424.0 / 124.0   # k_trace_lean's loop trip: 124 VALU instructions, 424 issue cycles at the measured per-opcode
+                                            # costs (profiles/r02_valu_issue_rates.txt)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_counters.json")
 
 CONFIGS = {
@@ -549,6 +551,12 @@ def main(argv=None):
                 roofline["valu_insts_per_launch"] = int(insts)
                 if pmc.get("SQ_THREAD_CYCLES_VALU"):
                     roofline["lane_utilisation"] = round(float(pmc["SQ_THREAD_CYCLES_VALU"]) / (64.0 * insts), 3)
+                if kernel_name.startswith("k_trace_lean"):
+                    # `frac` prices every instruction at the guide's 2 cycles; two thirds of this loop's instructions are
+                    # half-rate on gfx950 (min/max, cvt, cmp, packed f32, 3-operand forms): at the measured issue costs
+                    busy = insts * LEAN_LOOP_CYCLES_PER_INST / (SIMDS * CLOCK_GHZ * 1e9) / (k_avg * 1e-3)
+                    roofline["issue_weighted"] = {"frac": round(busy, 4), "cycles_per_instruction": round(LEAN_LOOP_CYCLES_PER_INST, 3),
+                                                  "source": "profiles/r02_valu_issue_rates.txt x the loop's instruction mix (DESIGN.md section 5)"}
                 roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
                 roofline["traffic_source"] = {"file": "profiles/pmc_counters.json", "summary": pmc.get("source"), "commit": pmc.get("commit"),
                                               "device_source_hash": pmc.get("device_source_hash"),
@@ -570,7 +578,7 @@ def main(argv=None):
                     c2.setTarget(tg0)
                     oframes.append(rto.make_frame(c2.getView(), c2.getPos(), W / H, 45.0, W, H))
                 obuf = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
-                ctx.timing_begin(0)
+                ctx.timing_begin(-1)                      # no per-launch events: only the pair around the whole sequence below
                 for fr in oframes[:16]:
                     render_to(obuf.data_ptr(), stream.cuda_stream, fr)
                 torch.cuda.synchronize()
@@ -582,8 +590,9 @@ def main(argv=None):
                 eb.record(stream)
                 torch.cuda.synchronize()
                 wall = time.perf_counter() - t_o
-                orbit = {"frames": n_orbit, "rad_per_frame": 0.01, "launches": "plain stream launches, launch-order table rebuilt every "
-                         f"{args.order_period}-th frame (k_sort_scatter inside the timed region)",
+                ctx.timing_begin(0)
+                orbit = {"frames": n_orbit, "rad_per_frame": 0.01, "launches": "plain stream launches, launch-order table rebuilt when the geometry's tile box moves and at "
+                         f"least every {args.order_period}-th frame (k_order_build inside the timed region)",
                          "ms_per_frame": round(wall / n_orbit * 1e3, 5), "gpu_ms_per_frame": round(ea.elapsed_time(eb) / n_orbit, 5),
                          "Mrays_per_s": round(rays * n_orbit / wall / 1e6, 1)}
         pcie = None

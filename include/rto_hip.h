@@ -289,7 +289,9 @@ int  rto_last_kernel_ms(rto_context* ctx, float* ms);
 /* Per-launch timing without synchronising inside a timed loop: after rto_timing_begin(ctx, n) the next n
  * traversal-kernel launches are bracketed by their own hipEvent pair on the launch stream (just that kernel: the
  * launch-order kernel that may follow is outside the pair); rto_timing_read synchronises the device and returns the
- * durations in ms.  rto_timing_begin(ctx, 0) switches it off. */
+ * durations in ms.  rto_timing_begin(ctx, 0) switches it off (rto_last_kernel_ms keeps working: one event pair per launch).
+ * rto_timing_begin(ctx, -1) records no events at all until the next rto_timing_begin(ctx, >= 0): an event costs ~2 us
+ * between two dependent launches, which matters when frames of ~50 us are issued back to back without a HIP graph. */
 int  rto_timing_begin(rto_context* ctx, int capacity);
 int  rto_timing_read(rto_context* ctx, float* ms, int capacity, int* count);   /* ms may be NULL to query count */
 /* The context's own hipStream_t (used by the synchronous entry points). */

@@ -99,6 +99,7 @@ struct rto_context {
     Counters* d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool eventsOff = false;    // rto_timing_begin(ctx, -1): no hipEventRecord around the traversal kernels at all
     // optional ring of event pairs, one per traversal-kernel launch (rto_timing_begin / rto_timing_read)
     std::vector<hipEvent_t> ringStart, ringStop;
     size_t ringUsed = 0;
@@ -1079,10 +1080,11 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     const bool packed = c->kernelMode >= RTO_KERNEL_PACKED || (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
     if (packed && !c->canonical) return fail(c, RTO_E_UNSUPPORTED, "render: packed kernel needs a canonical BFS octree");
     const bool capturing = stream_is_capturing(s);
+    const bool noEvents = capturing || c->eventsOff;     // events inside a capture cannot be timed; each record costs ~2 us between launches
     bool stopRecorded = false;
     hipEvent_t evA = c->ev0, evB = c->ev1;
     // a timing-ring slot is only taken by a launch that records events (events inside a capture cannot be timed)
-    if (!capturing && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
+    if (!noEvents && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
     bool startRecorded = false;
     // culling edge (S/RT:765-812): the root was culled but descendants survive.  The reference then starts at whatever
     // node landed at compacted index 0; only the generic kernel over the compacted array can follow that literally.
@@ -1090,7 +1092,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     if (packed && !rootCulledEdge) {
         const size_t lds = (size_t)(kBlock / kWave) * (P.depth + 1) * kWave * sizeof(uint2);   // +1: the lean kernel's dummy entry
         if (c->kernelMode == RTO_KERNEL_PACKED_V1) {
-            if (!capturing) RTO_HIP(c, hipEventRecord(evA, s));
+            if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
             startRecorded = true;
             hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
         } else {
@@ -1103,7 +1105,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 if (rc != RTO_OK) return rc;
             }
             const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
-            if (!capturing) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
+            if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
             startRecorded = true;
             const bool persistent = c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT && st && frameMode;
             if (persistent) {
@@ -1131,15 +1133,15 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
         RenderParams Q = P;
         if (c->culling && c->visibleNodes == 0) Q.rootVisible = 0;   // empty SSBO: nothing to traverse
         else if (c->culling) Q.rootVisible = 1;                      // compacted index 0 is whatever survived first (S/RT:765-772)
-        if (!capturing) RTO_HIP(c, hipEventRecord(evA, s));
+        if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
         startRecorded = true;
         hipLaunchKernelGGL(k_trace_generic<MODE>, dim3(blocks), dim3(kBlock), 0, s, Q, nodes, d_out, c->d_steps, c->d_counters);
     }
     RTO_HIP(c, hipGetLastError());
     (void)startRecorded;
-    if (!stopRecorded && !capturing) RTO_HIP(c, hipEventRecord(evB, s));
+    if (!stopRecorded && !noEvents) RTO_HIP(c, hipEventRecord(evB, s));
     if (evA != c->ev0) { c->lastA = evA; c->lastB = evB; } else { c->lastA = c->ev0; c->lastB = c->ev1; }
-    c->timed = !capturing;
+    c->timed = !noEvents;
     return RTO_OK;
 }
 
@@ -1486,7 +1488,8 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
         const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
         if ((rc = prepare_schedule(c, s, capturing, !count, false, 1, solidRect, P, &st)) != RTO_OK) return rc;
     }
-    if (!capturing) RTO_HIP(c, hipEventRecord(c->ev0, s));
+    const bool noEvents = capturing || c->eventsOff;
+    if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev0, s));
     if (packed) {
         PackedTriScene S{ c->d_desc, c->d_descFirstChild, c->d_tris, c->d_triOffset };
         const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint4);
@@ -1501,8 +1504,8 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
         else hipLaunchKernelGGL((k_trace_triangles<kModeColor, false>), dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
     }
     RTO_HIP(c, hipGetLastError());
-    if (!capturing) RTO_HIP(c, hipEventRecord(c->ev1, s));
-    c->timed = !capturing;
+    if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev1, s));
+    c->timed = !noEvents;
     return RTO_OK;
 }
 
@@ -1617,7 +1620,9 @@ int rto_last_kernel_ms(rto_context* c, float* ms) {
 }
 
 int rto_timing_begin(rto_context* c, int capacity) {
-    if (!c || capacity < 0) return RTO_E_INVALID;
+    if (!c || capacity < -1) return RTO_E_INVALID;
+    c->eventsOff = capacity < 0;
+    if (capacity < 0) capacity = 0;
     RTO_HIP(c, hipSetDevice(c->device));
     RTO_HIP(c, hipDeviceSynchronize());
     for (hipEvent_t e : c->ringStart) (void)hipEventDestroy(e);

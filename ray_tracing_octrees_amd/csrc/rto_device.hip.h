@@ -1101,10 +1101,11 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_persisten
 // Launch order of the box's tiles: a counting sort by descending cost (trip count an earlier frame recorded, 64
 // buckets of min(trips, 63)) done by ONE 1,024-thread block -- a few thousand tiles, no inter-block state: whatever the
 // cost array holds (stale values, tiles that were outside the box when it was written), the result is a permutation of
-// the box's tiles (entries tx | ty << 16), so every tile is rendered exactly once.  The buckets are staged in LDS first (one pass of independent,
-// coalesced loads: reading the costs inside the counting loops cost a dependent global load per step, 80 us per build);
-// wave w then owns the id range [w*chunk, (w+1)*chunk) of the box (ids row-major over boxW x boxH) and counts / places
-// its tiles with LDS atomics.  Tiles of one bucket keep their wave order; within a wave the order is the atomics'.
+// the box's tiles (entries tx | ty << 16), so every tile is rendered exactly once.  Wave w owns the box rows w, w+16, ...
+// (lanes walk a row: no division anywhere); the buckets of its tiles are staged in LDS by one pass of independent,
+// coalesced loads (reading the costs inside the counting loops cost a dependent global load per step, 80 us per build),
+// then counted and placed with LDS atomics.  Tiles of one bucket keep their wave order; within a wave the order is the
+// atomics'.
 constexpr int kOrderBuckets = 64;
 constexpr int kOrderBlock = 1024;
 constexpr int kOrderLdsTiles = 144 * 1024;          // buckets staged in LDS (1 byte per tile); larger boxes re-read the costs
@@ -1112,43 +1113,44 @@ constexpr int kOrderLdsTiles = 144 * 1024;          // buckets staged in LDS (1 
 __global__ __launch_bounds__(kOrderBlock) void k_order_build(const int* __restrict__ tileCost, int tilesX, int boxX0, int boxY0, int boxW, int boxH,
                                                               int staged, int* __restrict__ order, int* __restrict__ violations) {
     constexpr int kWaves = kOrderBlock / kWave;
-    extern __shared__ unsigned char stagedBucket[];  // [n] when staged
+    extern __shared__ unsigned char stagedBucket[];  // [boxH][boxW] when staged
     __shared__ int cnt[kWaves][kOrderBuckets];      // pass 1: counts; then each wave's write cursor per bucket
-    __shared__ int bucketBase[kOrderBuckets];
     const int n = boxW * boxH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunk = ((n + kWaves - 1) / kWaves + kWave - 1) / kWave * kWave;
-    const int lo = wave * chunk, hi = min(n, lo + chunk);
-    auto tile_of_id = [&](int i) { const int ry = i / boxW, rx = i - ry * boxW; return (boxY0 + ry) * tilesX + boxX0 + rx; };
-    auto bucket_of = [&](int i) {
-        return staged ? (int)stagedBucket[i] : min(max(tileCost[tile_of_id(i)], 0), kOrderBuckets - 1);
-    };
+    auto bucket_at = [&](int rx, int ry) { return min(max(tileCost[(boxY0 + ry) * tilesX + boxX0 + rx], 0), kOrderBuckets - 1); };
     for (int i = threadIdx.x; i < kWaves * kOrderBuckets; i += kOrderBlock) (&cnt[0][0])[i] = 0;
     if (staged)
-        for (int i = threadIdx.x; i < n; i += kOrderBlock) stagedBucket[i] = (unsigned char)min(max(tileCost[tile_of_id(i)], 0), kOrderBuckets - 1);
+        for (int ry = wave; ry < boxH; ry += kWaves)
+            for (int rx0 = lane; rx0 < boxW; rx0 += 4 * kWave) {          // four independent loads in flight per lane
+                int v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = rx0 + q * kWave < boxW ? bucket_at(rx0 + q * kWave, ry) : 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (rx0 + q * kWave < boxW) stagedBucket[ry * boxW + rx0 + q * kWave] = (unsigned char)v[q];
+            }
     __syncthreads();
-    for (int i = lo + lane; i < hi; i += kWave) atomicAdd(&cnt[wave][bucket_of(i)], 1);
+    for (int ry = wave; ry < boxH; ry += kWaves)
+        for (int rx = lane; rx < boxW; rx += kWave) atomicAdd(&cnt[wave][staged ? (int)stagedBucket[ry * boxW + rx] : bucket_at(rx, ry)], 1);
     __syncthreads();
-    if (threadIdx.x < kOrderBuckets) {              // per bucket: exclusive prefix over the waves, total
-        int run = 0;
-        for (int w = 0; w < kWaves; w++) { const int h = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += h; }
-        bucketBase[threadIdx.x] = run;
+    // write cursors: costlier buckets first, within a bucket wave 0 first.  Wave 0 does it: lane b owns bucket 63 - b.
+    if (wave == 0) {
+        const int b = kOrderBuckets - 1 - lane;
+        int total = 0;
+        for (int w = 0; w < kWaves; w++) total += cnt[w][b];
+        int incl = total;
+        for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        int run = incl - total;                                   // tiles of costlier buckets
+        for (int w = 0; w < kWaves; w++) { const int h = cnt[w][b]; cnt[w][b] = run; run += h; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {                         // costlier buckets first
-        int run = 0;
-        for (int b = kOrderBuckets - 1; b >= 0; b--) { const int h = bucketBase[b]; bucketBase[b] = run; run += h; }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kWaves * kOrderBuckets; i += kOrderBlock) (&cnt[0][0])[i] += bucketBase[i % kOrderBuckets];
-    __syncthreads();
-    for (int i = lo + lane; i < hi; i += kWave) {
-        const int pos = atomicAdd(&cnt[wave][bucket_of(i)], 1);
-        // cannot fall outside by construction (both passes see the same buckets: the kernel that writes the costs runs
-        // before or after this one on the stream, never beside it); refused writes are counted and tests assert 0
-        if (pos >= 0 && pos < n) { const int ry = i / boxW, rx = i - ry * boxW; order[pos] = (boxX0 + rx) | ((boxY0 + ry) << 16); }
-        else atomicAdd(violations, 1);
-    }
+    for (int ry = wave; ry < boxH; ry += kWaves)
+        for (int rx = lane; rx < boxW; rx += kWave) {
+            const int pos = atomicAdd(&cnt[wave][staged ? (int)stagedBucket[ry * boxW + rx] : bucket_at(rx, ry)], 1);
+            // cannot fall outside by construction (both passes see the same buckets: the kernel that writes the costs runs
+            // before or after this one on the stream, never beside it); refused writes are counted and tests assert 0
+            if (pos >= 0 && pos < n) order[pos] = (boxX0 + rx) | ((boxY0 + ry) << 16);
+            else atomicAdd(violations, 1);
+        }
 }
 
 // ================================================================ frustum culling (N3)
