@@ -108,7 +108,7 @@ int  rto_upload_octree(rto_context* ctx, const rto_node* nodes, int64_t num_node
 int  rto_build_octree(rto_context* ctx, const uint8_t* voxels, int dim_x, int dim_y, int dim_z,
                       const float grid_min[3], float voxel_size);
 int  rto_download_nodes(rto_context* ctx, rto_node* out, int64_t capacity, int64_t* count);   /* out may be NULL */
-/* Developer aid: rto_build_octree has two forms that produce the same arrays -- seven launches for any depth (pyramid
+/* Developer aid: rto_build_octree has two forms that produce the same arrays -- four launches for any depth (pyramid
  * levels kept in Morton order, every tree level ranked and emitted at once; grids up to 1024^3) and a level-by-level
  * form (~5 launches per level; any size).  level_by_level != 0 forces the second, 0 restores the automatic choice. */
 int  rto_debug_set_build_path(rto_context* ctx, int level_by_level);

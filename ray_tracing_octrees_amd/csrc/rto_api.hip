@@ -353,10 +353,11 @@ struct BuildScratch {
 };
 }  // namespace
 
-// The seven-launch build (k_mb_*): fills c->d_nodes / d_desc / d_descFirstChild from c->d_vox.  *total / *internal: sizes;
+// The four-launch build (k_mb_*): fills c->d_nodes / d_desc / d_descFirstChild from c->d_vox.  *total / *internal: sizes;
 // solidBox: lo[3], hi[3] of the cells that hold FILLED voxels (level-1 cell precision; lo > hi: nothing solid).
+// The voxels are uploaded here (between the events e0 and e1), after the scratch has been allocated and the chunk sums zeroed.
 static int build_octree_morton(rto_context* c, hipStream_t s, BuildScratch& scratch, int R, int dimX, int dimY, int dimZ,
-                               int64_t* total, int64_t* internal, int solidBox[6]) {
+                               const uint8_t* voxels, hipEvent_t e0, hipEvent_t e1, int64_t* total, int64_t* internal, int solidBox[6]) {
     MbLevels Lv;
     std::memset(&Lv, 0, sizeof Lv);
     Lv.R = R; Lv.dimX = dimX; Lv.dimY = dimY; Lv.dimZ = dimZ;
@@ -389,10 +390,12 @@ static int build_octree_morton(rto_context* c, hipStream_t s, BuildScratch& scra
     RTO_HIP(c, scratch.alloc(&d_chunk, (size_t)chunks + 1));
     RTO_HIP(c, scratch.alloc(&d_brickBox, (size_t)numBricks * 6));
     RTO_HIP(c, scratch.alloc(&d_tab, 1));
-    hipLaunchKernelGGL(k_mb_bricks, dim3((unsigned)numBricks), dim3(kBlock), 0, s, c->d_vox, Lv, bricksX, runsX, bricksY, d_brickBox);
-    hipLaunchKernelGGL(k_mb_top, dim3(1), dim3(1024), 0, s, Lv, d_brickBox, numBricks, d_tab);
-    if (chunks) hipLaunchKernelGGL(k_mb_chunk_sums, dim3(chunks), dim3(kBlock), 0, s, Lv, d_chunk);
-    hipLaunchKernelGGL(k_mb_scan_chunks, dim3(1), dim3(1024), 0, s, Lv, d_chunk, d_tab);
+    RTO_HIP(c, hipMemsetAsync(d_chunk, 0, ((size_t)chunks + 1) * sizeof(int), s));       // summed into by atomics
+    RTO_HIP(c, hipEventRecord(e0, s));
+    RTO_HIP(c, hipMemcpyAsync(c->d_vox, voxels, (size_t)dimX * dimY * dimZ, hipMemcpyHostToDevice, s));
+    RTO_HIP(c, hipEventRecord(e1, s));
+    hipLaunchKernelGGL(k_mb_bricks, dim3((unsigned)numBricks), dim3(kBlock), 0, s, c->d_vox, Lv, bricksX, runsX, bricksY, d_brickBox, d_chunk);
+    hipLaunchKernelGGL(k_mb_top_scan, dim3(1), dim3(1024), 0, s, Lv, d_brickBox, numBricks, d_chunk, d_tab);
     RTO_HIP(c, hipGetLastError());
     MbTables tab;
     RTO_HIP(c, hipMemcpyAsync(&tab, d_tab, sizeof tab, hipMemcpyDeviceToHost, s));
@@ -419,8 +422,8 @@ static int build_octree_morton(rto_context* c, hipStream_t s, BuildScratch& scra
     unsigned* d_cellOf = nullptr;                                  // descriptor index -> Morton index of the cell (its level follows from the bases)
     RTO_HIP(c, scratch.alloc(&d_cellOf, (size_t)tab.internal + 1));
     if (chunks) hipLaunchKernelGGL(k_mb_group_ranks, dim3(chunks), dim3(kBlock), 0, s, Lv, d_chunk, d_tab, d_cellOf);
-    hipLaunchKernelGGL(k_mb_emit, dim3((unsigned)((tab.internal + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, c->d_vox, Lv, d_tab, d_cellOf,
-                       c->d_nodes, c->d_desc, c->d_descFirstChild);
+    hipLaunchKernelGGL(k_mb_emit, dim3((unsigned)std::max<int64_t>(1, (tab.internal + kMbEmitCells - 1) / kMbEmitCells)), dim3(kBlock), 0, s,
+                       c->d_vox, Lv, d_tab, d_cellOf, c->d_nodes, c->d_desc, c->d_descFirstChild);
     RTO_HIP(c, hipGetLastError());
     return RTO_OK;
 }
@@ -452,21 +455,20 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     uint8_t* d_vox = nullptr;
     RTO_HIP(c, hipMalloc(&d_vox, nvox));
     c->d_vox = d_vox; c->voxDim[0] = dimX; c->voxDim[1] = dimY; c->voxDim[2] = dimZ;    // kept: rto_build_leaf_triangles reads it
-    RTO_HIP(c, hipEventRecord(e0, s));
-    RTO_HIP(c, hipMemcpyAsync(d_vox, voxels, nvox, hipMemcpyHostToDevice, s));
-    RTO_HIP(c, hipEventRecord(e1, s));
-
     int64_t total = 0, internal = 0;
     int box[6];
     bool haveBox = false;              // the Morton-order build delivers the solid box with its one read-back
     int* d_bbox = nullptr;
     RTO_HIP(c, scratch.alloc(&d_bbox, 6));
     if (R >= 1 && R <= kMbMaxDepth && c->buildPath == 0) {
-        // seven launches whatever the depth: every level ranked and emitted at once (Morton order == BFS order within a level)
-        const int rc = build_octree_morton(c, s, scratch, R, dimX, dimY, dimZ, &total, &internal, box);
+        // four launches whatever the depth: every level ranked and emitted at once (Morton order == BFS order within a level)
+        const int rc = build_octree_morton(c, s, scratch, R, dimX, dimY, dimZ, voxels, e0, e1, &total, &internal, box);
         if (rc != RTO_OK) return rc;
         haveBox = true;
     } else {
+        RTO_HIP(c, hipEventRecord(e0, s));
+        RTO_HIP(c, hipMemcpyAsync(d_vox, voxels, nvox, hipMemcpyHostToDevice, s));
+        RTO_HIP(c, hipEventRecord(e1, s));
         // level-by-level form (any depth up to kMaxDepth; also the cross-check of the other: rto_debug_set_build_path)
         // ---- occupancy pyramid, bottom-up; every level also leaves its number of mixed cells = internal nodes
         PyramidView V;

@@ -1932,7 +1932,7 @@ __global__ __launch_bounds__(kBlock) void k_build_emit(const int4* __restrict__ 
     nodes[levelBase + i] = nd;
 }
 
-// ---------------------------------------------------------------- N4, second form: the same tree in SEVEN launches
+// ---------------------------------------------------------------- N4, second form: the same tree in FOUR launches
 // The level-by-level form above needs ~5 dependent launches per tree level (~50 at 512^3: launch-bound, 0.48 ms).  The BFS
 // numbering of setOctree has a closed form that removes the dependency between levels: children are appended in child
 // order k = x | y<<1 | z<<2 below parents that are themselves in that order, so WITHIN a tree level the nodes are sorted by
@@ -1942,11 +1942,14 @@ __global__ __launch_bounds__(kBlock) void k_build_emit(const int4* __restrict__ 
 // and every level can be ranked and emitted at once:
 //   k_mb_bricks      voxels -> pyramid levels 1..5 of one 32^3 brick (LDS), written in Morton order, with the number of
 //                    mixed children of every cell (cnt); one block per brick that touches the grid
-//   k_mb_top         levels 6..R from level 5 (one block)
-//   k_mb_chunk_sums / k_mb_scan_chunks / k_mb_group_ranks
-//                    exclusive scan of cnt over all levels: G[level][p] = mixed cells of the level below that precede
-//                    p's first child; per-level totals -> node / descriptor bases -> ONE read-back sizes the outputs
-//   k_mb_emit        one thread per pyramid cell: a mixed cell writes its descriptor and its 8 children's records
+//                    mixed children of every cell (cnt); one block per run of bricks that touches the grid; the sums of cnt
+//                    per 1024-cell chunk go to the scan's chunk sums as it goes (integer atomics)
+//   k_mb_top_scan    one block: levels 6..R from level 5, then the exclusive scan of the chunk sums per level and the
+//                    per-level totals -> node / descriptor bases -> ONE read-back sizes the outputs
+//   k_mb_group_ranks exclusive scan of cnt inside every chunk: G[level][p] = mixed cells of the level below that precede
+//                    p's first child; cellOf[descriptor] = Morton index of the cell that becomes that internal node
+//   k_mb_emit        one thread per CHILD of an internal node (8 per cell): the records of a block are contiguous in the
+//                    array (node 1 + 8 d + k), so they are staged in LDS and leave as 16-byte stores
 // Bytes: voxels read once (1 B/voxel), pyramid + counts written and read once (2 x 2/7 B/voxel), 60 B per node written.
 constexpr int kMbBrickLevels = 5;                 // a brick is 32^3 voxels
 constexpr int kMbMaxDepth = 10;                   // Morton arrays of level 1 hold 8^(R-1) bytes: 134 MB at R = 10
@@ -2011,11 +2014,18 @@ __device__ __forceinline__ int mb_combine(const int s[8], int* mixedChildren) {
 constexpr int kMbRun = 4;
 constexpr int kMbBrickLds = 4096 + 512 + 64 + 16 + 16;       // levels 1..5 of one brick, 16-byte aligned each
 
+// 0x80 in every byte of w that equals 1 (exact: no carries between bytes)
+__device__ __forceinline__ unsigned mb_bytes_eq1(unsigned w) {
+    const unsigned t = w ^ 0x01010101u;
+    return ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);
+}
+
 __global__ __launch_bounds__(kBlock) void k_mb_bricks(const uint8_t* __restrict__ vox, MbLevels Lv, int bricksX, int runsX, int bricksY,
-                                                       int* __restrict__ blockBox /* [block][6] */) {
+                                                       int* __restrict__ blockBox /* [block][6] */, int* __restrict__ chunkSum /* zeroed */) {
     __shared__ __attribute__((aligned(16))) uint8_t st[kMbRun][kMbBrickLds];
     __shared__ __attribute__((aligned(16))) uint8_t ct[kMbRun][kMbBrickLds];          // mixed-children counts (level 1: always 0)
     __shared__ int box[6];
+    __shared__ int mixedSum[kMbRun][kMbBrickLevels + 1];                              // [brick][l]: sum of cnt over the brick's cells of level l
     const int R = Lv.R;
     const int B = R < kMbBrickLevels ? R : kMbBrickLevels;
     const int rx = blockIdx.x % runsX, by = (blockIdx.x / runsX) % bricksY, bz = blockIdx.x / (runsX * bricksY);
@@ -2023,6 +2033,7 @@ __global__ __launch_bounds__(kBlock) void k_mb_bricks(const uint8_t* __restrict_
     const int nb = min(kMbRun, bricksX - bx0);                                    // bricks of this run that touch the grid
     const int x0 = bx0 << kMbBrickLevels, y0 = by << kMbBrickLevels, z0 = bz << kMbBrickLevels;
     if (threadIdx.x < 6) box[threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : -0x7fffffff;
+    if (threadIdx.x < kMbRun * (kMbBrickLevels + 1)) (&mixedSum[0][0])[threadIdx.x] = 0;
     __syncthreads();
     // ---- level 1 from the voxels: one thread = 8 cells along x (16 voxels of four rows); 2 * nb such strips per cell row
     int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
@@ -2047,21 +2058,29 @@ __global__ __launch_bounds__(kBlock) void k_mb_bricks(const uint8_t* __restrict_
                 }
             }
         }
-        const unsigned mjk = (mb_spread3((unsigned)j) << 1) | (mb_spread3((unsigned)k) << 2);
-        bool stripAny = false;
+        // 16 bytes of the four rows at once: a byte is FILLED iff it equals 1, anything else (incl. outside the grid) is EMPTY
+        const unsigned mjk = (mb_spread3((unsigned)j) << 1) | (mb_spread3((unsigned)k) << 2) | mb_spread3((unsigned)sx);   // sx is 0 or 8: no carry into o
+        unsigned anyMask = 0;                                                   // bit o: cell o holds a FILLED voxel
 #pragma unroll
-        for (int o = 0; o < 8; o++) {
-            bool any0 = false, any1 = false;
+        for (int q = 0; q < 4; q++) {
+            const unsigned e0 = mb_bytes_eq1(q == 0 ? row[0].x : q == 1 ? row[0].y : q == 2 ? row[0].z : row[0].w);
+            const unsigned e1 = mb_bytes_eq1(q == 0 ? row[1].x : q == 1 ? row[1].y : q == 2 ? row[1].z : row[1].w);
+            const unsigned e2 = mb_bytes_eq1(q == 0 ? row[2].x : q == 1 ? row[2].y : q == 2 ? row[2].z : row[2].w);
+            const unsigned e3 = mb_bytes_eq1(q == 0 ? row[3].x : q == 1 ? row[3].y : q == 2 ? row[3].z : row[3].w);
+            const unsigned anyW = e0 | e1 | e2 | e3, allW = e0 & e1 & e2 & e3;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const unsigned w = (o >> 1) == 0 ? row[r].x : (o >> 1) == 1 ? row[r].y : (o >> 1) == 2 ? row[r].z : row[r].w;
-                const unsigned a = (w >> ((o & 1) * 16)) & 0xffu, b = (w >> ((o & 1) * 16 + 8)) & 0xffu;
-                any1 |= (a == 1) | (b == 1); any0 |= (a != 1) | (b != 1);      // anything but FILLED (incl. outside the grid) is EMPTY
+            for (int h = 0; h < 2; h++) {
+                const int o = 2 * q + h;
+                const bool any1 = ((anyW >> (16 * h)) & 0x8080u) != 0, all1 = ((allW >> (16 * h)) & 0x8080u) == 0x8080u;
+                constexpr unsigned kSpreadO[8] = { 0x0u, 0x1u, 0x8u, 0x9u, 0x40u, 0x41u, 0x48u, 0x49u };     // mb_spread3(o)
+                st[sb][kSpreadO[o] | mjk] = any1 ? (all1 ? 1 : 2) : 0;
+                anyMask |= any1 ? 1u << o : 0u;
             }
-            st[sb][mb_spread3((unsigned)(sx + o)) | mjk] = (any0 && any1) ? 2 : (any1 ? 1 : 0);
-            if (any1) { lo[0] = min(lo[0], vx + 2 * o); hi[0] = max(hi[0], vx + 2 * o + 2); stripAny = true; }
         }
-        if (stripAny) { lo[1] = min(lo[1], vy); hi[1] = max(hi[1], vy + 2); lo[2] = min(lo[2], vz); hi[2] = max(hi[2], vz + 2); }
+        if (anyMask) {
+            lo[0] = min(lo[0], vx + 2 * (int)__builtin_ctz(anyMask)); hi[0] = max(hi[0], vx + 2 * (32 - (int)__builtin_clz(anyMask)));
+            lo[1] = min(lo[1], vy); hi[1] = max(hi[1], vy + 2); lo[2] = min(lo[2], vz); hi[2] = max(hi[2], vz + 2);
+        }
     }
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -2084,9 +2103,20 @@ __global__ __launch_bounds__(kBlock) void k_mb_bricks(const uint8_t* __restrict_
             int mixedChildren;
             st[sb][offN + m] = (uint8_t)mb_combine(s8, &mixedChildren);
             ct[sb][offN + m] = (uint8_t)mixedChildren;
+            if (mixedChildren) atomicAdd(&mixedSum[sb][l], mixedChildren);        // mixed cells are a few per cent of a surface scene
         }
         __syncthreads();
         off = offN; cells = cellsN;
+    }
+    // ---- this block's share of the scan's chunk sums (k_mb_top_scan adds the levels above the bricks)
+    if ((int)threadIdx.x < nb * (B - 1)) {
+        const int sb = threadIdx.x / (B - 1), l = 2 + threadIdx.x % (B - 1);
+        const int v = mixedSum[sb][l];
+        if (v) {
+            const unsigned mb = mb_morton((unsigned)(bx0 + sb), (unsigned)by, (unsigned)bz);
+            const long long cell0 = R >= kMbBrickLevels ? (long long)mb << (3 * (kMbBrickLevels - l)) : 0;
+            atomicAdd(&chunkSum[(Lv.cntOffset[l] + cell0) / kMbChunk], v);
+        }
     }
     // ---- write-out (16 bytes per thread where a level has them): level l holds 8^(5-l) cells of a brick at morton(brick) << 3*(5-l)
     const bool whole = R >= kMbBrickLevels;                       // the bricks lie inside the root cube: every local cell exists
@@ -2115,44 +2145,6 @@ __global__ __launch_bounds__(kBlock) void k_mb_bricks(const uint8_t* __restrict_
     }
 }
 
-// levels B+1..R from level B, one block (at most 8^4 cells on level 6 of a 1024^3 grid); also the union of the brick boxes
-__global__ __launch_bounds__(1024) void k_mb_top(MbLevels Lv, const int* __restrict__ brickBox, int numBricks, MbTables* __restrict__ T) {
-    __shared__ int part[1024 / kWave][6];
-    const int R = Lv.R;
-    const int B = R < kMbBrickLevels ? R : kMbBrickLevels;
-    for (int l = B + 1; l <= R; l++) {
-        const long long cells = 1ll << (3 * (R - l));
-        for (long long p = threadIdx.x; p < cells; p += 1024) {
-            const uint2 ch = *reinterpret_cast<const uint2*>(Lv.state[l - 1] + 8 * p);
-            int s8[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) s8[c] = (int)(((c < 4 ? ch.x : ch.y) >> ((c & 3) * 8)) & 0xffu);
-            int mixedChildren;
-            Lv.state[l][p] = (uint8_t)mb_combine(s8, &mixedChildren);
-            Lv.cnt[l][p] = (uint8_t)mixedChildren;
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
-    for (int b = threadIdx.x; b < numBricks; b += 1024)
-#pragma unroll
-        for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], brickBox[(size_t)b * 6 + a]); hi[a] = max(hi[a], brickBox[(size_t)b * 6 + 3 + a]); }
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-        for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], __shfl_down(lo[a], o)); hi[a] = max(hi[a], __shfl_down(hi[a], o)); }
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int a = 0; a < 3; a++) { part[threadIdx.x >> 6][a] = lo[a]; part[threadIdx.x >> 6][3 + a] = hi[a]; }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        const int a = threadIdx.x;
-        int v = part[0][a];
-        for (int w = 1; w < 1024 / kWave; w++) v = a < 3 ? min(v, part[w][a]) : max(v, part[w][a]);
-        if (a < 3) T->solidLo[a] = v; else T->solidHi[a - 3] = v;
-    }
-}
-
 // scan domain: cnt[2], cnt[3], ..., cnt[R] back to back, each level padded to a multiple of kMbChunk
 __device__ __forceinline__ int mb_level_of(const MbLevels& Lv, long long idx) {
     int l = 2;
@@ -2160,39 +2152,67 @@ __device__ __forceinline__ int mb_level_of(const MbLevels& Lv, long long idx) {
     return l;
 }
 
-__global__ __launch_bounds__(kBlock) void k_mb_chunk_sums(MbLevels Lv, int* __restrict__ chunkSum) {
-    __shared__ int waveTotal[kBlock / kWave];
-    const long long c0 = (long long)blockIdx.x * kMbChunk;
-    const int l = mb_level_of(Lv, c0);
-    const long long cells = 1ll << (3 * (Lv.R - l)), local0 = c0 - Lv.cntOffset[l];
-    int s = 0;
-    for (int t = threadIdx.x; t < kMbChunk; t += kBlock) { const long long p = local0 + t; s += p < cells ? Lv.cnt[l][p] : 0; }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if ((threadIdx.x & 63) == 0) waveTotal[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kBlock / kWave; w++) t += waveTotal[w]; chunkSum[blockIdx.x] = t; }
-}
-
-// one block: per level, exclusive scan of the chunk sums (in place) and the level totals -> bases of every tree level
-__global__ __launch_bounds__(1024) void k_mb_scan_chunks(MbLevels Lv, int* __restrict__ chunkSum, MbTables* __restrict__ T) {
+// One block, after the bricks: (1) levels B+1..R from level B (at most 8^4 cells on level 6 of a 1024^3 grid) and their share
+// of the chunk sums; (2) the union of the brick boxes; (3) per level, the exclusive scan of the chunk sums (in place) and the
+// level totals -> bases of every tree level.
+__global__ __launch_bounds__(1024) void k_mb_top_scan(MbLevels Lv, const int* __restrict__ brickBox, int numBricks, int* __restrict__ chunkSum,
+                                                      MbTables* __restrict__ T) {
+    __shared__ int part[1024 / kWave][6];
     __shared__ int waveTotal[1024 / kWave];
     __shared__ long long mixedOf[kMbMaxDepth + 2];              // [l] mixed cells of pyramid level l
     const int R = Lv.R, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int B = R < kMbBrickLevels ? R : kMbBrickLevels;
+    for (int l = B + 1; l <= R; l++) {
+        const long long cells = 1ll << (3 * (R - l));
+        for (long long p = t; p < cells; p += 1024) {
+            const uint2 ch = *reinterpret_cast<const uint2*>(Lv.state[l - 1] + 8 * p);
+            int s8[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) s8[c] = (int)(((c < 4 ? ch.x : ch.y) >> ((c & 3) * 8)) & 0xffu);
+            int mixedChildren;
+            Lv.state[l][p] = (uint8_t)mb_combine(s8, &mixedChildren);
+            Lv.cnt[l][p] = (uint8_t)mixedChildren;
+            if (mixedChildren) atomicAdd(&chunkSum[(Lv.cntOffset[l] + p) / kMbChunk], mixedChildren);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
+    for (int b = t; b < numBricks; b += 1024)
+#pragma unroll
+        for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], brickBox[(size_t)b * 6 + a]); hi[a] = max(hi[a], brickBox[(size_t)b * 6 + 3 + a]); }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], __shfl_down(lo[a], o)); hi[a] = max(hi[a], __shfl_down(hi[a], o)); }
+    if (lane == 0)
+#pragma unroll
+        for (int a = 0; a < 3; a++) { part[wave][a] = lo[a]; part[wave][3 + a] = hi[a]; }
+    __threadfence();
+    __syncthreads();
+    if (t < 6) {
+        int v = part[0][t];
+        for (int w = 1; w < 1024 / kWave; w++) v = t < 3 ? min(v, part[w][t]) : max(v, part[w][t]);
+        if (t < 3) T->solidLo[t] = v; else T->solidHi[t - 3] = v;
+    }
+    // ---- the scan.  The sums were made by atomics (the bricks' and this block's own): read them at the L2
     if (t == 0) mixedOf[R] = Lv.state[R][0] == 2 ? 1 : 0;
     for (int l = 2; l <= R; l++) {
         const long long c0 = Lv.cntOffset[l] / kMbChunk, c1 = Lv.cntOffset[l + 1] / kMbChunk;    // this level's chunks
         const int nb = (int)(c1 - c0);
         const int per = (nb + 1023) / 1024;
-        const int lo = min(t * per, nb), hi = min(lo + per, nb);
+        const int first = min(t * per, nb), last = min(first + per, nb);
         int s = 0;
-        for (int i = lo; i < hi; i++) s += chunkSum[c0 + i];
+        for (int i = first; i < last; i++) s += __hip_atomic_load(&chunkSum[c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int incl = s;
         for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
         if (lane == kWave - 1) waveTotal[wave] = incl;
         __syncthreads();
         int run = incl - s, all = 0;
         for (int w = 0; w < 1024 / kWave; w++) { const int v = waveTotal[w]; if (w < wave) run += v; all += v; }
-        for (int i = lo; i < hi; i++) { const int v = chunkSum[c0 + i]; chunkSum[c0 + i] = run; run += v; }
+        for (int i = first; i < last; i++) {
+            const int v = __hip_atomic_load(&chunkSum[c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            chunkSum[c0 + i] = run; run += v;
+        }
         if (t == 0) mixedOf[l - 1] = all;                        // cnt[l] counts the mixed cells of level l-1
         __syncthreads();
     }
@@ -2254,70 +2274,76 @@ __global__ __launch_bounds__(kBlock) void k_mb_group_ranks(MbLevels Lv, const in
     }
 }
 
-// A mixed cell (Morton index p of pyramid level l, rank `rank` among the mixed cells of its level) is an internal node: it
-// writes its descriptor and the records of its 8 children (leaf or internal).
-__device__ __forceinline__ void mb_emit_cell(const uint8_t* __restrict__ vox, const MbLevels& Lv, const MbTables* __restrict__ T, int l, long long p,
-                                             long long rank, rto_node* __restrict__ nodes, uint2* __restrict__ desc, int* __restrict__ descFirstChild) {
-    const int R = Lv.R, L = R - l;
-    const unsigned cx = mb_compact3((unsigned)p), cy = mb_compact3((unsigned)(p >> 1)), cz = mb_compact3((unsigned)(p >> 2));
-    int cs[8];
-    if (l >= 2) {
-        const uint2 ch = *reinterpret_cast<const uint2*>(Lv.state[l - 1] + 8 * p);
-#pragma unroll
-        for (int k = 0; k < 8; k++) cs[k] = (int)(((k < 4 ? ch.x : ch.y) >> ((k & 3) * 8)) & 0xffu);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) cs[k] = mb_voxel(vox, Lv.dimX, Lv.dimY, Lv.dimZ, (int)(2 * cx + (k & 1)), (int)(2 * cy + ((k >> 1) & 1)), (int)(2 * cz + (k >> 2)));
-    }
-    const long long childNode0 = T->levelBase[L + 1] + 8 * rank;          // node index of child 0
-    const long long grandBase = l >= 2 ? T->levelBase[L + 2] : 0;          // tree level of the grandchildren
-    const long long childRank0 = l >= 2 ? (long long)Lv.group[l][p] : 0;   // rank of the first child among the mixed cells of level l-1
-    unsigned imask = 0, smask = 0;
-    int before = 0;                                                       // mixed children before child k
-    const int half = 1 << (l - 1);
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        rto_node nd;
-        nd.x = (int)(2 * cx + (k & 1)) * half; nd.y = (int)(2 * cy + ((k >> 1) & 1)) * half; nd.z = (int)(2 * cz + (k >> 2)) * half;
-        nd.size = half;
-        const bool internal = cs[k] == 2;
-        nd.isLeaf = internal ? 0 : 1; nd.isUniform = nd.isLeaf;            // S/OctreeVoxel.cpp:716-745: leaf <=> uniform
-        nd.isSolid = (!internal && cs[k] == 1) ? 1 : 0;
-        const long long g0 = grandBase + 8 * (childRank0 + before);
-#pragma unroll
-        for (int j = 0; j < 8; j++) nd.child[j] = internal ? (int)(g0 + j) : -1;
-        nodes[childNode0 + k] = nd;
-        if (internal) { imask |= 1u << k; before++; }
-        else if (cs[k] == 1) smask |= 1u << k;
-    }
-    const long long d = T->internalBase[L] + rank;
-    desc[d] = make_uint2(smask | (imask << 8) | 0xff0000u, imask ? (unsigned)(T->internalBase[L + 1] + childRank0) : 0u);
-    descFirstChild[d] = (int)childNode0;
-}
-
-// One thread per internal node (descriptor index d; thread `internal` handles the root's own record): level from the
-// descriptor bases, cell from cellOf (the root is cell 0 of level R).
+// A mixed cell (Morton index p of pyramid level l) is an internal node, descriptor index d: it owns its descriptor and the
+// records of its 8 children, nodes 1 + 8 d .. 1 + 8 d + 7 (tree level L's nodes follow level L-1's, 8 per internal node of
+// the level above, in descriptor order: levelBase[L + 1] + 8 * rank = 1 + 8 d).  One thread per child; a block's 256 records
+// (15,360 bytes) are contiguous, so they are built in LDS -- at the same 16-byte phase as their place in the array -- and
+// leave as full 16-byte stores.  Block 0 also writes the root's own record.
+constexpr int kMbEmitCells = kBlock / 8;
+constexpr int kMbNodeWords = (int)(sizeof(rto_node) / 4);
 __global__ __launch_bounds__(kBlock) void k_mb_emit(const uint8_t* __restrict__ vox, MbLevels Lv, const MbTables* __restrict__ T,
                                                      const unsigned* __restrict__ cellOf, rto_node* __restrict__ nodes, uint2* __restrict__ desc,
                                                      int* __restrict__ descFirstChild) {
-    const long long d = (long long)blockIdx.x * kBlock + threadIdx.x;
-    const int R = Lv.R;
+    __shared__ __attribute__((aligned(16))) int stage[4 + kBlock * kMbNodeWords];
+    const int R = Lv.R, t = threadIdx.x, k = t & 7;
     const long long internal = T->internal;
-    if (d > internal) return;
-    if (d == internal) {                                           // the root's own record
+    const long long d0 = (long long)blockIdx.x * kMbEmitCells, d = d0 + (t >> 3);
+    if (blockIdx.x == 0 && t == 0) {                               // the root's own record
         const int state = Lv.state[R][0];
         rto_node nd;
         nd.x = nd.y = nd.z = 0; nd.size = 1 << R;
         nd.isLeaf = state == 2 ? 0 : 1; nd.isUniform = nd.isLeaf; nd.isSolid = state == 1 ? 1 : 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) nd.child[k] = state == 2 ? 1 + k : -1;
+        for (int j = 0; j < 8; j++) nd.child[j] = state == 2 ? 1 + j : -1;
         nodes[0] = nd;
-        return;
     }
-    int L = 0;
-    while (L < R && d >= T->internalBase[L + 1]) L++;
-    const long long p = L == 0 ? 0 : (long long)cellOf[d];
-    mb_emit_cell(vox, Lv, T, R - L, p, d - T->internalBase[L], nodes, desc, descFirstChild);
+    if (d < internal) {
+        int L = 0;
+        while (L < R && d >= T->internalBase[L + 1]) L++;
+        const int l = R - L;
+        const long long p = L == 0 ? 0 : (long long)cellOf[d];
+        const unsigned cx = mb_compact3((unsigned)p), cy = mb_compact3((unsigned)(p >> 1)), cz = mb_compact3((unsigned)(p >> 2));
+        const int half = 1 << (l - 1);
+        const int x = (int)(2 * cx + (k & 1)), y = (int)(2 * cy + ((k >> 1) & 1)), z = (int)(2 * cz + (k >> 2));     // in cells of level l-1
+        unsigned imask = 0, smask = 0;                             // children that are internal / solid leaves
+        if (l >= 2) {
+            const uint2 ch = *reinterpret_cast<const uint2*>(Lv.state[l - 1] + 8 * p);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const unsigned sj = ((j < 4 ? ch.x : ch.y) >> ((j & 3) * 8)) & 0xffu;
+                imask |= sj == 2u ? 1u << j : 0u; smask |= sj == 1u ? 1u << j : 0u;
+            }
+        } else {
+            const bool filled = mb_voxel(vox, Lv.dimX, Lv.dimY, Lv.dimZ, x, y, z) == 1;
+            smask = (unsigned)((__ballot(filled) >> (threadIdx.x & 56)) & 0xffull);      // the 8 lanes of this cell
+        }
+        const bool isInternal = (imask >> k) & 1u;
+        const long long childRank0 = l >= 2 ? (long long)Lv.group[l][p] : 0;   // rank of the first child among the mixed cells of level l-1
+        const int before = __builtin_popcount(imask & ((1u << k) - 1u));       // mixed children before child k
+        const int g0 = isInternal ? (int)(T->levelBase[L + 2] + 8 * (childRank0 + before)) : 0;
+        int* w = stage + 3 + t * kMbNodeWords;
+        w[0] = x * half; w[1] = y * half; w[2] = z * half; w[3] = half;
+        w[4] = isInternal ? 0 : 1;                                 // isLeaf
+        w[5] = (smask >> k) & 1u;                                  // isSolid
+        w[6] = w[4];                                               // isUniform (S/OctreeVoxel.cpp:716-745: leaf <=> uniform)
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[7 + j] = isInternal ? g0 + j : -1;
+        if (k == 0) {
+            desc[d] = make_uint2(smask | (imask << 8) | 0xff0000u, imask ? (unsigned)(T->internalBase[L + 1] + childRank0) : 0u);
+            descFirstChild[d] = (int)(1 + 8 * d);
+        }
+    }
+    __syncthreads();
+    const long long left = internal - d0;
+    const int words = (int)(left < kMbEmitCells ? (left > 0 ? left : 0) : kMbEmitCells) * 8 * kMbNodeWords;       // this block's records
+    // global word (1 + 8 d0) * 15 + i  <->  stage[3 + i]: (15 + 120 d0) % 4 == 3, so 16-byte groups coincide
+    int* g = reinterpret_cast<int*>(nodes) + (1 + 8 * d0) * kMbNodeWords - 3;
+    for (int c = t; 4 * c < 3 + words; c += kBlock) {
+        if (c > 0 && 4 * c + 4 <= 3 + words) *reinterpret_cast<int4*>(g + 4 * c) = *reinterpret_cast<const int4*>(stage + 4 * c);
+        else
+            for (int q = 0; q < 4; q++)
+                if (4 * c + q >= 3 && 4 * c + q < 3 + words) g[4 * c + q] = stage[4 * c + q];
+    }
 }
 
 // bounding box of the solid leaves (voxel units) for the launch-order heuristic.  Grid-stride over the nodes with a
