@@ -489,7 +489,7 @@ def main(argv=None):
     if rank == 0:
         kernel_name = KERNEL_NAMES[args.kernel] if info.canonical else "k_trace_generic"
         if triangles:
-            kernel_name = "k_trace_packed_triangles" if (info.canonical and args.kernel != "generic") else "k_trace_triangles"
+            kernel_name = ("k_trace_packed_triangles" if args.kernel == "packed_v3" else "k_trace_lean_triangles") if (info.canonical and args.kernel != "generic") else "k_trace_triangles"
             _, tstats = ctx.render_triangles_host(frame, shadow=True, stats=True)     # primary + shadow pops (instrumented kernel)
             stats = {"rays": rays, "pops": tstats["pops"], "hits": tstats["hits"], "capped": None}
         else:

@@ -83,6 +83,7 @@ struct rto_context {
     // leaf triangles (config 5 extension)
     float* d_tris = nullptr;
     int* d_triOffset = nullptr;
+    uint2* d_triRec = nullptr;       // k_trace_lean_triangles: one record per interesting child (k_unified_fill)
     int64_t numTris = 0;
 
     // separable ray terms (per column / per row), cached by (W, H, aspect, tanHalfFov)
@@ -142,6 +143,7 @@ static void free_octree(rto_context* c) {
     (void)hipFree(c->d_compact); c->d_compact = nullptr;
     (void)hipFree(c->d_tris); c->d_tris = nullptr;
     (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
+    (void)hipFree(c->d_triRec); c->d_triRec = nullptr;
     (void)hipFree(c->d_vox); c->d_vox = nullptr;
     c->voxDim[0] = c->voxDim[1] = c->voxDim[2] = 0;
     c->numTris = 0;
@@ -1164,6 +1166,32 @@ static int ensure_steps(rto_context* c, size_t pixels) {
     return RTO_OK;
 }
 
+// Records of the lean triangle kernel (k_unified_*): after k_desc_trimask, on stream s.  Leaves c->d_triRec.
+static int build_triangle_records(rto_context* c, hipStream_t s) {
+    (void)hipFree(c->d_triRec); c->d_triRec = nullptr;
+    if (!(c->canonical && c->numInternal > 0)) return RTO_OK;
+    const int64_t n = c->numInternal;
+    const int nb = (int)((n + kBlock - 1) / kBlock);
+    BuildScratch scratch(s);
+    int *d_count = nullptr, *d_first = nullptr, *d_bs = nullptr, *d_bb = nullptr;
+    int64_t* d_total = nullptr;
+    RTO_HIP(c, scratch.alloc(&d_count, (size_t)n)); RTO_HIP(c, scratch.alloc(&d_first, (size_t)n + 1));
+    RTO_HIP(c, scratch.alloc(&d_bs, (size_t)nb)); RTO_HIP(c, scratch.alloc(&d_bb, (size_t)nb)); RTO_HIP(c, scratch.alloc(&d_total, 1));
+    hipLaunchKernelGGL(k_unified_count, dim3(nb), dim3(kBlock), 0, s, c->d_desc, n, d_count);
+    hipLaunchKernelGGL(k_block_sums, dim3(nb), dim3(kBlock), 0, s, d_count, n, d_bs);
+    hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, s, d_bs, nb, d_bb, d_total);
+    hipLaunchKernelGGL(k_block_exclusive_scan, dim3(nb), dim3(kBlock), 0, s, d_count, n, d_bb, d_total, d_first);
+    RTO_HIP(c, hipGetLastError());
+    int64_t total = 0;
+    RTO_HIP(c, hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, s));
+    RTO_HIP(c, hipStreamSynchronize(s));
+    if (total + 1 > 0x7fffffff) return fail(c, RTO_E_UNSUPPORTED, "leaf triangles: record indices are int32");
+    RTO_HIP(c, hipMalloc(&c->d_triRec, (size_t)(total + 1) * sizeof(uint2)));
+    hipLaunchKernelGGL(k_unified_fill, dim3(nb), dim3(kBlock), 0, s, c->d_desc, c->d_descFirstChild, c->d_triOffset, d_first, n, c->d_triRec);
+    RTO_HIP(c, hipGetLastError());
+    return RTO_OK;
+}
+
 extern "C" {
 
 int rto_render_device(rto_context* c, const rto_frame* f, const rto_partition* p, void* d_out, void* hip_stream) {
@@ -1331,6 +1359,7 @@ int rto_upload_leaf_triangles(rto_context* c, const float* tris, int64_t num_tri
     RTO_HIP(c, hipDeviceSynchronize());          // frames in flight on any stream still read the old buffers / descriptors
     (void)hipFree(c->d_tris); c->d_tris = nullptr;
     (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
+    (void)hipFree(c->d_triRec); c->d_triRec = nullptr;
     RTO_HIP(c, hipMalloc(&c->d_tris, (size_t)(num_tris ? num_tris : 1) * 12 * sizeof(float)));
     RTO_HIP(c, hipMalloc(&c->d_triOffset, (size_t)(c->numNodes + 1) * sizeof(int)));
     if (num_tris) RTO_HIP(c, hipMemcpy(c->d_tris, tris, (size_t)num_tris * 12 * sizeof(float), hipMemcpyHostToDevice));
@@ -1340,6 +1369,8 @@ int rto_upload_leaf_triangles(rto_context* c, const float* tris, int64_t num_tri
         hipLaunchKernelGGL(k_desc_trimask, dim3((unsigned)((c->numInternal + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
                            c->d_descFirstChild, c->d_triOffset, c->numInternal, c->d_desc);
         RTO_HIP(c, hipGetLastError());
+        const int rcRec = build_triangle_records(c, c->stream);
+        if (rcRec != RTO_OK) return rcRec;
         RTO_HIP(c, hipStreamSynchronize(c->stream));
     }
     return RTO_OK;
@@ -1399,6 +1430,7 @@ int rto_build_leaf_triangles(rto_context* c, const uint8_t* voxels, int dimX, in
     }
     (void)hipFree(c->d_tris); c->d_tris = nullptr;
     (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
+    (void)hipFree(c->d_triRec); c->d_triRec = nullptr;
     c->numTris = 0;
 
     const int64_t n = c->numNodes;
@@ -1448,6 +1480,8 @@ int rto_build_leaf_triangles(rto_context* c, const uint8_t* voxels, int dimX, in
         hipLaunchKernelGGL(k_desc_trimask, dim3((unsigned)((c->numInternal + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
                            c->d_descFirstChild, c->d_triOffset, c->numInternal, c->d_desc);
         RTO_HIP(c, hipGetLastError());
+        const int rcRec = build_triangle_records(c, s);
+        if (rcRec != RTO_OK) return rcRec;
     }
     RTO_HIP(c, hipEventRecord(e2, s));
     RTO_HIP(c, hipStreamSynchronize(s));
@@ -1493,12 +1527,22 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
     const bool noEvents = capturing || c->eventsOff;
     if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev0, s));
     if (packed) {
-        PackedTriScene S{ c->d_desc, c->d_descFirstChild, c->d_tris, c->d_triOffset };
-        const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint4);
         const int lblocks = (P.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
-        if (shadeOut) hipLaunchKernelGGL((k_trace_packed_triangles<kModeColor, true>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
-        else if (count) hipLaunchKernelGGL((k_trace_packed_triangles<kModeSteps, false>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
-        else hipLaunchKernelGGL((k_trace_packed_triangles<kModeColor, false>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+        if (c->d_triRec && c->kernelMode != RTO_KERNEL_PACKED_V3) {
+            // default: the lean loop on the unified records (8-byte stack entries, shadow rays start inside the loop)
+            LeanTriScene S{ c->d_triRec, c->d_tris };
+            const size_t lds = (size_t)(kBlock / kWave) * ((P.depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));   // stacks + the keys of the triangle rounds
+            if (shadeOut) hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, true>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+            else if (count) hipLaunchKernelGGL((k_trace_lean_triangles<kModeSteps, false>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+            else hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, false>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+        } else {
+            // RTO_KERNEL_PACKED_V3: round 1's form on the descriptors + triOffset (kept in the test matrix)
+            PackedTriScene S{ c->d_desc, c->d_descFirstChild, c->d_tris, c->d_triOffset };
+            const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint4);
+            if (shadeOut) hipLaunchKernelGGL((k_trace_packed_triangles<kModeColor, true>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+            else if (count) hipLaunchKernelGGL((k_trace_packed_triangles<kModeSteps, false>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+            else hipLaunchKernelGGL((k_trace_packed_triangles<kModeColor, false>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+        }
     } else {
         TriScene S{ c->d_nodes, c->d_tris, c->d_triOffset };
         if (shadeOut) hipLaunchKernelGGL((k_trace_triangles<kModeColor, true>), dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);

@@ -1584,6 +1584,287 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed_triangles(RenderParams 
     }
 }
 
+// ---------------------------------------------------------------- N2 in the lean form (default for canonical trees)
+// k_trace_packed_triangles with the loop of k_trace_lean.  What makes that possible is ONE index space for everything a
+// ray can pop and act on: the "interesting" children of a node -- its internal children and its triangle-owning leaves --
+// get consecutive records in `rec` (k_unified_*), so `first record + popcount(interesting children below j)` addresses
+// child j whether it is a node (record = its descriptor: masks | first record of ITS interesting children) or a leaf
+// (record = first triangle, triangle count).  A stack entry is then the same 8 bytes as in k_trace_lean (the packed form
+// needs 16: it carries the node index of the first child to reach triOffset), which doubles the waves an LDS-limited CU
+// holds, and the pop counters follow from identities (1) and (2) of trace_tile_lean instead of being carried.
+//   * a lane that pops a triangle leaf waits; when no lane walks any more the waiting lanes test their triangles
+//     together; a miss pops the next pending candidate there and then (no visit: the entry is on the stack);
+//   * a lane whose primary ray has found its triangle starts its shadow ray AT ONCE, inside the same loop, instead of
+//     idling until the whole wave has finished its primary rays.
+struct LeanTriScene {
+    const uint2* rec;           // [0] the root's descriptor; see above
+    const float* tris;          // 12 floats per triangle: v0, v1, v2, face normal
+};
+
+// interesting children per descriptor (after k_desc_trimask)
+__global__ __launch_bounds__(kBlock) void k_unified_count(const uint2* __restrict__ desc, int64_t nInternal, int* __restrict__ count) {
+    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (d >= nInternal) return;
+    const unsigned x = desc[d].x;
+    count[d] = __builtin_popcount(((x >> 8) | (x >> 24)) & 0xffu);
+}
+
+// first[d] = exclusive scan of count: the records of d's interesting children start at 1 + first[d] (record 0 is the root)
+__global__ __launch_bounds__(kBlock) void k_unified_fill(const uint2* __restrict__ desc, const int* __restrict__ descFirstChild,
+                                                          const int* __restrict__ triOffset, const int* __restrict__ first, int64_t nInternal,
+                                                          uint2* __restrict__ rec) {
+    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (d >= nInternal) return;
+    const uint2 dd = desc[d];
+    const unsigned im = (dd.x >> 8) & 0xffu, tm = dd.x >> 24, it = im | tm;
+    const int c0 = descFirstChild[d];
+    const unsigned r0 = 1u + (unsigned)first[d];
+    if (d == 0) rec[0] = make_uint2(dd.x, r0);
+    for (int k = 0; k < 8; k++) {
+        if (!((it >> k) & 1u)) continue;
+        const unsigned idx = r0 + (unsigned)__builtin_popcount(it & ((1u << k) - 1u));
+        if ((im >> k) & 1u) {
+            const unsigned cd = dd.y + (unsigned)__builtin_popcount(im & ((1u << k) - 1u));
+            rec[idx] = make_uint2(desc[cd].x, 1u + (unsigned)first[cd]);
+        } else {
+            const int t0 = triOffset[c0 + k];
+            rec[idx] = make_uint2((unsigned)t0, (unsigned)(triOffset[c0 + k + 1] - t0));
+        }
+    }
+}
+
+#ifndef RTO_TRI_WAVES
+#define RTO_TRI_WAVES 5
+#endif
+template <int MODE, bool SHADE>
+__global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles(RenderParams P, LeanTriScene Sc, int shadow, float4* __restrict__ out,
+                                                                                 Counters* __restrict__ counters) {
+    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64], b in [0, depth]
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds_stack + (size_t)(kBlock / kWave) * (P.depth + 1) * kWave) + wave * kWave;
+    const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    if (slot >= P.launchWaves) return;
+    int tile, tx, ty;
+    resolve_slot(P, slot, tx, ty, tile);
+    const int px = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    const bool inImage = valid && (py < P.H);
+    // outside this rectangle no ray can meet the geometry (instrumented frames: the root box, whose miss costs exactly the
+    // root's pop; colour / shade frames: the solid leaves' box widened by a voxel, which holds every triangle)
+    const bool outside = px < P.rootX0 || px > P.rootX1 || py < P.rootY0 || py > P.rootY1;
+    const Geo G = geo_of(P);
+    float lnx = P.lightNeg[0], lny = P.lightNeg[1], lnz = P.lightNeg[2];
+    asm volatile("" : "+s"(lnx), "+s"(lny), "+s"(lnz));                    // see geo_of
+
+    float shade = kShadeMiss;
+    int stepsTotal = 0;            // pops of the finished rays of this pixel (primary, then shadow)
+    bool hitPrimary = false;
+    Ray r;
+    bool alive = false;            // walking the tree
+    if (inImage) {
+        stepsTotal = 1;            // the root's own pop of the primary ray
+        if (!outside) {
+            r = generate_ray_tab(P, px, py);
+            float tNear, tFar, a0, a1, a2, a3, a4, a5;
+            alive = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+        }
+    }
+    const bool risky = alive && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
+                                  __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
+    const bool anyRisky = __builtin_amdgcn_ballot_w64(risky) != 0ull;   // wave-uniform; shadow rays are never risky themselves
+                                                                         // (finite light direction), the exact form serves them too
+    unsigned cur = 0;
+    int cx = 0, cy = 0, cz = 0;
+    int bpos = P.depth - 1;
+    unsigned lvlPending = 0;
+    const unsigned sentinel = 1u << P.depth;
+    int S = 0;                                                          // identity (1), for the ray in flight
+    const int capBound = kMaxTraversalSteps + 7 * P.depth;
+    unsigned sgnX = (unsigned)((int)__float_as_uint(r.ix) >> 31), sgnY = (unsigned)((int)__float_as_uint(r.iy) >> 31),
+             sgnZ = (unsigned)((int)__float_as_uint(r.iz) >> 31);
+    bool haveLeaf = false;         // a popped triangle leaf (record `cur`) waits for its test
+    bool ended = false;            // the ray in flight ran out of nodes (or into the cap) in the node loop
+    bool shadowRay = false;        // the ray in flight is the pixel's shadow ray
+    float ndotl = 0.0f;
+    const char* recBytes = reinterpret_cast<const char*>(Sc.rec);
+    int trips = 0, rounds = 0;
+
+    for (;;) {
+#if defined(RTO_TRI_BATCH)
+        // A/B build: a triangle round as soon as RTO_TRI_BATCH lanes wait with a leaf (their tests cost by the pair now)
+        while (__builtin_amdgcn_ballot_w64(alive) != 0ull && __builtin_popcountll(__builtin_amdgcn_ballot_w64(haveLeaf)) < RTO_TRI_BATCH)
+        if (alive) {
+#else
+        while (alive) {
+#endif
+            trips++;
+            const uint2 d = *reinterpret_cast<const uint2*>(recBytes + (cur << 3));
+            const int Lb = __builtin_ctz(lvlPending | sentinel);
+            const uint2 e = stk[Lb * kWave];
+            const float fh = __uint_as_float((unsigned)(bpos + 127) << 23);        // (float)(1 << bpos), exact (bpos = -1 after a finest leaf: unused)
+            unsigned fail8;
+            if (anyRisky) fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz,
+                                                        r.ix, r.iy, r.iz, cx, cy, cz, 1 << (bpos & 31));
+            else fail8 = child_fail_mask_fast(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                              sgnX, sgnY, sgnZ, cx, cy, cz, fh);
+            const unsigned vm0 = (d.x >> 16) & 0xffu;
+            S += __builtin_popcount(vm0);
+            // children that do more than count a pop: visible internal ones and visible triangle leaves that pass the slab test
+            const unsigned cand = bop3<kAndAndNot>((d.x >> 8) | (d.x >> 24), vm0, fail8);
+            const unsigned noWork = (unsigned)(((int)cand - 1) >> 31);
+            const bool dead = (cand | lvlPending) == 0 || S >= capBound;
+            const unsigned W = bop3<kSelC>(bop3<kAndOr>(d.x, 0xffffff00u, cand), e.x, noWork);
+            const unsigned base = bop3<kSelC>(d.y, e.y, noWork);
+            const int bpos2 = (int)bop3<kSelC>((unsigned)bpos, (unsigned)Lb, noWork);
+            const int j = 31 - __builtin_clz(W & 0xffu);
+            const unsigned bitj = 1u << j;
+            const bool leaf = ((W >> 8) & bitj) == 0;
+            const unsigned Wn = W ^ bitj;
+            stk[bpos2 * kWave] = make_uint2(Wn, base);
+            const unsigned hl = 1u << bpos2;
+            const unsigned noneLeft = (unsigned)(((int)(Wn & 0xffu) - 1) >> 31);
+            lvlPending = bop3<kReplace>(lvlPending, hl, noneLeft);
+            cur = base + (unsigned)__builtin_popcount(((W >> 8) | (W >> 24)) & (bitj - 1u));    // record of the popped child
+            const unsigned keep = 0u - (hl + hl);
+            const unsigned sj = (unsigned)j << bpos2;
+            cx = (int)bop3<kOrAnd>((unsigned)cx & keep, sj, hl);
+            cy = (int)bop3<kOrAnd>((unsigned)cy & keep, sj >> 1, hl);
+            cz = (int)bop3<kOrAnd>((unsigned)cz & keep, sj >> 2, hl);
+            bpos = bpos2 - 1;
+            haveLeaf = !dead && leaf;
+            ended = dead;
+            alive = !dead && !leaf;
+        }
+        rounds++;
+        // ---- the waiting lanes' triangles, tested by ALL 64 lanes (S/RT semantics of the pop: it happens only below the
+        //      cap).  Leaves own 1 to several dozen triangles (big uniform leaves), so "each lane loops over its own leaf"
+        //      runs at 21 % lane utilisation behind the longest leaf.  Instead the (leaf, triangle) pairs of the whole wave
+        //      are numbered by a prefix sum and dealt out 64 at a time: pair w belongs to the first lane whose inclusive
+        //      prefix exceeds w (binary search with ds_bpermute), the worker fetches that lane's ray by ds_bpermute, and a
+        //      hit is folded into the owner's 64-bit key (t bits, triangle index) with ds_min_u64 -- the same winner as the
+        //      sequential loop: smallest t, then smallest index.
+        bool endedHit = false;
+        int Rrest = 0;             // identity (2) at the leaf that was hit, when it was needed
+        bool haveR = false;
+        float bestT = 1e30f;
+        int best = -1;
+        if (__builtin_amdgcn_ballot_w64(haveLeaf) != 0ull) {
+            if (haveLeaf && (1 + S > kMaxTraversalSteps || MODE == kModeSteps)) {
+                for (int b = P.depth - 1; b > bpos; b--) {
+                    const unsigned w = stk[b * kWave].x;
+                    const unsigned jl = ((cx >> b) & 1) | (((cy >> b) & 1) << 1) | (((cz >> b) & 1) << 2);
+                    Rrest += __builtin_popcount(__builtin_amdgcn_ubfe(w, 16, 8) & ((1u << jl) - 1u));
+                }
+                haveR = true;
+                if (1 + S - Rrest > kMaxTraversalSteps) { ended = true; S = capBound; haveLeaf = false; }   // S/RT:254: the loop ended before this pop
+            }
+            uint2 tr = make_uint2(0u, 0u);                          // first triangle, triangles of this lane's leaf
+            if (haveLeaf) tr = *reinterpret_cast<const uint2*>(recBytes + (cur << 3));
+            const int cnt = (int)tr.y;
+            int incl = cnt;
+            for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
+            keys[lane] = ~0ull;
+            __builtin_amdgcn_wave_barrier();
+            for (int w0 = 0; w0 < total; w0 += kWave) {
+                const int w = w0 + lane;
+                int owner = 0;                                      // lanes whose inclusive prefix is <= w
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int v = __shfl(incl, owner + step - 1);
+                    if (v <= w) owner += step;
+                }
+                const int inclO = __shfl(incl, owner), cntO = __shfl(cnt, owner);
+                const int k = (int)__shfl((int)tr.x, owner) + (w - (inclO - cntO));
+                const float oox = __shfl(r.ox, owner), ooy = __shfl(r.oy, owner), ooz = __shfl(r.oz, owner);
+                const float odx = __shfl(r.dx, owner), ody = __shfl(r.dy, owner), odz = __shfl(r.dz, owner);
+                if (w < total) {
+                    float t;
+                    if (ray_triangle(oox, ooy, ooz, odx, ody, odz, Sc.tris + (size_t)k * 12, t) && t < 1e30f)
+                        atomicMin(&keys[owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)k);   // t > 0: its bits order like the value
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (haveLeaf) {
+                const unsigned long long key = keys[lane];
+                if (key != ~0ull) { best = (int)(unsigned)key; bestT = __uint_as_float((unsigned)(key >> 32)); }
+                if (best >= 0) { ended = true; endedHit = true; haveLeaf = false; }
+                else if (lvlPending == 0) { ended = true; haveLeaf = false; }              // nothing left: the ray misses
+                else {
+                    // pop the next pending candidate right here -- no visit, the entry is on the stack; if that is another
+                    // triangle leaf the lane waits for the next round (batched tests beat chained ones)
+                    const int Lb = __builtin_ctz(lvlPending);
+                    const uint2 e = stk[Lb * kWave];
+                    const int j = 31 - __builtin_clz(e.x & 0xffu);
+                    const unsigned bitj = 1u << j;
+                    const unsigned Wn = e.x ^ bitj;
+                    stk[Lb * kWave] = make_uint2(Wn, e.y);
+                    const unsigned hl = 1u << Lb;
+                    if ((Wn & 0xffu) == 0) lvlPending &= ~hl;
+                    cur = e.y + (unsigned)__builtin_popcount(((e.x >> 8) | (e.x >> 24)) & (bitj - 1u));
+                    const unsigned keep = 0u - (hl + hl);
+                    cx = (int)(((unsigned)cx & keep) | ((j & 1) ? hl : 0u));
+                    cy = (int)(((unsigned)cy & keep) | ((j & 2) ? hl : 0u));
+                    cz = (int)(((unsigned)cz & keep) | ((j & 4) ? hl : 0u));
+                    bpos = Lb - 1;
+                    if ((e.x >> 8) & bitj) { haveLeaf = false; alive = true; }             // an internal child: back to the node loop
+                }
+            }
+        }
+        // ---- a ray has ended: account for it; a primary hit starts the shadow ray
+        if (ended) {
+            ended = false;
+            int steps = 1 + S;
+            if (endedHit && haveR) steps -= Rrest;
+            if (steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
+            stepsTotal += steps - (shadowRay ? 0 : 1);                 // the primary ray's root pop is already in
+            if (!shadowRay) {
+                if (endedHit) {
+                    hitPrimary = true;
+                    float nx = Sc.tris[(size_t)best * 12 + 9], ny = Sc.tris[(size_t)best * 12 + 10], nz = Sc.tris[(size_t)best * 12 + 11];
+                    if (nx * r.dx + ny * r.dy + nz * r.dz > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+                    ndotl = gmax(0.0f, nx * lnx + ny * lny + nz * lnz);
+                    shade = ndotl;
+                    if (shadow) {
+                        const float bias = G.vs * 1e-3f;
+                        const float hx = r.ox + r.dx * bestT, hy = r.oy + r.dy * bestT, hz = r.oz + r.dz * bestT;
+                        r.ox = hx + nx * bias; r.oy = hy + ny * bias; r.oz = hz + nz * bias;
+                        r.dx = lnx; r.dy = lny; r.dz = lnz;
+                        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+                        sgnX = (unsigned)((int)__float_as_uint(r.ix) >> 31); sgnY = (unsigned)((int)__float_as_uint(r.iy) >> 31);
+                        sgnZ = (unsigned)((int)__float_as_uint(r.iz) >> 31);
+                        shadowRay = true;
+                        float tNear, tFar, a0, a1, a2, a3, a4, a5;
+                        alive = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+                        if (!alive) stepsTotal += 1;                  // the shadow ray pops the root and misses it
+                        cur = 0; cx = cy = cz = 0; bpos = P.depth - 1; lvlPending = 0; S = 0;
+                    }
+                }
+            } else if (endedHit) shade = 0.0f;                         // something between the hit and the light
+        }
+        if (__builtin_amdgcn_ballot_w64(alive || haveLeaf) == 0ull) break;
+    }
+    if (P.tileCost) {
+        int cost = trips + 4 * rounds;                                    // of the lane that walked longest
+        for (int off = 32; off > 0; off >>= 1) cost = max(cost, __shfl_xor(cost, off));
+        if (lane == 0 && ty < P.tilesY) P.tileCost[tile] = cost >> 2;
+    }
+    if (valid && !(P.skipOutside && outside)) {
+        if (SHADE) __builtin_nontemporal_store(shade, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);
+        else store_pixel(out + (size_t)ly * P.W + px, shade_color(shade));
+    }
+    if (MODE == kModeColor) fill_outside<SHADE ? kModeShade : kModeColor>(P, out, lane, slot);
+    if (MODE == kModeSteps) {
+        unsigned long long pops = inImage ? (unsigned long long)stepsTotal : 0ull, hits = (inImage && hitPrimary) ? 1ull : 0ull;
+        for (int off = 32; off > 0; off >>= 1) { pops += __shfl_down(pops, off); hits += __shfl_down(hits, off); }
+        if (lane == 0) { atomicAdd(&counters->pops, pops); atomicAdd(&counters->hits, hits); }
+    }
+}
+
 // ================================================================ N1: octreeRaySkip
 // Iterative form of the reference's recursive octreeRaySkip (453-skeleton/VolumeRaycastRenderer.cpp:50-155, "S/VR"):
 // children are tried in order of increasing Hamming distance from the octant of the ray's positive
