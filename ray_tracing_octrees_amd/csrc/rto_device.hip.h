@@ -1592,8 +1592,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed_triangles(RenderParams 
 // (record = first triangle, triangle count).  A stack entry is then the same 8 bytes as in k_trace_lean (the packed form
 // needs 16: it carries the node index of the first child to reach triOffset), which doubles the waves an LDS-limited CU
 // holds, and the pop counters follow from identities (1) and (2) of trace_tile_lean instead of being carried.
-//   * a lane that pops a triangle leaf waits; when no lane walks any more the waiting lanes test their triangles
-//     together; a miss pops the next pending candidate there and then (no visit: the entry is on the stack);
+//   * a lane that pops a triangle leaf waits; when 16 lanes wait (or nobody walks any more) the triangles of the waiting
+//     lanes are dealt out to all 64 lanes, pair by pair; a miss pops the next pending candidate there and then (no visit:
+//     the entry is on the stack);
 //   * a lane whose primary ray has found its triangle starts its shadow ray AT ONCE, inside the same loop, instead of
 //     idling until the whole wave has finished its primary rays.
 struct LeanTriScene {
@@ -1635,6 +1636,9 @@ __global__ __launch_bounds__(kBlock) void k_unified_fill(const uint2* __restrict
 
 #ifndef RTO_TRI_WAVES
 #define RTO_TRI_WAVES 5
+#endif
+#ifndef RTO_TRI_BATCH
+#define RTO_TRI_BATCH 16
 #endif
 template <int MODE, bool SHADE>
 __global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles(RenderParams P, LeanTriScene Sc, int shadow, float4* __restrict__ out,
@@ -1694,13 +1698,11 @@ __global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles(
     int trips = 0, rounds = 0;
 
     for (;;) {
-#if defined(RTO_TRI_BATCH)
-        // A/B build: a triangle round as soon as RTO_TRI_BATCH lanes wait with a leaf (their tests cost by the pair now)
+        // node loop: until nobody walks, or RTO_TRI_BATCH lanes wait with a leaf (the tests cost by the pair, so a round
+        // for 16 leaves -- ~70 pairs -- fills the wave; measured at config 5: 2 / 4 / 8 / 12 / 16 / 20 / 32 / 48 / 64 lanes ->
+        // 632 / 599 / 554 / 535 / 533 / 534 / 560 / 614 / 641 us)
         while (__builtin_amdgcn_ballot_w64(alive) != 0ull && __builtin_popcountll(__builtin_amdgcn_ballot_w64(haveLeaf)) < RTO_TRI_BATCH)
         if (alive) {
-#else
-        while (alive) {
-#endif
             trips++;
             const uint2 d = *reinterpret_cast<const uint2*>(recBytes + (cur << 3));
             const int Lb = __builtin_ctz(lvlPending | sentinel);
