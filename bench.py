@@ -99,6 +99,13 @@ def parse_args(argv=None):
     ap.add_argument("--orbit-frames", type=int, default=None,
                     help="N=1, octree configs: extra figure with the camera orbiting 0.01 rad per frame, plain launches, launch-order "
                          "table rebuilt every --order-period-th frame (default 240; 0 = skip)")
+    ap.add_argument("--frames-per-launch", type=int, default=None,
+                    help="N=1, octree configs: frames rendered by ONE kernel launch (rto_render_batch_device, at most 8; default 4). A single "
+                         "frame's kernel lasts as long as its deepest tile's chain of node visits with most of the GPU idle; frames "
+                         "launched together fill it.  1 = one launch per frame (also reported in the line as `one_frame_per_launch`)")
+    ap.add_argument("--rehearse-world", type=int, default=0,
+                    help="with --gpus 1 --force-comm: render / ship / assemble as rank 0 of that many GPUs (rto_comm_debug_rehearse); "
+                         "the line then reports the per-rank cost of the split, NOT a frame rate (only 1/N of every frame is rendered)")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1: drive the frames through rto_comm_* with a one-rank RCCL communicator (rehearses the N>1 code path on one GPU)")
     ap.add_argument("--launcher-dry-run", action="store_true", help="--gpus N without WORLD_SIZE: print the child command line and exit")
@@ -256,6 +263,8 @@ def pmc_entry(config: str, kernel_name: str, order: str):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.rehearse_world > 1:
+        args.no_verify, args.cpu_frames, args.force_comm = True, 0, True     # the assembled frames hold one rank's bands only
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         sys.exit(self_launch(args, argv))
@@ -315,6 +324,10 @@ def main(argv=None):
         if dist is not None:
             dist.broadcast_object_list(ids, src=0)
         comm = _hip.Comm(ctx, world, rank, ids[0], band_rows=args.band_rows)
+        if args.rehearse_world > 1:
+            if world != 1:
+                raise SystemExit("--rehearse-world needs --gpus 1 --force-comm")
+            comm.debug_rehearse(args.rehearse_world, 0)       # this GPU plays rank 0 of that many: per-rank cost of the split, no peer traffic
         comm_mode = _hip.RESIDENT_TRIANGLES_SHADOW if triangles else _hip.RESIDENT_OCTREE
 
     def backend():
@@ -410,19 +423,50 @@ def main(argv=None):
             render_to(bufs[i].data_ptr(), streams[i].cuda_stream)
         sync_all()
     use_graph = world == 1 and fif == 1 and args.graph_frames > 0 and not use_comm
+    # frames per kernel launch (rto_render_batch_device): octree frames of the single-GPU path only
+    fpl = 1
+    if world == 1 and fif == 1 and not use_comm and not triangles:
+        fpl = max(1, min(8, args.steps, 4 if args.frames_per_launch is None else args.frames_per_launch))
+    batch_buf = torch.empty((fpl, H, W, 4), dtype=torch.float32, device="cuda") if fpl > 1 else None
+    batch_arrs = {}
+
+    def render_chunk(nf, out=None):
+        """nf <= fpl consecutive frames in one launch, into batch_buf[0..nf-1]"""
+        if nf not in batch_arrs:
+            batch_arrs[nf] = rto.Context.frame_array([frame] * nf)
+        ctx.render_batch_device(batch_arrs[nf], (out if out is not None else batch_buf).data_ptr(), H * W * 16, None, False, stream.cuda_stream)
+
+    def render_frames_plain(nframes):
+        if fpl == 1:
+            return run_frames(nframes)
+        full, rest = divmod(nframes, fpl)
+        for _ in range(full):
+            render_chunk(fpl)
+        if rest:
+            render_chunk(rest)
+        return batch_buf[(rest or fpl) - 1]
+
+    if fpl > 1:
+        for _ in range(3):
+            render_chunk(fpl)
+        sync_all()
     graph = None
     gframes = 0
     if use_graph:
         # after the warm-up frames the render entry points allocate nothing and never synchronise: they can be stream-captured
-        gframes = min(args.graph_frames, args.steps)
+        gframes = min(args.graph_frames, args.steps) // fpl * fpl
         buf0 = renderer.render(frame)
         ctx.timing_begin(0)
         sync_all()
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
-                for _ in range(gframes):
-                    render_to(buf0.data_ptr(), stream.cuda_stream)
+                if fpl > 1:
+                    for _ in range(gframes // fpl):
+                        render_chunk(fpl)
+                else:
+                    for _ in range(gframes):
+                        render_to(buf0.data_ptr(), stream.cuda_stream)
             graph.replay()                              # untimed: first replay of a fresh graph
             sync_all()
             ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -437,17 +481,20 @@ def main(argv=None):
                 renderer.render(frame)
             sync_all()
     if not use_graph:
-        ctx.timing_begin(args.steps if not (triangles or use_comm) else 0)  # HIP event pair around every traversal kernel, on its launch stream, no syncs
+        ctx.timing_begin(-(-args.steps // fpl) if not (triangles or use_comm) else 0)  # HIP event pair around every traversal kernel, on its launch stream, no syncs
     sync_all()
     t0 = time.perf_counter()
     if use_graph:
         ev_a.record(stream)
         for _ in range(args.steps // gframes):
             graph.replay()
-        for _ in range(args.steps % gframes):           # exactly K frames: the remainder as plain launches
-            render_to(buf0.data_ptr(), stream.cuda_stream)
+        if fpl > 1:                                     # exactly K frames: the remainder as plain launches
+            img = render_frames_plain(args.steps % gframes) if args.steps % gframes else batch_buf[fpl - 1]
+        else:
+            for _ in range(args.steps % gframes):
+                render_to(buf0.data_ptr(), stream.cuda_stream)
+            img = buf0
         ev_b.record(stream)
-        img = buf0
     elif fif > 1:
         for k in range(args.steps):
             s_ = streams[k % fif]
@@ -457,7 +504,7 @@ def main(argv=None):
         if world == 1 and triangles and not use_comm:
             ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev_a.record(stream)
-        img = run_frames(args.steps)
+        img = render_frames_plain(args.steps)
         if world == 1 and triangles and not use_comm:
             ev_b.record(stream)
     sync_all()
@@ -488,6 +535,8 @@ def main(argv=None):
                    "what": "rto_comm_submit of ONE frame + rto_comm_flush per frame: render part -> grouped send/recv -> assemble, host waits for each frame"}
     if rank == 0:
         kernel_name = KERNEL_NAMES[args.kernel] if info.canonical else "k_trace_generic"
+        if fpl > 1 and kernel_name == "k_trace_lean":
+            kernel_name = "k_trace_lean_batch"
         if triangles:
             kernel_name = ("k_trace_packed_triangles" if args.kernel == "packed_v3" else "k_trace_lean_triangles") if (info.canonical and args.kernel != "generic") else "k_trace_triangles"
             _, tstats = ctx.render_triangles_host(frame, shadow=True, stats=True)     # primary + shadow pops (instrumented kernel)
@@ -510,9 +559,10 @@ def main(argv=None):
                 k_avg = ev_a.elapsed_time(ev_b) / args.steps
                 kms = [k_avg]
             else:
-                kms = sorted(float(x) for x in ctx.timing_read())
-                assert len(kms) == args.steps
-                k_avg = sum(kms) / len(kms)
+                kms = [float(x) for x in ctx.timing_read()]
+                assert len(kms) == -(-args.steps // fpl)
+                k_avg = sum(kms) / args.steps                       # per frame
+                kms = sorted(x / fpl for x in kms[: args.steps // fpl]) or sorted(kms)
             cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
             for a, b in cal:
                 a.record(stream); b.record(stream)
@@ -521,6 +571,8 @@ def main(argv=None):
             hbm_alg = rays * bytes_per_ray / (k_avg * 1e-3) / 1e9
             order_key = "centre-out" if args.order != "temporal" else "temporal"
             pmc = pmc_entry(args.config, kernel_name, order_key)
+            if pmc is not None and int(pmc.get("frames_per_launch", 1)) != fpl:
+                pmc = None                                           # counted for another batch size
             roofline = {
                 "bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s", "frac": None,
                 "traffic": None, "traffic_source": None,
@@ -530,7 +582,8 @@ def main(argv=None):
                 "launch_order": ("centre-out" if order_key == "centre-out" else
                                  "temporal (tiles sorted by an earlier frame's trip counts; table built during the warm-up, frozen while the frames are replayed from the graph)" if use_graph else
                                  f"temporal (tiles sorted by an earlier frame's trip counts; k_sort_scatter after every {args.order_period}-th frame)"),
-                "kernel_ms_avg": round(k_avg, 5), "kernel_ms_median": round(kms[len(kms) // 2], 5),
+                "frames_per_launch": fpl,
+                "kernel_ms_avg": round(k_avg * fpl, 5), "kernel_ms_median": round(kms[len(kms) // 2] * fpl, 5), "kernel_ms_per_frame": round(k_avg, 5),
                 "kernel_ms_how": (f"one HIP event pair on the launch stream around the {args.steps} timed frames / {args.steps} (events inside a captured "
                                   f"graph cannot be timed): an upper bound of the kernel's duration, it includes the gap between consecutive launches") if (use_graph or triangles)
                                  else "HIP event pair around every traversal kernel launch of the timed region, on its launch stream",
@@ -538,14 +591,14 @@ def main(argv=None):
                 "hbm_algorithmic": {
                     "achieved": round(hbm_alg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "ratio": round(hbm_alg / HBM_PEAK_GBS, 4),
                     "bytes_per_ray": round(bytes_per_ray, 2), "pops_per_ray": round(pops_per_ray, 4),
-                    "bytes_per_launch": int(round(rays * bytes_per_ray)),
+                    "bytes_per_launch": int(round(rays * bytes_per_ray)) * fpl,
                     "note": "SURVEY 8d: pops x 60 B reference node + 16 B pixel" + tri_note + ". The packed kernels read 8-byte descriptors of "
                             "internal nodes only (L1/L2 resident), so this ratio exceeds 1: it prices the reference's layout, not this kernel's traffic",
                 },
             }
             if pmc is not None:
-                insts = float(pmc["SQ_INSTS_VALU"])
-                achieved = insts / (k_avg * 1e-3) / 1e9
+                insts = float(pmc["SQ_INSTS_VALU"])                  # per launch = fpl frames
+                achieved = insts / (k_avg * fpl * 1e-3) / 1e9
                 roofline["achieved"] = round(achieved, 1)
                 roofline["frac"] = round(achieved / VALU_PEAK_GINST, 4)
                 roofline["valu_insts_per_launch"] = int(insts)
@@ -554,7 +607,7 @@ def main(argv=None):
                 if kernel_name.startswith("k_trace_lean"):
                     # `frac` prices every instruction at the guide's 2 cycles; two thirds of this loop's instructions are
                     # half-rate on gfx950 (min/max, cvt, cmp, packed f32, 3-operand forms): at the measured issue costs
-                    busy = insts * LEAN_LOOP_CYCLES_PER_INST / (SIMDS * CLOCK_GHZ * 1e9) / (k_avg * 1e-3)
+                    busy = insts * LEAN_LOOP_CYCLES_PER_INST / (SIMDS * CLOCK_GHZ * 1e9) / (k_avg * fpl * 1e-3)
                     roofline["issue_weighted"] = {"frac": round(busy, 4), "cycles_per_instruction": round(LEAN_LOOP_CYCLES_PER_INST, 3),
                                                   "source": "profiles/r02_valu_issue_rates.txt x the loop's instruction mix (DESIGN.md section 5)"}
                 roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
@@ -640,7 +693,7 @@ def main(argv=None):
             "config": {
                 "workload": f"BASELINE config {args.config}: {what}, octree to min-leaf 1 ({info.num_nodes} nodes), "
                             f"{W}x{H} primary rays{', Marching-Cubes leaf triangles + 1 shadow ray per hit' if triangles else ''}, {camtxt}, fov 45",
-                "parallelism": (("1 GPU" + (f", frames replayed from a HIP graph of {gframes} consecutive frames" if use_graph else ", plain stream launches")) if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else
+                "parallelism": (("1 GPU" + (f", {fpl} consecutive frames per kernel launch (rto_render_batch_device)" if fpl > 1 else "") + (f", launches replayed from a HIP graph of {gframes} consecutive frames" if use_graph else ", plain stream launches")) if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else
                                (f"screen split over {world} GPUs, {args.band_rows}-row bands round-robin, rto_comm_submit: ONE grouped RCCL send/recv per {'frame' if fpg == 1 else f'{fpg} frames'} "
                                 f"into rank 0 (4-byte Lambert term per pixel), batch k's gather overlaps batch k+1's render" if use_comm else "") + ("" if use_comm else f"screen split over {world} GPUs, {args.band_rows}-row bands "
                                                           f"round-robin, 1 RCCL gather per {'frame' if fpg == 1 else f'{fpg} frames'} ({'4-byte Lambert term' if args.payload == 'shade' else 'RGBA32F'} per pixel"
@@ -655,6 +708,42 @@ def main(argv=None):
             "verified_against_oracle": verified,
             "device": ctx.device_name,
         }
+        if fpl > 1:
+            # the same frames one launch each, in a graph of their own (outside the timed region): what a caller gets that must
+            # show frame i before it knows frame i+1's camera
+            same = all(bool(torch.equal(batch_buf[i], batch_buf[0])) for i in range(1, fpl))
+            if not same:
+                sys.exit("bench: the frames of one launch differ from each other -- result void")
+            n1 = max(1, min(50, args.steps))
+            one_ms = None
+            try:
+                g1 = torch.cuda.CUDAGraph()
+                ctx.timing_begin(0)
+                for _ in range(3):
+                    render_to(batch_buf.data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g1, stream=stream):
+                    for _ in range(n1):
+                        render_to(batch_buf.data_ptr(), stream.cuda_stream)
+                g1.replay(); torch.cuda.synchronize()
+                reps1 = max(1, min(40, args.steps // n1))
+                e1a, e1b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e1a.record(stream)
+                for _ in range(reps1):
+                    g1.replay()
+                e1b.record(stream)
+                torch.cuda.synchronize()
+                one_ms = e1a.elapsed_time(e1b) / (reps1 * n1)
+            except Exception as e:
+                print(f"bench: one-frame-per-launch leg skipped ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+            if one_ms:
+                result["one_frame_per_launch"] = {"ms_per_frame": round(one_ms, 5), "Mrays_per_s": round(rays / one_ms / 1e3, 1), "frames": reps1 * n1,
+                                                  "what": "rto_render_device, one kernel launch per frame, replayed from a HIP graph: a frame's kernel is as long as its "
+                                                          "deepest tile's chain of dependent node visits; `value` launches several frames together instead"}
+        if args.rehearse_world > 1:
+            result["rehearsal"] = {"as_rank_0_of": args.rehearse_world,
+                                   "what": "ONE GPU doing what rank 0 of that many does per frame (render its bands, grouped send/recv with itself, assemble); "
+                                           "value / ms_per_step are the per-rank pipeline rate of the split, not a frame rate of this machine"}
         if roofline is not None:
             result["roofline"] = roofline
         if orbit is not None:

@@ -195,9 +195,13 @@ int  rto_assemble_shade_device(rto_context* ctx, const rto_frame* frame, const r
  * ([rank][batch][part-0 rows][width], either payload), this rebuilds frame `index` of the batch. */
 int  rto_assemble_batch_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part, const void* d_gathered,
                                int batch, int index, int shade_payload, void* d_frame, void* hip_stream);
-/* The whole batch with one call each (a caller in an interpreted language pays per call): this part of frames[0..n-1]
- * (same width/height) into d_out + i*frame_stride_bytes, either payload; and all `batch` frames of a gather into
- * d_frames + i*frame_stride_bytes. */
+/* Several frames at once: this part (NULL: the whole frame) of frames[0..n-1] (any cameras, same width/height) into
+ * d_out + i*frame_stride_bytes, either payload, asynchronously on hip_stream, up to 8 frames per kernel launch.  One frame's
+ * kernel cannot be shorter than the ~36 us its deepest tile needs for its chain of dependent node visits, with most of the
+ * GPU idle meanwhile; frames rendered together fill it (config 2: 46 -> 36 us per frame; a rank of an 8-GPU split: 36 -> 6 us
+ * per part).  Pixels are those of n rto_render_device calls.  This is the throughput form: a caller that must show frame i
+ * before it knows frame i+1's camera keeps using rto_render_device.
+ * rto_assemble_batch_all_device: all `batch` frames of a gather into d_frames + i*frame_stride_bytes. */
 int  rto_render_batch_device(rto_context* ctx, const rto_frame* frames, int n, const rto_partition* part, int shade_payload,
                              void* d_out, size_t frame_stride_bytes, void* hip_stream);
 int  rto_assemble_batch_all_device(rto_context* ctx, const rto_frame* frames, int batch, const rto_partition* part,
@@ -231,6 +235,9 @@ int  rto_comm_submit_all(rto_comm* const* comms, int n_comms, const rto_frame* f
  * asynchronous, rto_download_resident / rto_resident_frame of rank 0's context give the assembled frame */
 int  rto_comm_render_resident_all(rto_comm* const* comms, int n_comms, const rto_frame* frame, int mode);
 int  rto_comm_flush(rto_comm* comm);              /* waits until every submitted batch is complete on this rank */
+/* Developer aid: a ONE-rank communicator renders, ships and assembles as rank as_rank of as_world GPUs (every per-rank cost
+ * of an N-GPU split except the other GPUs' traffic); the assembled frames hold that rank's bands only.  as_world = 0: off. */
+int  rto_comm_debug_rehearse(rto_comm* comm, int as_world, int as_rank);
 void* rto_comm_stream(rto_comm* comm);            /* hipStream_t the gathers and (rank 0) the assembled frames are ordered on */
 
 /* ---- N2: leaf triangles + shadow ray (BASELINE config 5) -------------------------

@@ -1192,6 +1192,57 @@ static int build_triangle_records(rto_context* c, hipStream_t s) {
     return RTO_OK;
 }
 
+// n frames (n <= kMaxBatch) in one launch of k_trace_lean_batch; falls back to n launches when the lean kernel is not the
+// one in use (generic array, another kernel selected, the culled-root edge).  MODE: kModeColor or kModeShade.
+template <int MODE>
+static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, float4* const* outs, hipStream_t s) {
+    const bool packed = c->kernelMode >= RTO_KERNEL_PACKED || (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
+    const bool lean = packed && c->canonical && (c->kernelMode == RTO_KERNEL_AUTO || c->kernelMode == RTO_KERNEL_PACKED) &&
+                      !(c->culling && !c->rootVisible && c->visibleNodes > 0);
+    bool sameDepth = true;
+    for (int i = 1; i < n; i++) sameDepth = sameDepth && Ps[i].depth == Ps[0].depth;
+    if (!lean || n == 1 || !sameDepth) {
+        for (int i = 0; i < n; i++) {
+            const int rc = launch_trace<MODE>(c, Ps[i], outs[i], s);
+            if (rc != RTO_OK) return rc;
+        }
+        return RTO_OK;
+    }
+    const bool capturing = stream_is_capturing(s);
+    const bool noEvents = capturing || c->eventsOff;
+    RenderBatch B;
+    B.n = n;
+    int maxWaves = 0;
+    rto_context::OrderState* st = nullptr;
+    for (int i = 0; i < n; i++) {
+        B.P[i] = Ps[i];
+        B.out[i] = outs[i];
+        if (Ps[i].tilesX * Ps[i].tilesY <= 0) { B.P[i].launchWaves = 0; continue; }
+        const int solidRect[4] = { Ps[i].solidX0, Ps[i].solidY0, Ps[i].solidX1, Ps[i].solidY1 };
+        const int rc = prepare_schedule(c, s, capturing, true, false, 0, solidRect, B.P[i], &st);
+        if (rc != RTO_OK) return rc;
+        maxWaves = std::max(maxWaves, B.P[i].launchWaves);
+    }
+    // the frames share this stream's launch-order table: it fits the box of the frame that rebuilt it last, every other
+    // box falls back to the centre-out order (any permutation of a frame's own box renders that frame correctly)
+    for (int i = 0; i < n; i++) {
+        if (!B.P[i].tileOrder || !st) continue;
+        const int box[4] = { B.P[i].boxX0, B.P[i].boxY0, B.P[i].boxW, B.P[i].boxH };
+        if (!st->valid || std::memcmp(box, st->box, sizeof box) != 0) B.P[i].tileOrder = nullptr;
+    }
+    if (maxWaves <= 0) return RTO_OK;
+    hipEvent_t evA = c->ev0, evB = c->ev1;
+    if (!noEvents && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
+    if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
+    const size_t lds = (size_t)(kBlock / kWave) * (Ps[0].depth + 1) * kWave * sizeof(uint2);
+    const long long waves = (long long)maxWaves * n;
+    hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)((waves + (kBlock / kWave) - 1) / (kBlock / kWave))), dim3(kBlock), lds, s, B, c->d_desc);
+    RTO_HIP(c, hipGetLastError());
+    if (!noEvents) RTO_HIP(c, hipEventRecord(evB, s));
+    c->timed = !noEvents;
+    return RTO_OK;
+}
+
 extern "C" {
 
 int rto_render_device(rto_context* c, const rto_frame* f, const rto_partition* p, void* d_out, void* hip_stream) {
@@ -1240,11 +1291,11 @@ static int assemble_common(rto_context* c, const rto_frame* f, const rto_partiti
     const size_t stride = partPixels * (size_t)batch, base = partPixels * (size_t)index;
     const int bandRows = p->num_parts > 1 ? p->band_rows : f->height;
     if (shade)
-        hipLaunchKernelGGL(k_assemble_shade, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, (const float*)d_gathered + base, (float4*)d_frame,
-                           f->width, f->height, p->num_parts, bandRows, stride);
+        hipLaunchKernelGGL(k_assemble_shade, dim3(1, (unsigned)f->height, 1), dim3(256), 0, (hipStream_t)hip_stream,
+                           (const float*)d_gathered + base, (char*)d_frame, (size_t)0, (size_t)0, f->width, f->height, p->num_parts, bandRows, stride);
     else
-        hipLaunchKernelGGL(k_assemble, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, (const float4*)d_gathered + base, (float4*)d_frame,
-                           f->width, f->height, p->num_parts, bandRows, stride);
+        hipLaunchKernelGGL(k_assemble, dim3(1, (unsigned)f->height, 1), dim3(256), 0, (hipStream_t)hip_stream,
+                           (const float4*)d_gathered + base, (char*)d_frame, (size_t)0, (size_t)0, f->width, f->height, p->num_parts, bandRows, stride);
     RTO_HIP(c, hipGetLastError());
     return RTO_OK;
 }
@@ -1267,14 +1318,20 @@ int rto_render_batch_device(rto_context* c, const rto_frame* frames, int n, cons
     if (!c) return RTO_E_INVALID;
     if (!frames || n < 1 || !d_out) return fail(c, RTO_E_INVALID, "rto_render_batch_device: NULL argument / empty batch");
     RTO_HIP(c, hipSetDevice(c->device));
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n; i++)
         if (frames[i].width != frames[0].width || frames[i].height != frames[0].height)
             return fail(c, RTO_E_INVALID, "rto_render_batch_device: the frames of a batch share width and height");
-        RenderParams P;
-        int rc = fill_params(c, &frames[i], p, P, (hipStream_t)hip_stream);
-        if (rc != RTO_OK) return rc;
-        float4* out = reinterpret_cast<float4*>(static_cast<char*>(d_out) + (size_t)i * frame_stride_bytes);
-        rc = shade_payload ? launch_trace<kModeShade>(c, P, out, (hipStream_t)hip_stream) : launch_trace<kModeColor>(c, P, out, (hipStream_t)hip_stream);
+    for (int i0 = 0; i0 < n; i0 += kMaxBatch) {
+        const int m = std::min(kMaxBatch, n - i0);
+        RenderParams P[kMaxBatch];
+        float4* outs[kMaxBatch];
+        for (int i = 0; i < m; i++) {
+            const int rc = fill_params(c, &frames[i0 + i], p, P[i], (hipStream_t)hip_stream);
+            if (rc != RTO_OK) return rc;
+            outs[i] = reinterpret_cast<float4*>(static_cast<char*>(d_out) + (size_t)(i0 + i) * frame_stride_bytes);
+        }
+        const int rc = shade_payload ? launch_trace_batch<kModeShade>(c, P, m, outs, (hipStream_t)hip_stream)
+                                     : launch_trace_batch<kModeColor>(c, P, m, outs, (hipStream_t)hip_stream);
         if (rc != RTO_OK) return rc;
     }
     return RTO_OK;

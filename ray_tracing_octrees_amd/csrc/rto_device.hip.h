@@ -1068,6 +1068,30 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean(RenderPar
     trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
 }
 
+// Several frames in ONE launch (rto_render_batch_device, and every rank of the multi-GPU split: its parts of a batch of
+// frames).  A frame's kernel cannot finish before its deepest tile has walked its ~140 dependent node visits (~36 us at
+// config 2, whatever share of the frame the launch covers), and while that tile walks most wave slots are idle; waves of
+// other frames fill them.  Launch slots are dealt round-robin over the frames (wave g -> frame g % n, slot g / n), so the
+// costliest tiles of every frame start first.  Each frame brings its own RenderParams (camera, rectangle, launch order).
+constexpr int kMaxBatch = 8;
+struct RenderBatch {
+    RenderParams P[kMaxBatch];
+    float4* out[kMaxBatch];
+    int n;
+};
+template <int MODE>
+__global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_batch(RenderBatch B, const uint2* __restrict__ desc) {
+    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    const int slot = g / B.n, f = g - slot * B.n;
+    const RenderParams& P = B.P[f];
+    uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;
+    if (slot >= P.launchWaves) return;
+    trace_tile_lean<MODE>(P, desc, B.out[f], nullptr, nullptr, stk, lane, slot);
+}
+
 // Persistent-threads form of the default kernel (RTO_KERNEL_PACKED_PERSISTENT): the grid only fills the machine, every
 // wave renders its first tile and then keeps taking launch slots from a global counter until none is left.  The host
 // zeroes the counter with a memset node in front of every launch, so each launch is self-contained (safe to capture
@@ -2888,29 +2912,29 @@ __global__ __launch_bounds__(kBlock) void k_block_exclusive_scan(const int* __re
 // d_gathered: numParts compact buffers, each padded to partRows rows of W pixels; part p starts partStride pixels after
 // part p-1 (partRows * W when one frame was gathered; batch * partRows * W when the ranks shipped `batch` frames in
 // one collective, the caller then passes the pointer to its frame inside part 0).
-__global__ void k_assemble(const float4* __restrict__ gathered, float4* __restrict__ frame,
+// One block row per image row (the band arithmetic is per row, not per pixel), blockIdx.z = frame of the batch; a frame of
+// the batch starts srcFrameStride elements after the previous one inside every part, and dstFrameStride bytes after it in
+// the output.  HBM-bound: 16 B (4 B) read and 16 B written per pixel.
+__global__ void k_assemble(const float4* __restrict__ gathered, char* __restrict__ frames, size_t srcFrameStride, size_t dstFrameStride,
                            int W, int H, int numParts, int bandRows, size_t partStride) {
-    const size_t n = (size_t)W * H;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        int y = (int)(i / W), x = (int)(i - (size_t)y * W);
-        int gband = y / bandRows, r = y - gband * bandRows;
-        int part = gband % numParts, band = gband / numParts;
-        size_t src = (size_t)part * partStride + ((size_t)band * bandRows + r) * W + x;
-        frame[i] = gathered[src];
-    }
+    const int y = blockIdx.y;
+    const int gband = y / bandRows, r = y - gband * bandRows;
+    const int part = gband % numParts, band = gband / numParts;
+    const float4* src = gathered + (size_t)blockIdx.z * srcFrameStride + (size_t)part * partStride + ((size_t)band * bandRows + r) * W;
+    float4* dst = reinterpret_cast<float4*>(frames + (size_t)blockIdx.z * dstFrameStride) + (size_t)y * W;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < W; x += gridDim.x * blockDim.x) store_pixel(dst + x, src[x]);
 }
 
 // Same re-interleave for the 4-byte shade payload, finishing the colour expression (shade_color) on the way.
-__global__ void k_assemble_shade(const float* __restrict__ gathered, float4* __restrict__ frame,
+__global__ void k_assemble_shade(const float* __restrict__ gathered, char* __restrict__ frames, size_t srcFrameStride, size_t dstFrameStride,
                                  int W, int H, int numParts, int bandRows, size_t partStride) {
-    const size_t n = (size_t)W * H;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        int y = (int)(i / W), x = (int)(i - (size_t)y * W);
-        int gband = y / bandRows, r = y - gband * bandRows;
-        int part = gband % numParts, band = gband / numParts;
-        size_t src = (size_t)part * partStride + ((size_t)band * bandRows + r) * W + x;
-        frame[i] = shade_color(gathered[src]);
-    }
+    const int y = blockIdx.y;
+    const int gband = y / bandRows, r = y - gband * bandRows;
+    const int part = gband % numParts, band = gband / numParts;
+    const float* src = gathered + (size_t)blockIdx.z * srcFrameStride + (size_t)part * partStride + ((size_t)band * bandRows + r) * W;
+    float4* dst = reinterpret_cast<float4*>(frames + (size_t)blockIdx.z * dstFrameStride) + (size_t)y * W;
+    // consecutive lanes take consecutive pixels: 256 B read, 1 KB written per wave instruction, whole lines either way
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < W; x += gridDim.x * blockDim.x) store_pixel(dst + x, shade_color(src[x]));
 }
 
 }  // namespace rto

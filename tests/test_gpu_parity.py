@@ -673,6 +673,51 @@ def test_frames_in_flight_on_several_streams_of_one_context(ctx, orc, scenes):
         ctx.set_launch_order(1, 8)
 
 
+def test_several_frames_in_one_launch(ctx, orc, scenes):
+    """rto_render_batch_device: up to 8 frames per kernel launch (k_trace_lean_batch), every frame with its own camera --
+    hence its own rectangle, box and launch order.  11 frames = a launch of 8 and one of 3; whole frames in colour, one
+    part of a 3-way split as the 4-byte payload; repeated so that the shared launch-order table is rebuilt in between;
+    the other kernel choices take the same call as a sequence of launches."""
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere64")
+    upload(ctx, s)
+    W, H = 417, 250
+    cams = [orc.Camera(0.2 + 0.45 * i, 0.3 + 0.11 * i, 1.5 + 0.07 * i) for i in range(11)]
+    frames = [rto.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H) for c in cams]
+    wants = [oracle_frame(orc, s, c.get_view(), c.get_pos(), W, H)[0] for c in cams]
+    arr = hip.Context.frame_array(frames)
+    stream = torch.cuda.Stream()
+    out = torch.empty((11, H, W, 4), dtype=torch.float32, device="cuda")
+    try:
+        for kernel in (rto.KERNEL_AUTO, rto.KERNEL_PACKED_V3, rto.KERNEL_GENERIC):
+            ctx.set_kernel(kernel)
+            for rep in range(3 if kernel == rto.KERNEL_AUTO else 1):
+                ctx.set_launch_order(1, 1 + rep)
+                out.fill_(7.0)
+                torch.cuda.synchronize()
+                ctx.render_batch_device(arr, out.data_ptr(), out.stride(0) * 4, None, False, stream.cuda_stream)
+                torch.cuda.synchronize()
+                for i in range(11):
+                    assert_bit_exact(out[i].cpu().numpy(), wants[i], f"batched frame {i}, kernel {kernel}, repeat {rep}")
+        ctx.set_kernel(rto.KERNEL_AUTO)
+        part = hip.Partition(3, 1, 16)
+        rows = ctx.partition_rows(frames[0], part)
+        shade = torch.full((11, rows, W), 7.0, dtype=torch.float32, device="cuda")
+        ctx.render_batch_device(arr, shade.data_ptr(), shade.stride(0) * 4, part, True, stream.cuda_stream)
+        torch.cuda.synchronize()
+        owner = (np.arange(H) // 16) % 3
+        for i in range(11):
+            one = torch.empty((rows, W), dtype=torch.float32, device="cuda")
+            ctx.render_shade_device(frames[i], one.data_ptr(), part, stream.cuda_stream)
+            torch.cuda.synchronize()
+            assert one.cpu().numpy().tobytes() == shade[i].cpu().numpy().tobytes(), f"batched part, frame {i}"
+        assert int((owner == 1).sum()) == rows
+        assert ctx.debug_sort_violations() == 0
+    finally:
+        ctx.set_kernel(rto.KERNEL_AUTO)
+        ctx.set_launch_order(1, 8)
+
+
 def test_resident_frame_stays_on_the_gpu(ctx, orc, scenes, camera):
     """rto_render_resident leaves the frame in the context's device buffer (the reference's texture is never read
     back either); rto_download_resident / the device pointer give the oracle's pixels, for the octree and triangle paths."""
@@ -1299,6 +1344,24 @@ def test_comm_one_rank_through_the_c_abi(ctx, orc, scenes):
             assert_bit_exact(one.cpu().numpy(), wtri, f"comm triangles mode {mode}")
         with pytest.raises(rto.RtoError):
             comm.submit(arr4, 0, 0)                                     # rank 0 without a frame buffer
+        # every rank of a 2-, 3- and 8-GPU split, played in turn by this GPU (rto_comm_debug_rehearse): the bands rank r
+        # renders, ships and assembles must be the oracle's rows b*16 .. b*16+15 with b % world == r -- together the whole frame
+        upload(ctx, s)
+        for world in (2, 3, 8):
+            got = np.zeros((H, W, 4), np.float32)
+            owner = (np.arange(H) // 16) % world
+            for r in range(world):
+                comm.debug_rehearse(world, r)
+                two = torch.full((2, H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+                comm.submit(hip.Context.frame_array([frames[0], frames[3]]), two.data_ptr(), two.stride(0) * 4)
+                comm.flush()
+                a, b = two[0].cpu().numpy(), two[1].cpu().numpy()
+                got[owner == r] = a[owner == r]
+                assert_bit_exact(b[owner == r], wants[3][owner == r], f"rehearsal world {world} rank {r}, second frame of the batch")
+            assert_bit_exact(got, wants[0], f"rehearsal world {world}: the ranks' bands together")
+        comm.debug_rehearse(0)
+        with pytest.raises(rto.RtoError):
+            comm.debug_rehearse(4, 4)
     finally:
         comm.close()
 

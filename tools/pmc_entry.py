@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_entry.py SUMMARY.json CONFIG KERNEL ORDER SOURCE -- merge the counters of one tools/profile_gpu.sh run
+"""tools/pmc_entry.py SUMMARY.json CONFIG KERNEL ORDER SOURCE [FRAMES_PER_LAUNCH] -- merge the counters of one tools/profile_gpu.sh run
 into profiles/pmc_counters.json (what bench.py reads for roofline.achieved / traffic; keyed by config, kernel and
 launch order, stamped with the commit and a hash of the device sources the counters were measured on)."""
 import hashlib
@@ -21,11 +21,12 @@ def device_source_hash() -> str:
 
 def main():
     summary_path, config, kernel, order, source = sys.argv[1:6]
+    fpl = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     s = json.load(open(summary_path))
-    name = next(k for k in s["counters_per_launch"] if kernel in k and ("<0" in k or "<" not in k))
+    name = next(k for k in s["counters_per_launch"] if (kernel + "<0") in k or (kernel + "(") in k)     # exact kernel, colour mode
     c = s["counters_per_launch"][name]
     entry = {
-        "config": config, "kernel": kernel, "order": order, "kernel_symbol": name,
+        "config": config, "kernel": kernel, "order": order, "kernel_symbol": name, "frames_per_launch": fpl,
         "SQ_INSTS_VALU": int(round(c["SQ_INSTS_VALU"])), "SQ_THREAD_CYCLES_VALU": int(round(c["SQ_THREAD_CYCLES_VALU"])),
         "SQ_WAVES": int(round(c["SQ_WAVES"])),
         "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
@@ -34,7 +35,7 @@ def main():
         "source": source,
         "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
         "device_source_hash": device_source_hash(),
-        "note": "rocprofv3 --pmc, separate passes (counters only), 10 plain-launch frames each; FETCH_SIZE/WRITE_SIZE in KiB, read side "
+        "note": "rocprofv3 --pmc, separate passes (counters only), 12 plain-launch frames each; FETCH_SIZE/WRITE_SIZE in KiB, read side "
                 "doubled per MI355X_MICROARCH.md (an upper bound for 8-byte gathers)",
     }
     path = os.path.join(ROOT, "profiles", "pmc_counters.json")

@@ -2,7 +2,7 @@
 # tools/profile_gpu.sh TAG CONFIG [extra bench args...]  -- run on the GPU box (via gpurun), from the repo root.
 # Collects, for `python3 bench.py --config CONFIG <args>`:
 #   1. rocprofv3 --kernel-trace --stats            (per-kernel durations of the default bench run)
-#   2. separate --pmc passes (counters only; never combined with other trace domains), 10 frames each
+#   2. separate --pmc passes (counters only; never combined with other trace domains), 12 frames each
 # and writes raw CSVs under gpurun_out/prof_$TAG/, a JSON summary gpurun_out/prof_$TAG/summary.json
 # (tools/summarize_profile.py) and the bench line of pass 1 (bench.json).  Copy what should be judged into
 # profiles/ and merge the counters with tools/pmc_entry.py.
@@ -25,7 +25,7 @@ PASSES=(
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --pmc $P --output-format csv -d "$OUT/pmc$i" -- python3 "$R/bench.py" $ARGS --steps 10 --warmup 2 --ramp-ms 0 --graph-frames 0 > "$OUT/pmc$i.log" 2>&1 || { echo "pmc pass $i ($P) failed"; tail -3 "$OUT/pmc$i.log"; }
+  timeout -k 10 400 rocprofv3 --pmc $P --output-format csv -d "$OUT/pmc$i" -- python3 "$R/bench.py" $ARGS --steps 12 --warmup 2 --ramp-ms 0 --graph-frames 0 > "$OUT/pmc$i.log" 2>&1 || { echo "pmc pass $i ($P) failed"; tail -3 "$OUT/pmc$i.log"; }
 done
 cd "$R"
 python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.json" && python3 - "$OUT/summary.json" <<'PY'
