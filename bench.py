@@ -571,7 +571,7 @@ def main(argv=None):
             hbm_alg = rays * bytes_per_ray / (k_avg * 1e-3) / 1e9
             order_key = "centre-out" if args.order != "temporal" else "temporal"
             pmc = pmc_entry(args.config, kernel_name, order_key)
-            if pmc is not None and int(pmc.get("frames_per_launch", 1)) != fpl:
+            if pmc is not None and int(pmc.get("frames_per_launch") or 1) != fpl:
                 pmc = None                                           # counted for another batch size
             roofline = {
                 "bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s", "frac": None,
