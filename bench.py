@@ -513,6 +513,10 @@ def main(argv=None):
         elapsed = max_over_ranks(elapsed)
 
     # ---- everything below is outside the timed region ---------------------------------------------
+    if img is not None:
+        img = img.clone()                                # the legs below reuse the frame buffers
+    if fpl > 1 and not all(bool(torch.equal(batch_buf[i], batch_buf[0])) for i in range(1, fpl)):
+        sys.exit("bench: the frames of one launch differ from each other -- result void")
     rays = W * H
     result = None
     latency = None
@@ -648,6 +652,22 @@ def main(argv=None):
                          f"least every {args.order_period}-th frame (k_order_build inside the timed region)",
                          "ms_per_frame": round(wall / n_orbit * 1e3, 5), "gpu_ms_per_frame": round(ea.elapsed_time(eb) / n_orbit, 5),
                          "Mrays_per_s": round(rays * n_orbit / wall / 1e6, 1)}
+                if fpl > 1:
+                    # the same orbit when the cameras of fpl consecutive frames are known together (a recorded path, an offline
+                    # sequence): fpl frames per launch, each with its own camera, plain launches
+                    groups = [rto.Context.frame_array(oframes[i:i + fpl]) for i in range(0, n_orbit - n_orbit % fpl, fpl)]
+                    ctx.timing_begin(-1)
+                    for ga in groups[:4]:
+                        ctx.render_batch_device(ga, batch_buf.data_ptr(), H * W * 16, None, False, stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    t_o = time.perf_counter()
+                    for ga in groups:
+                        ctx.render_batch_device(ga, batch_buf.data_ptr(), H * W * 16, None, False, stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    wall = time.perf_counter() - t_o
+                    ctx.timing_begin(0)
+                    nb = len(groups) * fpl
+                    orbit["frames_per_launch_%d" % fpl] = {"frames": nb, "ms_per_frame": round(wall / nb * 1e3, 5), "Mrays_per_s": round(rays * nb / wall / 1e6, 1)}
         pcie = None
         if world == 1 and not triangles:
             # the C ABI's host-buffer entry point (kernel + D2H over PCIe): informational, never `value`
@@ -711,9 +731,6 @@ def main(argv=None):
         if fpl > 1:
             # the same frames one launch each, in a graph of their own (outside the timed region): what a caller gets that must
             # show frame i before it knows frame i+1's camera
-            same = all(bool(torch.equal(batch_buf[i], batch_buf[0])) for i in range(1, fpl))
-            if not same:
-                sys.exit("bench: the frames of one launch differ from each other -- result void")
             n1 = max(1, min(50, args.steps))
             one_ms = None
             try:
