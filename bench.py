@@ -608,7 +608,7 @@ def main(argv=None):
                 roofline["valu_insts_per_launch"] = int(insts)
                 if pmc.get("SQ_THREAD_CYCLES_VALU"):
                     roofline["lane_utilisation"] = round(float(pmc["SQ_THREAD_CYCLES_VALU"]) / (64.0 * insts), 3)
-                if kernel_name.startswith("k_trace_lean"):
+                if kernel_name in ("k_trace_lean", "k_trace_lean_batch", "k_trace_lean_persistent"):
                     # `frac` prices every instruction at the guide's 2 cycles; two thirds of this loop's instructions are
                     # half-rate on gfx950 (min/max, cvt, cmp, packed f32, 3-operand forms): at the measured issue costs
                     busy = insts * LEAN_LOOP_CYCLES_PER_INST / (SIMDS * CLOCK_GHZ * 1e9) / (k_avg * fpl * 1e-3)
