@@ -1031,7 +1031,7 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     rto_context::OrderState* st = order_state(c, s, capturing);      // this stream's scheduling state
     *stOut = st;
     rto_context::OrderState* o = (c->orderPolicy == RTO_ORDER_TEMPORAL && (frameMode || timelineMode) &&
-                                  P.tilesX <= 0xffff && P.tilesY <= 0x7fff) ? st : nullptr;      // table entries are tx | ty << 16
+                                  P.tilesX <= 0xffff && P.tilesY <= 0x7fff) ? st : nullptr;      // table entries are x | y << 16 inside the box
     if (o) {
         c->lastOrderStream = s;
         if (o->tiles != tiles) {
@@ -1057,10 +1057,11 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     }
     if (o) {
         const int box[4] = { Q.boxX0, Q.boxY0, Q.boxW, Q.boxH };
-        // The table is a scheduling hint rebuilt from the costs the previous frames recorded: when the box moved
-        // (camera) or every orderPeriod-th frame.  k_order_build emits a permutation of the box's tiles whatever the
+        // The table is a scheduling hint rebuilt from the costs the previous frames recorded: when the box changed its
+        // SIZE (the entries are relative to the box's corner: a box that only moved -- a camera in motion -- keeps using
+        // it) or every orderPeriod-th frame.  k_order_build emits a permutation of the box's tiles whatever the
         // cost array holds and keeps no state between calls, so rebuilding inside a stream capture is safe too.
-        if (!o->fixed && Q.traceWaves > 0 && (!o->valid || std::memcmp(box, o->box, sizeof box) != 0 || o->age >= c->orderPeriod)) {
+        if (!o->fixed && Q.traceWaves > 0 && (!o->valid || box[2] != o->box[2] || box[3] != o->box[3] || o->age >= c->orderPeriod)) {
             if (o->costValid) {
                 const int staged = Q.traceWaves <= kOrderLdsTiles ? 1 : 0;
                 hipLaunchKernelGGL(k_order_build, dim3(1), dim3(kOrderBlock), staged ? (size_t)((Q.traceWaves + 15) & ~15) : 0, s, o->d_tileCost, Q.tilesX,
@@ -1223,12 +1224,13 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
         if (rc != RTO_OK) return rc;
         maxWaves = std::max(maxWaves, B.P[i].launchWaves);
     }
-    // the frames share this stream's launch-order table: it fits the box of the frame that rebuilt it last, every other
-    // box falls back to the centre-out order (any permutation of a frame's own box renders that frame correctly)
+    // the frames share this stream's launch-order table: its entries are relative to the box's corner, so it serves every
+    // frame whose box has the size of the one it was last rebuilt for (a moving camera shifts the box far more often than
+    // it resizes it); any other box falls back to the centre-out order (any permutation of a frame's own box renders it)
     for (int i = 0; i < n; i++) {
-        if (!B.P[i].tileOrder || !st) continue;
-        const int box[4] = { B.P[i].boxX0, B.P[i].boxY0, B.P[i].boxW, B.P[i].boxH };
-        if (!st->valid || std::memcmp(box, st->box, sizeof box) != 0) B.P[i].tileOrder = nullptr;
+        if (!st || B.P[i].launchWaves <= 0 || !B.P[i].tileCost) continue;       // tileCost set: the temporal order is in use for this frame
+        const bool fits = st->valid && B.P[i].boxW == st->box[2] && B.P[i].boxH == st->box[3] && B.P[i].traceWaves > 0;
+        B.P[i].tileOrder = fits ? st->d_tileOrder : nullptr;
     }
     if (maxWaves <= 0) return RTO_OK;
     hipEvent_t evA = c->ev0, evB = c->ev1;

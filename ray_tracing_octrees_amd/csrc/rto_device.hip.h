@@ -70,7 +70,7 @@ struct RenderParams {
     int orderCx, orderCy;           // tile nearest the projected scene centre: tiles launch centre-out (heavy first)
     int rootX0, rootY0, rootX1, rootY1;   // pixel rectangle (inclusive, GLOBAL rows) outside of which no ray can meet the root box
     int solidX0, solidY0, solidX1, solidY1;   // the same for the bounding box of the solid leaves (host side: replaces root* for colour / shade frames)
-    const int* tileOrder;           // launch slot -> tile as tx | ty << 16: the tiles of the box below, costliest tiles of an EARLIER
+    const int* tileOrder;           // launch slot -> tile as x | y << 16 relative to the box below: its tiles, costliest tiles of an EARLIER
                                     // frame first (null: centre-out over the box)
     int* tileCost;                  // tile -> loop trip count of its wave in THIS frame (null: not recorded)
     // Launch geometry of the packed kernels.  Only tiles of the box [boxX0, boxX0+boxW) x [boxY0, boxY0+boxH) -- the tile
@@ -527,7 +527,7 @@ __device__ __forceinline__ void tile_of(const RenderParams& P, int t, int& tx, i
 __device__ __forceinline__ bool resolve_slot(const RenderParams& P, int slot, int& tx, int& ty, int& tile) {
     tx = 0; ty = P.tilesY; tile = 0;
     if (slot >= P.traceWaves) return false;
-    if (P.tileOrder) { const unsigned e = (unsigned)P.tileOrder[slot]; tx = (int)(e & 0xffffu); ty = (int)(e >> 16); }   // entries are tx | ty << 16
+    if (P.tileOrder) { const unsigned e = (unsigned)P.tileOrder[slot]; tx = P.boxX0 + (int)(e & 0xffffu); ty = P.boxY0 + (int)(e >> 16); }   // entries: tile inside the box, x | y << 16
     else tile_of(P, slot, tx, ty);
     tile = ty * P.tilesX + tx;
     return true;
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_persisten
 // Launch order of the box's tiles: a counting sort by descending cost (trip count an earlier frame recorded, 64
 // buckets of min(trips, 63)) done by ONE 1,024-thread block -- a few thousand tiles, no inter-block state: whatever the
 // cost array holds (stale values, tiles that were outside the box when it was written), the result is a permutation of
-// the box's tiles (entries tx | ty << 16), so every tile is rendered exactly once.  Wave w owns the box rows w, w+16, ...
+// the box's tiles (entries x | y << 16 relative to the box's corner), so every tile is rendered exactly once.  Wave w owns the box rows w, w+16, ...
 // (lanes walk a row: no division anywhere); the buckets of its tiles are staged in LDS by one pass of independent,
 // coalesced loads (reading the costs inside the counting loops cost a dependent global load per step, 80 us per build),
 // then counted and placed with LDS atomics.  Tiles of one bucket keep their wave order; within a wave the order is the
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_build(const int* __restri
             const int pos = atomicAdd(&cnt[wave][staged ? (int)stagedBucket[ry * boxW + rx] : bucket_at(rx, ry)], 1);
             // cannot fall outside by construction (both passes see the same buckets: the kernel that writes the costs runs
             // before or after this one on the stream, never beside it); refused writes are counted and tests assert 0
-            if (pos >= 0 && pos < n) order[pos] = (boxX0 + rx) | ((boxY0 + ry) << 16);
+            if (pos >= 0 && pos < n) order[pos] = rx | (ry << 16);           // relative to the box: a box of the same size elsewhere can use the table
             else atomicAdd(violations, 1);
         }
 }
