@@ -423,9 +423,9 @@ def main(argv=None):
             render_to(bufs[i].data_ptr(), streams[i].cuda_stream)
         sync_all()
     use_graph = world == 1 and fif == 1 and args.graph_frames > 0 and not use_comm
-    # frames per kernel launch (rto_render_batch_device): octree frames of the single-GPU path only
+    # frames per kernel launch (rto_render_batch_device / rto_render_triangles_batch_device): the single-GPU path
     fpl = 1
-    if world == 1 and fif == 1 and not use_comm and not triangles:
+    if world == 1 and fif == 1 and not use_comm:
         fpl = max(1, min(8, args.steps, 4 if args.frames_per_launch is None else args.frames_per_launch))
     batch_buf = torch.empty((fpl, H, W, 4), dtype=torch.float32, device="cuda") if fpl > 1 else None
     batch_arrs = {}
@@ -434,7 +434,10 @@ def main(argv=None):
         """nf <= fpl consecutive frames in one launch, into batch_buf[0..nf-1]"""
         if nf not in batch_arrs:
             batch_arrs[nf] = rto.Context.frame_array([frame] * nf)
-        ctx.render_batch_device(batch_arrs[nf], (out if out is not None else batch_buf).data_ptr(), H * W * 16, None, False, stream.cuda_stream)
+        if triangles:
+            ctx.render_triangles_batch_device(batch_arrs[nf], (out if out is not None else batch_buf).data_ptr(), H * W * 16, True, None, False, stream.cuda_stream)
+        else:
+            ctx.render_batch_device(batch_arrs[nf], (out if out is not None else batch_buf).data_ptr(), H * W * 16, None, False, stream.cuda_stream)
 
     def render_frames_plain(nframes):
         if fpl == 1:
@@ -543,6 +546,8 @@ def main(argv=None):
             kernel_name = "k_trace_lean_batch"
         if triangles:
             kernel_name = ("k_trace_packed_triangles" if args.kernel == "packed_v3" else "k_trace_lean_triangles") if (info.canonical and args.kernel != "generic") else "k_trace_triangles"
+            if fpl > 1 and kernel_name == "k_trace_lean_triangles":
+                kernel_name = "k_trace_lean_triangles_batch"
             _, tstats = ctx.render_triangles_host(frame, shadow=True, stats=True)     # primary + shadow pops (instrumented kernel)
             stats = {"rays": rays, "pops": tstats["pops"], "hits": tstats["hits"], "capped": None}
         else:

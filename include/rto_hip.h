@@ -259,6 +259,11 @@ int  rto_download_leaf_triangles(rto_context* ctx, float* tris, int64_t tri_capa
                                  int64_t* num_tris);
 int  rto_render_triangles_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part, int shadow,
                                  void* d_out, void* hip_stream);
+/* Several frames per kernel launch, as rto_render_batch_device: this part (NULL: whole frames) of frames[0..n-1] into
+ * d_out + i*frame_stride_bytes, RGBA32F or (shade_payload) the 4-byte Lambert term.  A part's kernel lasts as long as its
+ * deepest tile (0.24 ms at config 5 whatever its share of the pixels); parts launched together fill the GPU. */
+int  rto_render_triangles_batch_device(rto_context* ctx, const rto_frame* frames, int n, const rto_partition* part, int shadow, int shade_payload,
+                                       void* d_out, size_t frame_stride_bytes, void* hip_stream);
 int  rto_render_triangles_host(rto_context* ctx, const rto_frame* frame, int shadow, float* host_rgba, rto_stats* stats);
 /* 4-byte payload variant (see rto_render_shade_device); reassemble with rto_assemble_shade_device. */
 int  rto_render_triangles_shade_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part, int shadow,

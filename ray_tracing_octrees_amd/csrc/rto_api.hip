@@ -1614,6 +1614,72 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
     return RTO_OK;
 }
 
+// The parts (or whole frames) of n <= kMaxBatch frames in one launch of k_trace_lean_triangles_batch; n launches when the
+// lean triangle kernel is not the one in use.
+static int launch_triangles_batch(rto_context* c, const rto_frame* frames, int n, const rto_partition* p, int shadow, float4* const* outs,
+                                  hipStream_t s, bool shadeOut) {
+    const bool lean = c->d_triRec && c->canonical && c->numInternal > 0 && !c->culling &&
+                      (c->kernelMode == RTO_KERNEL_AUTO || c->kernelMode == RTO_KERNEL_PACKED);
+    if (!lean || n == 1) {
+        for (int i = 0; i < n; i++) {
+            const int rc = launch_triangles(c, &frames[i], p, shadow, outs[i], s, false, shadeOut);
+            if (rc != RTO_OK) return rc;
+        }
+        return RTO_OK;
+    }
+    if (!c->d_triOffset) return fail(c, RTO_E_NO_OCTREE, "render_triangles: no leaf triangles uploaded");
+    const bool capturing = stream_is_capturing(s);
+    const bool noEvents = capturing || c->eventsOff;
+    RenderBatch B;
+    B.n = n;
+    int maxWaves = 0;
+    rto_context::OrderState* st = nullptr;
+    for (int i = 0; i < n; i++) {
+        int rc = fill_params(c, &frames[i], p, B.P[i], s);
+        if (rc != RTO_OK) return rc;
+        B.out[i] = outs[i];
+        if (B.P[i].tilesX * B.P[i].tilesY <= 0) { B.P[i].launchWaves = 0; continue; }
+        const int solidRect[4] = { B.P[i].solidX0, B.P[i].solidY0, B.P[i].solidX1, B.P[i].solidY1 };
+        if ((rc = prepare_schedule(c, s, capturing, true, false, 1, solidRect, B.P[i], &st)) != RTO_OK) return rc;
+        maxWaves = std::max(maxWaves, B.P[i].launchWaves);
+    }
+    for (int i = 0; i < n; i++) {                                   // one box-relative order table per stream: see launch_trace_batch
+        if (!st || B.P[i].launchWaves <= 0 || !B.P[i].tileCost) continue;
+        const bool fits = st->valid && B.P[i].boxW == st->box[2] && B.P[i].boxH == st->box[3] && B.P[i].traceWaves > 0;
+        B.P[i].tileOrder = fits ? st->d_tileOrder : nullptr;
+    }
+    if (maxWaves <= 0) return RTO_OK;
+    if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev0, s));
+    LeanTriScene S{ c->d_triRec, c->d_tris };
+    const size_t lds = (size_t)(kBlock / kWave) * ((B.P[0].depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));
+    const long long waves = (long long)maxWaves * n;
+    const dim3 grid((unsigned)((waves + (kBlock / kWave) - 1) / (kBlock / kWave)));
+    if (shadeOut) hipLaunchKernelGGL(k_trace_lean_triangles_batch<true>, grid, dim3(kBlock), lds, s, B, S, shadow);
+    else hipLaunchKernelGGL(k_trace_lean_triangles_batch<false>, grid, dim3(kBlock), lds, s, B, S, shadow);
+    RTO_HIP(c, hipGetLastError());
+    if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev1, s));
+    c->timed = !noEvents;
+    return RTO_OK;
+}
+
+int rto_render_triangles_batch_device(rto_context* c, const rto_frame* frames, int n, const rto_partition* p, int shadow, int shade_payload,
+                                      void* d_out, size_t frame_stride_bytes, void* hip_stream) {
+    if (!c) return RTO_E_INVALID;
+    if (!frames || n < 1 || !d_out) return fail(c, RTO_E_INVALID, "rto_render_triangles_batch_device: NULL argument / empty batch");
+    RTO_HIP(c, hipSetDevice(c->device));
+    for (int i = 0; i < n; i++)
+        if (frames[i].width != frames[0].width || frames[i].height != frames[0].height)
+            return fail(c, RTO_E_INVALID, "rto_render_triangles_batch_device: the frames of a batch share width and height");
+    for (int i0 = 0; i0 < n; i0 += kMaxBatch) {
+        const int m = std::min(kMaxBatch, n - i0);
+        float4* outs[kMaxBatch];
+        for (int i = 0; i < m; i++) outs[i] = reinterpret_cast<float4*>(static_cast<char*>(d_out) + (size_t)(i0 + i) * frame_stride_bytes);
+        const int rc = launch_triangles_batch(c, &frames[i0], m, p, shadow, outs, (hipStream_t)hip_stream, shade_payload != 0);
+        if (rc != RTO_OK) return rc;
+    }
+    return RTO_OK;
+}
+
 int rto_render_triangles_device(rto_context* c, const rto_frame* f, const rto_partition* p, int shadow, void* d_out, void* hip_stream) {
     if (!c) return RTO_E_INVALID;
     if (!d_out) return fail(c, RTO_E_INVALID, "rto_render_triangles_device: d_out is NULL");

@@ -1665,15 +1665,9 @@ __global__ __launch_bounds__(kBlock) void k_unified_fill(const uint2* __restrict
 #define RTO_TRI_BATCH 16
 #endif
 template <int MODE, bool SHADE>
-__global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles(RenderParams P, LeanTriScene Sc, int shadow, float4* __restrict__ out,
-                                                                                 Counters* __restrict__ counters) {
-    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64], b in [0, depth]
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds_stack + (size_t)(kBlock / kWave) * (P.depth + 1) * kWave) + wave * kWave;
-    const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
-    if (slot >= P.launchWaves) return;
+__device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P, const LeanTriScene& Sc, int shadow, float4* __restrict__ out,
+                                                          Counters* __restrict__ counters, uint2* stk, unsigned long long* keys,
+                                                          const int lane, const int slot) {
     int tile, tx, ty;
     resolve_slot(P, slot, tx, ty, tile);
     const int px = tx * 8 + (lane & 7);
@@ -1889,6 +1883,35 @@ __global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles(
         for (int off = 32; off > 0; off >>= 1) { pops += __shfl_down(pops, off); hits += __shfl_down(hits, off); }
         if (lane == 0) { atomicAdd(&counters->pops, pops); atomicAdd(&counters->hits, hits); }
     }
+}
+
+template <int MODE, bool SHADE>
+__global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles(RenderParams P, LeanTriScene Sc, int shadow, float4* __restrict__ out,
+                                                                                 Counters* __restrict__ counters) {
+    extern __shared__ uint2 lds_stack[];   // [wave][level][lane], then the keys of the triangle rounds [wave][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64], b in [0, depth]
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds_stack + (size_t)(kBlock / kWave) * (P.depth + 1) * kWave) + wave * kWave;
+    const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    if (slot >= P.launchWaves) return;
+    trace_tile_lean_triangles<MODE, SHADE>(P, Sc, shadow, out, counters, stk, keys, lane, slot);
+}
+
+// Several frames (or the parts of several frames: a rank of the multi-GPU split) in one launch, as k_trace_lean_batch: a
+// part's kernel lasts as long as its deepest tile (~0.24 ms at config 5 whatever the part's share of the pixels).
+template <bool SHADE>
+__global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles_batch(RenderBatch B, LeanTriScene Sc, int shadow) {
+    extern __shared__ uint2 lds_stack[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    const int slot = g / B.n, f = g - slot * B.n;
+    const RenderParams& P = B.P[f];
+    uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds_stack + (size_t)(kBlock / kWave) * (P.depth + 1) * kWave) + wave * kWave;
+    if (slot >= P.launchWaves) return;
+    trace_tile_lean_triangles<kModeColor, SHADE>(P, Sc, shadow, B.out[f], nullptr, stk, keys, lane, slot);
 }
 
 // ================================================================ N1: octreeRaySkip

@@ -32,7 +32,7 @@ SYMBOLS = (
     "rto_upload_leaf_triangles", "rto_build_leaf_triangles", "rto_download_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_debug_sort_violations", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
     "rto_comm_unique_id", "rto_comm_create", "rto_comm_create_all", "rto_comm_destroy", "rto_comm_last_error", "rto_comm_submit",
-    "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_stream", "rto_comm_debug_rehearse",
+    "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_render_triangles_batch_device",
 )
 COMM_ID_BYTES = 128
 RESIDENT_OCTREE, RESIDENT_TRIANGLES, RESIDENT_TRIANGLES_SHADOW = 0, 1, 2
@@ -149,6 +149,7 @@ def load():
     L.rto_comm_render_resident_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Frame), C.c_int]
     L.rto_comm_flush.argtypes = [vp]
     L.rto_comm_debug_rehearse.argtypes = [vp, C.c_int, C.c_int]
+    L.rto_render_triangles_batch_device.argtypes = [vp, C.POINTER(Frame), C.c_int, C.POINTER(Partition), C.c_int, C.c_int, vp, C.c_size_t, vp]
     L.rto_comm_stream.argtypes = [vp]
     L.rto_comm_stream.restype = vp
     _lib = L
@@ -327,6 +328,13 @@ class Context:
     def render_batch_device(self, frames_arr, d_out: int, frame_stride_bytes: int, part: Partition | None, shade: bool, stream: int = 0):
         self._check(self._L.rto_render_batch_device(self._h, frames_arr, len(frames_arr), C.byref(part) if part else None, 1 if shade else 0,
                                                     C.c_void_p(d_out), frame_stride_bytes, C.c_void_p(stream) if stream else None))
+
+    def render_triangles_batch_device(self, frames_arr, d_out: int, frame_stride_bytes: int, shadow: bool = True, part: Partition | None = None,
+                                      shade: bool = False, stream: int = 0):
+        """Config 5's frames, up to 8 per kernel launch (rto_render_triangles_batch_device)."""
+        self._check(self._L.rto_render_triangles_batch_device(self._h, frames_arr, len(frames_arr), C.byref(part) if part else None,
+                                                              1 if shadow else 0, 1 if shade else 0, C.c_void_p(d_out), frame_stride_bytes,
+                                                              C.c_void_p(stream) if stream else None))
 
     def assemble_batch_all_device(self, frames_arr, part: Partition, d_gathered: int, shade: bool, d_frames: int, frame_stride_bytes: int,
                                   stream: int = 0):

@@ -713,6 +713,18 @@ def test_several_frames_in_one_launch(ctx, orc, scenes):
             assert one.cpu().numpy().tobytes() == shade[i].cpu().numpy().tobytes(), f"batched part, frame {i}"
         assert int((owner == 1).sum()) == rows
         assert ctx.debug_sort_violations() == 0
+        # config 5's kernel takes batches the same way (rto_render_triangles_batch_device): 5 cameras, with and without shadow
+        wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
+        ctx.build_leaf_triangles(s.grid.data)
+        arr5 = hip.Context.frame_array(frames[:5])
+        for shadow in (True, False):
+            out[:5].fill_(7.0)
+            torch.cuda.synchronize()
+            ctx.render_triangles_batch_device(arr5, out.data_ptr(), out.stride(0) * 4, shadow, None, False, stream.cuda_stream)
+            torch.cuda.synchronize()
+            for i in range(5):
+                want, _ = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, cams[i].get_view(), cams[i].get_pos(), W / H, 45.0, W, H, shadow=shadow)
+                assert_bit_exact(out[i].cpu().numpy(), want, f"batched triangle frame {i}, shadow {shadow}")
     finally:
         ctx.set_kernel(rto.KERNEL_AUTO)
         ctx.set_launch_order(1, 8)
@@ -1359,6 +1371,17 @@ def test_comm_one_rank_through_the_c_abi(ctx, orc, scenes):
                 got[owner == r] = a[owner == r]
                 assert_bit_exact(b[owner == r], wants[3][owner == r], f"rehearsal world {world} rank {r}, second frame of the batch")
             assert_bit_exact(got, wants[0], f"rehearsal world {world}: the ranks' bands together")
+        # the same for config 5's path: the parts of two frames in one launch of the triangle kernel
+        ctx.build_leaf_triangles(s.grid.data)
+        wtris = [orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, cams[i].get_view(), cams[i].get_pos(), W / H, 45.0, W, H, shadow=True)[0] for i in (1, 2)]
+        owner = (np.arange(H) // 16) % 3
+        for r in range(3):
+            comm.debug_rehearse(3, r)
+            two = torch.full((2, H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+            comm.submit(hip.Context.frame_array([frames[1], frames[2]]), two.data_ptr(), two.stride(0) * 4, hip.RESIDENT_TRIANGLES_SHADOW)
+            comm.flush()
+            for q in range(2):
+                assert_bit_exact(two[q].cpu().numpy()[owner == r], wtris[q][owner == r], f"triangle rehearsal rank {r} of 3, frame {q}")
         comm.debug_rehearse(0)
         with pytest.raises(rto.RtoError):
             comm.debug_rehearse(4, 4)
