@@ -760,7 +760,7 @@ def main(argv=None):
                 print(f"bench: one-frame-per-launch leg skipped ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
             if one_ms:
                 result["one_frame_per_launch"] = {"ms_per_frame": round(one_ms, 5), "Mrays_per_s": round(rays / one_ms / 1e3, 1), "frames": reps1 * n1,
-                                                  "what": "rto_render_device, one kernel launch per frame, replayed from a HIP graph: a frame's kernel is as long as its "
+                                                  "what": "one kernel launch per frame (rto_render_device / rto_render_triangles_device), replayed from a HIP graph: a frame's kernel is as long as its "
                                                           "deepest tile's chain of dependent node visits; `value` launches several frames together instead"}
         if args.rehearse_world > 1:
             result["rehearsal"] = {"as_rank_0_of": args.rehearse_world,

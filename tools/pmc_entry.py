@@ -23,7 +23,7 @@ def main():
     summary_path, config, kernel, order, source = sys.argv[1:6]
     fpl = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     s = json.load(open(summary_path))
-    name = next(k for k in s["counters_per_launch"] if (kernel + "<0") in k or (kernel + "(") in k)     # exact kernel, colour mode
+    name = next(k for k in s["counters_per_launch"] if (kernel + "<0") in k or (kernel + "<false>") in k or (kernel + "(") in k)     # exact kernel, colour mode
     c = s["counters_per_launch"][name]
     entry = {
         "config": config, "kernel": kernel, "order": order, "kernel_symbol": name, "frames_per_launch": fpl,
