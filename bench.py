@@ -411,6 +411,24 @@ def main(argv=None):
                 renderer.render(frame)
             torch.cuda.synchronize()
             ramp_frames += 20
+    primed = 0
+    if use_comm:
+        # untimed, disclosed: full batches through the pipe before the warm-up -- RCCL opens its connections at the first
+        # send/recv, the buffers take the size of a full batch, every GPU reaches its working clock (all ranks: same count)
+        t_end = time.perf_counter() + max(args.ramp_ms, 100.0) * 1e-3
+        ptr0 = comm_frames.data_ptr() if rank == 0 else 0
+        rounds = 0
+        while True:
+            for _ in range(4):
+                comm.submit(comm_arr, ptr0, H * W * 16, comm_mode)
+            comm.flush()
+            rounds += 1
+            go_on = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], dtype=torch.float64)
+            if dist is not None:
+                dist.all_reduce(go_on, op=dist.ReduceOp.MIN)          # every rank submits the same number of collectives
+            if float(go_on.item()) == 0.0:
+                break
+        primed = rounds * 4 * fpg
     run_frames(args.warmup)
     sync_all()
 
@@ -727,7 +745,8 @@ def main(argv=None):
                                                           f"{f', {npipe} such pipelines on {npipe} HIP streams take the batches in turn' if npipe > 1 else ''})"),
                 "kernel": args.kernel,
                 "clock_ramp": (f"{ramp_frames} untimed frames of the same workload ({args.ramp_ms:.0f} ms) before the {args.warmup} warm-up frames, "
-                               "so that a cold GPU has reached its working clock") if ramp_frames else "none",
+                               "so that a cold GPU has reached its working clock") if ramp_frames else
+                              (f"{primed} untimed frames in full batches through the pipe before the {args.warmup} warm-up frames (RCCL connections, buffers, clocks)" if primed else "none"),
             },
             "hit_rays": stats["hits"], "capped_rays": stats["capped"],
             "verified_against_oracle": verified,
