@@ -87,6 +87,7 @@ def test_fuzz_random_scenes_and_cameras(ctx, orc, seed):
     ext = np.float32(max(g.dims)) * g.voxel_size
     centre = g.min + 0.5 * np.array(g.dims, np.float32) * g.voxel_size
     tris = off = None
+    shots = []
     for shot in range(3):
         kind = ("outside", "inside", "grazing")[shot]
         radius = float(ext * {"outside": rng.uniform(1.2, 4.0), "inside": rng.uniform(0.05, 0.45), "grazing": rng.uniform(0.7, 1.0)}[kind])
@@ -114,12 +115,27 @@ def test_fuzz_random_scenes_and_cameras(ctx, orc, seed):
             assert gt.tobytes() == np.ascontiguousarray(tris, np.float32).reshape(-1, 12).tobytes(), f"seed {seed}: triangles"
         if len(tris):
             wt, wst = orc.render_triangles(s.nodes, tris, off, s.min, s.voxel, view, pos, aspect, fov, W, H, shadow=True)
-            for kname, kernel in (("packed", rto.KERNEL_AUTO), ("generic", rto.KERNEL_GENERIC)):
+            for kname, kernel in (("lean", rto.KERNEL_AUTO), ("packed", rto.KERNEL_PACKED_V3), ("generic", rto.KERNEL_GENERIC)):
                 ctx.set_kernel(kernel)
                 got, gs = ctx.render_triangles_host(f, shadow=True, stats=True)
                 assert_bit_exact(got, wt, f"seed {seed} {kind} triangles {kname}")
                 assert (gs["pops"], gs["hits"]) == (wst["pops"], wst["hits"]), f"seed {seed} {kind} triangles {kname}"
+            shots.append((f, W, H, want, wt))
     ctx.set_kernel(rto.KERNEL_AUTO)
+    # the same frames through the several-frames-per-launch kernels (frames of one launch share width and height)
+    torch = pytest.importorskip("torch")
+    for f, W, H, want, wt in shots:
+        arr = hip.Context.frame_array([f, f, f])
+        out = torch.full((3, H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+        ctx.render_batch_device(arr, out.data_ptr(), out.stride(0) * 4, None, False, 0)
+        torch.cuda.synchronize()
+        for i in range(3):
+            assert_bit_exact(out[i].cpu().numpy(), want, f"seed {seed} batched frame {i}")
+        out.fill_(7.0)
+        ctx.render_triangles_batch_device(arr, out.data_ptr(), out.stride(0) * 4, True, None, False, 0)
+        torch.cuda.synchronize()
+        for i in range(3):
+            assert_bit_exact(out[i].cpu().numpy(), wt, f"seed {seed} batched triangle frame {i}")
 
 
 @pytest.mark.parametrize("kname,kernel", KERNELS)
