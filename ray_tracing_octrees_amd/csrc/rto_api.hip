@@ -578,9 +578,6 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     }
     RTO_HIP(c, hipEventElapsedTime(&c->buildUploadMs, e0, e1));
     RTO_HIP(c, hipEventElapsedTime(&c->buildMs, e1, e2));
-    if (std::getenv("RTO_DEBUG_BUILD"))
-        std::fprintf(stderr, "rto_build_octree: path %s, solid box lo (%d %d %d) hi (%d %d %d), nodes %lld internal %lld\n", haveBox ? "morton" : "levels",
-                     box[0], box[1], box[2], box[3], box[4], box[5], (long long)total, (long long)internal);
 
     c->numNodes = total; c->visibleNodes = total; c->numInternal = internal;
     c->rootSize = 1 << R; c->depth = R;

@@ -959,12 +959,6 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     int trips = 0;                                                      // wave-uniform trip count = this tile's cost
     while (alive) {
         trips++;
-#if defined(RTO_PRIO)
-        // A/B build: waves still running after many trips are the frame's critical path: let them win VALU arbitration
-        if (trips == RTO_PRIO) __builtin_amdgcn_s_setprio(1);
-        else if (trips == 2 * RTO_PRIO) __builtin_amdgcn_s_setprio(2);
-        else if (trips == 3 * RTO_PRIO) __builtin_amdgcn_s_setprio(3);
-#endif
         const uint2 d = *reinterpret_cast<const uint2*>(descBytes + (cur << 3));
         // the resume entry depends only on lvlPending: fetch it under the descriptor load and the slab math
         const int Lb = __builtin_ctz(lvlPending | sentinel);
@@ -2335,13 +2329,16 @@ __device__ __forceinline__ int mb_combine(const int s[8], int* mixedChildren) {
     return (mixed || (any0 && any1)) ? 2 : (any1 ? 1 : 0);
 }
 
-// One block per run of kMbRun 32^3-voxel bricks along x (a wave instruction then reads 128 contiguous bytes of a voxel
+// One block per run of kMbRun 32^3-voxel bricks along x (a wave instruction then reads 32 * kMbRun contiguous bytes of a voxel
 // row instead of 32: the voxels are x-fastest and a single brick's rows are 32 bytes).  B = min(5, R) levels; a grid
 // smaller than a brick has one brick that reaches above the root: cells beyond the root's domain are not written.  LDS
 // holds each brick's levels in LOCAL MORTON order, so the 8 children of a cell are 8 consecutive bytes and the write-out is
 // a straight 16-byte copy.  blockBox: per block, the box (level-1 cell precision, voxel units) of its cells that hold
 // FILLED voxels.
-constexpr int kMbRun = 4;
+#ifndef RTO_MB_RUN
+#define RTO_MB_RUN 2
+#endif
+constexpr int kMbRun = RTO_MB_RUN;
 constexpr int kMbBrickLds = 4096 + 512 + 64 + 16 + 16;       // levels 1..5 of one brick, 16-byte aligned each
 
 // 0x80 in every byte of w that equals 1 (exact: no carries between bytes)
