@@ -88,9 +88,10 @@ def parse_args(argv=None):
                     help="N>1: independent submit/flush pipelines, each on its own HIP stream, that take the batches in turn; 1 = a single pipeline")
     ap.add_argument("--frames-per-gather", type=int, default=8,
                     help="N>1: consecutive frames whose parts travel in ONE gather (fewer, larger collectives); 1 = one gather per frame")
-    ap.add_argument("--graph-frames", type=int, default=50,
-                    help="N=1: capture this many consecutive frames (one kernel each, strictly one after the other) in a HIP "
-                         "graph and replay it; 0 = plain stream launches with a HIP event pair around every kernel")
+    ap.add_argument("--graph-frames", type=int, default=None,
+                    help="N=1: capture this many consecutive frames in a HIP graph and replay it; 0 = plain stream launches with a "
+                         "HIP event pair around every kernel.  Default: 48 when --steps >= 200, else 0 (with several frames per "
+                         "launch a short run gains nothing from a graph and pays its first launch)")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="N=1 only: render consecutive frames on this many HIP streams (own framebuffers); 1 = strictly one frame at a time")
     ap.add_argument("--ramp-ms", type=float, default=300.0,
@@ -263,6 +264,8 @@ def pmc_entry(config: str, kernel_name: str, order: str):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.graph_frames is None:
+        args.graph_frames = 48 if args.steps >= 200 else 0
     if args.rehearse_world > 1:
         args.no_verify, args.cpu_frames, args.force_comm = True, 0, True     # the assembled frames hold one rank's bands only
     world_env = os.environ.get("WORLD_SIZE")
@@ -736,7 +739,7 @@ def main(argv=None):
             "config": {
                 "workload": f"BASELINE config {args.config}: {what}, octree to min-leaf 1 ({info.num_nodes} nodes), "
                             f"{W}x{H} primary rays{', Marching-Cubes leaf triangles + 1 shadow ray per hit' if triangles else ''}, {camtxt}, fov 45",
-                "parallelism": (("1 GPU" + (f", {fpl} consecutive frames per kernel launch (rto_render_batch_device)" if fpl > 1 else "") + (f", launches replayed from a HIP graph of {gframes} consecutive frames" if use_graph else ", plain stream launches")) if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else
+                "parallelism": (("1 GPU" + (f", {fpl} consecutive frames per kernel launch ({'rto_render_triangles_batch_device' if triangles else 'rto_render_batch_device'})" if fpl > 1 else "") + (f", launches replayed from a HIP graph of {gframes} consecutive frames" if use_graph else ", plain stream launches")) if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else
                                (f"screen split over {world} GPUs, {args.band_rows}-row bands round-robin, rto_comm_submit: ONE grouped RCCL send/recv per {'frame' if fpg == 1 else f'{fpg} frames'} "
                                 f"into rank 0 (4-byte Lambert term per pixel), batch k's gather overlaps batch k+1's render" if use_comm else "") + ("" if use_comm else f"screen split over {world} GPUs, {args.band_rows}-row bands "
                                                           f"round-robin, 1 RCCL gather per {'frame' if fpg == 1 else f'{fpg} frames'} ({'4-byte Lambert term' if args.payload == 'shade' else 'RGBA32F'} per pixel"
