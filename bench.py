@@ -559,7 +559,9 @@ def main(argv=None):
         lat = (time.perf_counter() - t_l) / n_lat
         if dist is not None:
             lat = max_over_ranks(lat)
-        latency = {"ms_per_frame": round(lat * 1e3, 5), "frames": n_lat,
+        sent, whole = comm.debug_last_payload()
+        latency = {"payload_bytes_per_frame_and_rank": sent * 4, "payload_bytes_whole_rows": whole * 4,
+                   "ms_per_frame": round(lat * 1e3, 5), "frames": n_lat,
                    "what": "rto_comm_submit of ONE frame + rto_comm_flush per frame: render part -> grouped send/recv -> assemble, host waits for each frame"}
     if rank == 0:
         kernel_name = KERNEL_NAMES[args.kernel] if info.canonical else "k_trace_generic"

@@ -238,6 +238,9 @@ int  rto_comm_flush(rto_comm* comm);              /* waits until every submitted
 /* Developer aid: a ONE-rank communicator renders, ships and assembles as rank as_rank of as_world GPUs (every per-rank cost
  * of an N-GPU split except the other GPUs' traffic); the assembled frames hold that rank's bands only.  as_world = 0: off. */
 int  rto_comm_debug_rehearse(rto_comm* comm, int as_world, int as_rank);
+/* Developer aid: floats this rank shipped for the batch submitted last -- only the columns of the geometry's screen rectangle
+ * travel, rank 0 paints the background itself -- and what whole rows would have been. */
+int  rto_comm_debug_last_payload(const rto_comm* comm, int64_t* packed_floats, int64_t* full_floats);
 void* rto_comm_stream(rto_comm* comm);            /* hipStream_t the gathers and (rank 0) the assembled frames are ordered on */
 
 /* ---- N2: leaf triangles + shadow ray (BASELINE config 5) -------------------------

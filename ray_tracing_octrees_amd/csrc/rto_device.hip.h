@@ -2957,4 +2957,39 @@ __global__ void k_assemble_shade(const float* __restrict__ gathered, char* __res
     for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < W; x += gridDim.x * blockDim.x) store_pixel(dst + x, shade_color(src[x]));
 }
 
+// The multi-GPU payload without its background: outside the columns of the geometry's screen rectangle every pixel of a
+// frame is a miss by construction (the same rectangle the traversal kernels use), so a rank ships only the window
+// [x0, x0 + w) of every row of its part and rank 0 paints the rest itself -- about a third of the bytes on the links at
+// config 2.  CropInfo: the windows of the frames of one batch and where each frame starts inside a rank's packed part.
+constexpr int kMaxCropFrames = 32;
+struct CropInfo {
+    int n;
+    int x0[kMaxCropFrames], w[kMaxCropFrames];
+    long long off[kMaxCropFrames];
+};
+
+// [frame][rows][W] -> [frame: rows x w_i], one block row per part row, blockIdx.z = frame
+__global__ void k_pack_columns(const float* __restrict__ src, float* __restrict__ dst, CropInfo C, size_t srcFrameStride, int W) {
+    const int i = blockIdx.z, y = blockIdx.y;
+    const int w = C.w[i];
+    const float* s = src + (size_t)i * srcFrameStride + (size_t)y * W + C.x0[i];
+    float* d = dst + C.off[i] + (size_t)y * w;
+    for (int x = threadIdx.x; x < w; x += blockDim.x) d[x] = s[x];
+}
+
+// k_assemble_shade over packed parts: inside the window the colour of the shipped Lambert term, outside it the background
+__global__ void k_assemble_shade_crop(const float* __restrict__ gathered, char* __restrict__ frames, CropInfo C, size_t dstFrameStride,
+                                      int W, int H, int numParts, int bandRows, size_t partStride) {
+    const int i = blockIdx.z, y = blockIdx.y;
+    const int gband = y / bandRows, r = y - gband * bandRows;
+    const int part = gband % numParts, band = gband / numParts;
+    const int x0 = C.x0[i], w = C.w[i];
+    const float* src = gathered + (size_t)part * partStride + C.off[i] + ((size_t)band * bandRows + r) * w;
+    float4* dst = reinterpret_cast<float4*>(frames + (size_t)i * dstFrameStride) + (size_t)y * W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        const unsigned rel = (unsigned)(x - x0);
+        store_pixel(dst + x, shade_color(rel < (unsigned)w ? src[rel] : kShadeMiss));
+    }
+}
+
 }  // namespace rto

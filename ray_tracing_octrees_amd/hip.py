@@ -32,7 +32,7 @@ SYMBOLS = (
     "rto_upload_leaf_triangles", "rto_build_leaf_triangles", "rto_download_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_debug_sort_violations", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
     "rto_comm_unique_id", "rto_comm_create", "rto_comm_create_all", "rto_comm_destroy", "rto_comm_last_error", "rto_comm_submit",
-    "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_render_triangles_batch_device",
+    "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_comm_debug_last_payload", "rto_render_triangles_batch_device",
 )
 COMM_ID_BYTES = 128
 RESIDENT_OCTREE, RESIDENT_TRIANGLES, RESIDENT_TRIANGLES_SHADOW = 0, 1, 2
@@ -149,6 +149,7 @@ def load():
     L.rto_comm_render_resident_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Frame), C.c_int]
     L.rto_comm_flush.argtypes = [vp]
     L.rto_comm_debug_rehearse.argtypes = [vp, C.c_int, C.c_int]
+    L.rto_comm_debug_last_payload.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.rto_render_triangles_batch_device.argtypes = [vp, C.POINTER(Frame), C.c_int, C.POINTER(Partition), C.c_int, C.c_int, vp, C.c_size_t, vp]
     L.rto_comm_stream.argtypes = [vp]
     L.rto_comm_stream.restype = vp
@@ -495,6 +496,12 @@ class Comm:
 
     def flush(self):
         self._check(self._L.rto_comm_flush(self._h))
+
+    def debug_last_payload(self):
+        """(floats shipped for the last batch, floats whole rows would have been) for this rank."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._L.rto_comm_debug_last_payload(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def debug_rehearse(self, as_world: int, as_rank: int = 0):
         """One-rank communicator only: split frames as rank `as_rank` of `as_world` GPUs (0 switches it off)."""

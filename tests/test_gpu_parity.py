@@ -1356,7 +1356,18 @@ def test_comm_one_rank_through_the_c_abi(ctx, orc, scenes):
         for k in range(6):
             for i in range(4):
                 assert_bit_exact(out[k, i].cpu().numpy(), wants[i], f"comm batch {k} frame {i}")
+        sent, whole = comm.debug_last_payload()
+        assert 0 < sent < whole, "only the columns of the geometry's rectangle travel"
         one = torch.full((H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+        # a camera that looks away from the scene: nothing but background, a token window travels
+        away = orc.Camera(0.5, 0.7, 1.8)
+        away.set_target(40.0, 0.0, 40.0)
+        fa = rto.make_frame(away.get_view(), away.get_pos(), W / H, 45.0, W, H)
+        wa = oracle_frame(orc, s, away.get_view(), away.get_pos(), W, H)[0]
+        comm.submit(hip.Context.frame_array([fa, frames[1]]), out[0].data_ptr(), out.stride(1) * 4)
+        comm.flush()
+        assert_bit_exact(out[0, 0].cpu().numpy(), wa, "comm: frame without geometry")
+        assert_bit_exact(out[0, 1].cpu().numpy(), wants[1], "comm: frame after the empty one")
         for i in (2, 0, 3):                                             # batch size changes: buffers are re-made after a drain
             comm.submit(hip.Context.frame_array([frames[i]]), one.data_ptr(), one.stride(0) * 4 * H)
             comm.flush()
