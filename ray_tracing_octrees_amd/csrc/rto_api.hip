@@ -46,6 +46,7 @@ struct rto_context {
     int* d_blockBase = nullptr;
     int64_t* d_visibleCount = nullptr;
     rto_node* d_compact = nullptr;
+    bool compactValid = false;       // d_compact / d_remap hold the compaction of the CURRENT visibility flags (made on demand)
     int64_t visibleNodes = 0;
 
     // temporal launch order (packed kernel): an earlier frame's per-tile cost -> this frame's slot->tile table.
@@ -187,7 +188,7 @@ int rto_create(int device_ordinal, rto_context** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipMalloc(&c->d_counters, sizeof(Counters))) != hipSuccess ||
-        (e = hipMalloc(&c->d_visibleCount, sizeof(int64_t))) != hipSuccess ||
+        (e = hipMalloc(&c->d_visibleCount, 2 * sizeof(int64_t))) != hipSuccess ||     // [0] count of visible nodes, [1] the root's flag
         (e = hipMalloc(&c->d_sortViolations, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_sortViolations, 0, sizeof(int))) != hipSuccess) {
         std::string msg = std::string("rto_create: ") + hipGetErrorString(e);
         rto_destroy(c);
@@ -700,6 +701,25 @@ int rto_set_kernel(rto_context* c, int kernel) {
 
 // ---------------------------------------------------------------- frustum culling
 // One frustum update for the given planes (LEFT, RIGHT, TOP, BOTTOM, NEAR, FAR; normalised) and margin.
+static bool stream_is_capturing(hipStream_t s);
+
+// remap + compaction of the current visibility flags into d_compact, on stream s (ordered behind the frustum update, which
+// ran on c->stream and was waited for)
+static int ensure_compact(rto_context* c, hipStream_t s) {
+    if (!c->culling || c->compactValid) return RTO_OK;
+    if (stream_is_capturing(s))
+        return fail(c, RTO_E_UNSUPPORTED, "render: the compacted node array of the last frustum update is made on first use; "
+                                          "render one frame with this kernel before hipStreamBeginCapture");
+    const int64_t n = c->numNodes;
+    const int nb = (int)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_cull_remap, dim3(nb), dim3(kBlock), 0, s, c->d_vis, n, c->d_blockBase, c->d_remap);
+    hipLaunchKernelGGL(k_cull_compact, dim3(nb), dim3(kBlock), 0, s, c->d_nodes, n, c->d_remap, c->d_compact);
+    RTO_HIP(c, hipGetLastError());
+    RTO_HIP(c, hipStreamSynchronize(s));          // later users may sit on other streams
+    c->compactValid = true;
+    return RTO_OK;
+}
+
 static int update_frustum_planes(rto_context* c, const float planes[24], float margin) {
     const int64_t n = c->numNodes;
     const int nb = (int)((n + kBlock - 1) / kBlock);
@@ -716,20 +736,20 @@ static int update_frustum_planes(rto_context* c, const float planes[24], float m
     std::memcpy(C.gridMin, c->gridMin, sizeof C.gridMin);
     C.voxelSize = c->voxelSize;
     C.margin = margin;
-    hipLaunchKernelGGL(k_cull_flags, dim3(nb), dim3(kBlock), 0, c->stream, C, c->d_nodes, n, c->d_vis, c->d_blockCount);
+    hipLaunchKernelGGL(k_cull_flags, dim3(nb), dim3(kBlock), 0, c->stream, C, c->d_nodes, n, c->d_vis, c->d_blockCount, c->d_visibleCount + 1);
     hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, c->stream, c->d_blockCount, nb, c->d_blockBase, c->d_visibleCount);
-    hipLaunchKernelGGL(k_cull_remap, dim3(nb), dim3(kBlock), 0, c->stream, c->d_vis, n, c->d_blockBase, c->d_remap);
-    hipLaunchKernelGGL(k_cull_compact, dim3(nb), dim3(kBlock), 0, c->stream, c->d_nodes, n, c->d_remap, c->d_compact);
+    // The compacted array itself (S/RT:765-802: remap + copy, 2 x 22 MB of traffic at config 2) is made when somebody asks for
+    // it -- rto_download_visible_nodes, the generic kernel, the culled-root edge: ensure_compact().  The packed kernels render
+    // from the visibility bits in the descriptors, which is all a frustum update has to refresh for them.
+    c->compactValid = false;
     if (c->canonical && nbInt > 0)
         hipLaunchKernelGGL(k_desc_vismask, dim3(nbInt), dim3(kBlock), 0, c->stream, c->d_vis, c->d_descFirstChild, c->numInternal, c->d_desc);
     RTO_HIP(c, hipGetLastError());
-    int64_t visible = 0;
-    uint8_t rootVis = 0;
-    RTO_HIP(c, hipMemcpyAsync(&visible, c->d_visibleCount, sizeof visible, hipMemcpyDeviceToHost, c->stream));
-    RTO_HIP(c, hipMemcpyAsync(&rootVis, c->d_vis, 1, hipMemcpyDeviceToHost, c->stream));
+    int64_t back[2] = { 0, 0 };                     // visible nodes, the root's flag: one read-back
+    RTO_HIP(c, hipMemcpyAsync(back, c->d_visibleCount, sizeof back, hipMemcpyDeviceToHost, c->stream));
     RTO_HIP(c, hipStreamSynchronize(c->stream));
-    c->visibleNodes = visible;
-    c->rootVisible = rootVis ? 1 : 0;
+    c->visibleNodes = back[0];
+    c->rootVisible = back[1] ? 1 : 0;
     c->culling = true;
     return RTO_OK;
 }
@@ -776,6 +796,8 @@ int rto_download_visible_nodes(rto_context* c, rto_node* out, int64_t capacity, 
     *count = c->visibleNodes;
     if (!out) return RTO_OK;
     if (capacity < c->visibleNodes) return fail(c, RTO_E_INVALID, "rto_download_visible_nodes: capacity too small");
+    const int rcCompact = ensure_compact(c, c->stream);
+    if (rcCompact != RTO_OK) return rcCompact;
     const rto_node* src = c->culling ? c->d_compact : c->d_nodes;
     RTO_HIP(c, hipStreamSynchronize(c->stream));
     RTO_HIP(c, hipMemcpy(out, src, (size_t)c->visibleNodes * sizeof(rto_node), hipMemcpyDeviceToHost));
@@ -1131,6 +1153,8 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             }
         }
     } else {
+        const int rcCompact = ensure_compact(c, s);
+        if (rcCompact != RTO_OK) return rcCompact;
         const rto_node* nodes = c->culling ? c->d_compact : c->d_nodes;
         RenderParams Q = P;
         if (c->culling && c->visibleNodes == 0) Q.rootVisible = 0;   // empty SSBO: nothing to traverse

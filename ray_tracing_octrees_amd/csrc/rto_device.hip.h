@@ -1204,13 +1204,14 @@ __device__ __forceinline__ bool node_visible(const CullParams& C, int x, int y, 
 
 // one thread per node: visibility flag + per-block visible count
 __global__ __launch_bounds__(kBlock) void k_cull_flags(CullParams C, const rto_node* __restrict__ nodes, int64_t n,
-                                                        uint8_t* __restrict__ vis, int* __restrict__ blockCount) {
+                                                        uint8_t* __restrict__ vis, int* __restrict__ blockCount, int64_t* __restrict__ rootVisible) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     bool v = false;
     if (i < n) {
         const rto_node* nd = nodes + i;
         v = node_visible(C, nd->x, nd->y, nd->z, nd->size);
         vis[i] = v ? 1 : 0;
+        if (i == 0) *rootVisible = v ? 1 : 0;          // read back together with the count of visible nodes
     }
     int cnt = __syncthreads_count(v ? 1 : 0);
     if (threadIdx.x == 0) blockCount[blockIdx.x] = cnt;
