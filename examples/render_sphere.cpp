@@ -40,11 +40,20 @@ int main(int argc, char** argv) {
     for (int i = 0; i < frames; i++) bvhRayTracer.renderSceneCompute(camera, W, H, aspect, 45.0f);
     bvhRayTracer.finish();                                      // the frames stay on the GPU, like the reference's texture
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / frames;
+    // what 453-skeleton/main.cpp:1357-1363 does while the camera moves: frustum update + frame, every frame
+    bvhRayTracer.setFrustumCullingEnabled(true);
+    bvhRayTracer.renderSceneComputeWithCulling(camera, W, H, aspect, 45.0f, true);
+    bvhRayTracer.finish();
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int i = 0; i < frames; i++) bvhRayTracer.renderSceneComputeWithCulling(camera, W, H, aspect, 45.0f, true);
+    bvhRayTracer.finish();
+    const double sc = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() / frames;
     const std::vector<float>& fb = bvhRayTracer.framebuffer();
     size_t lit = 0;
     for (size_t p = 0; p < fb.size(); p += 4) lit += fb[p] != 0.0f;
     std::printf("%d^3 sphere, %d nodes, %dx%d: %zu lit pixels, %.4f ms per renderSceneCompute (frame left on the GPU)\n",
                 dim, bvhRayTracer.numNodes(), W, H, lit, s * 1e3);
+    std::printf("with a frustum update before every frame (renderSceneComputeWithCulling, updateFrustum = true): %.4f ms\n", sc * 1e3);
     if (out) {
         if (FILE* f = std::fopen(out, "wb")) {
             std::fprintf(f, "P6\n%d %d\n255\n", W, H);
