@@ -47,6 +47,7 @@ struct rto_context {
     int64_t* d_visibleCount = nullptr;
     rto_node* d_compact = nullptr;
     bool compactValid = false;       // d_compact / d_remap hold the compaction of the CURRENT visibility flags (made on demand)
+    bool otherStreams = false;       // a frame was launched on a stream other than c->stream since the last device-wide wait
     int64_t visibleNodes = 0;
 
     // temporal launch order (packed kernel): an earlier frame's per-tile cost -> this frame's slot->tile table.
@@ -759,8 +760,9 @@ int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, floa
     if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_update_frustum: no octree uploaded");
     RTO_HIP(c, hipSetDevice(c->device));
     // the visibility masks live in the descriptors every traversal kernel reads: frames still in flight on caller
-    // streams must be done before they change, and the change must be complete before this returns
-    RTO_HIP(c, hipDeviceSynchronize());
+    // streams must be done before they change, and the change must be complete before this returns.  Frames on the
+    // context's own stream (rto_render_resident: what RayTracerBVH uses) are ordered before the update by the stream itself.
+    if (c->otherStreams) { RTO_HIP(c, hipDeviceSynchronize()); c->otherStreams = false; }
     if (!enable) {
         const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
         if (c->culling && c->canonical && nbInt > 0) {
@@ -1098,6 +1100,7 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
 
 template <int MODE>
 static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hipStream_t s) {
+    if (s != c->stream) c->otherStreams = true;
     const int tiles = P.tilesX * P.tilesY;
     if (tiles <= 0) return RTO_OK;
     const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
@@ -1218,6 +1221,7 @@ static int build_triangle_records(rto_context* c, hipStream_t s) {
 // one in use (generic array, another kernel selected, the culled-root edge).  MODE: kModeColor or kModeShade.
 template <int MODE>
 static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, float4* const* outs, hipStream_t s) {
+    if (s != c->stream) c->otherStreams = true;
     const bool packed = c->kernelMode >= RTO_KERNEL_PACKED || (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
     const bool lean = packed && c->canonical && (c->kernelMode == RTO_KERNEL_AUTO || c->kernelMode == RTO_KERNEL_PACKED) &&
                       !(c->culling && !c->rootVisible && c->visibleNodes > 0);
@@ -1587,6 +1591,7 @@ int rto_download_leaf_triangles(rto_context* c, float* tris, int64_t tri_capacit
 
 static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partition* p, int shadow, float4* d_out, hipStream_t s,
                             bool count, bool shadeOut = false) {
+    if (s != c->stream) c->otherStreams = true;
     if (!c->d_triOffset) return fail(c, RTO_E_NO_OCTREE, "render_triangles: no leaf triangles uploaded");
     if (c->culling) return fail(c, RTO_E_UNSUPPORTED, "render_triangles: not available while frustum culling is active");
     RenderParams P;
@@ -1639,6 +1644,7 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
 // lean triangle kernel is not the one in use.
 static int launch_triangles_batch(rto_context* c, const rto_frame* frames, int n, const rto_partition* p, int shadow, float4* const* outs,
                                   hipStream_t s, bool shadeOut) {
+    if (s != c->stream) c->otherStreams = true;
     const bool lean = c->d_triRec && c->canonical && c->numInternal > 0 && !c->culling &&
                       (c->kernelMode == RTO_KERNEL_AUTO || c->kernelMode == RTO_KERNEL_PACKED);
     if (!lean || n == 1) {

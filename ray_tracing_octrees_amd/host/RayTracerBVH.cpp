@@ -28,6 +28,7 @@ struct HipApi {
     decltype(&rto_render_resident) render_resident = nullptr;
     decltype(&rto_download_resident) download_resident = nullptr;
     decltype(&rto_synchronize) synchronize = nullptr;
+    decltype(&rto_timing_begin) timing_begin = nullptr;
     decltype(&rto_render_triangles_host) render_triangles_host = nullptr;
     decltype(&rto_comm_create_all) comm_create_all = nullptr;
     decltype(&rto_comm_destroy) comm_destroy = nullptr;
@@ -72,6 +73,7 @@ struct HipApi {
         render_resident = reinterpret_cast<decltype(render_resident)>(sym("rto_render_resident"));
         download_resident = reinterpret_cast<decltype(download_resident)>(sym("rto_download_resident"));
         synchronize = reinterpret_cast<decltype(synchronize)>(sym("rto_synchronize"));
+        timing_begin = reinterpret_cast<decltype(timing_begin)>(sym("rto_timing_begin"));
         render_triangles_host = reinterpret_cast<decltype(render_triangles_host)>(sym("rto_render_triangles_host"));
         comm_create_all = reinterpret_cast<decltype(comm_create_all)>(sym("rto_comm_create_all"));
         comm_destroy = reinterpret_cast<decltype(comm_destroy)>(sym("rto_comm_destroy"));
@@ -201,6 +203,7 @@ void RayTracerBVH::ensureComputeInitialized() {
             return;
         }
         m_ctxs.push_back(c);
+        api().timing_begin(c, -1);                     // nobody reads kernel timings through this class: no event pair per launch
     }
     m_ctx = m_ctxs[0];
     if (m_numDevices > 1) {
