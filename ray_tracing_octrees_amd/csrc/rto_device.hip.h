@@ -1676,6 +1676,10 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     const Geo G = geo_of(P);
     float lnx = P.lightNeg[0], lny = P.lightNeg[1], lnz = P.lightNeg[2];
     asm volatile("" : "+s"(lnx), "+s"(lny), "+s"(lnz));                    // see geo_of
+    // every shadow ray has this direction: its reciprocal and signs are computed once per wave, not once per hit
+    const float lix = 1.0f / lnx, liy = 1.0f / lny, liz = 1.0f / lnz;
+    const unsigned lsx = (unsigned)((int)__float_as_uint(lix) >> 31), lsy = (unsigned)((int)__float_as_uint(liy) >> 31),
+                   lsz = (unsigned)((int)__float_as_uint(liz) >> 31);
 
     float shade = kShadeMiss;
     int stepsTotal = 0;            // pops of the finished rays of this pixel (primary, then shadow)
@@ -1849,9 +1853,8 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
                         const float hx = r.ox + r.dx * bestT, hy = r.oy + r.dy * bestT, hz = r.oz + r.dz * bestT;
                         r.ox = hx + nx * bias; r.oy = hy + ny * bias; r.oz = hz + nz * bias;
                         r.dx = lnx; r.dy = lny; r.dz = lnz;
-                        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-                        sgnX = (unsigned)((int)__float_as_uint(r.ix) >> 31); sgnY = (unsigned)((int)__float_as_uint(r.iy) >> 31);
-                        sgnZ = (unsigned)((int)__float_as_uint(r.iz) >> 31);
+                        r.ix = lix; r.iy = liy; r.iz = liz;
+                        sgnX = lsx; sgnY = lsy; sgnZ = lsz;
                         shadowRay = true;
                         float tNear, tFar, a0, a1, a2, a3, a4, a5;
                         alive = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
