@@ -107,6 +107,8 @@ def parse_args(argv=None):
     ap.add_argument("--rehearse-world", type=int, default=0,
                     help="with --gpus 1 --force-comm: render / ship / assemble as rank 0 of that many GPUs (rto_comm_debug_rehearse); "
                          "the line then reports the per-rank cost of the split, NOT a frame rate (only 1/N of every frame is rendered)")
+    ap.add_argument("--rehearse-rank", type=int, default=0, help="with --rehearse-world: the rank to play (from 4 GPUs on rank 0 only gathers "
+                                                                  "and assembles, ranks 1..N-1 render)")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1: drive the frames through rto_comm_* with a one-rank RCCL communicator (rehearses the N>1 code path on one GPU)")
     ap.add_argument("--launcher-dry-run", action="store_true", help="--gpus N without WORLD_SIZE: print the child command line and exit")
@@ -330,7 +332,7 @@ def main(argv=None):
         if args.rehearse_world > 1:
             if world != 1:
                 raise SystemExit("--rehearse-world needs --gpus 1 --force-comm")
-            comm.debug_rehearse(args.rehearse_world, 0)       # this GPU plays rank 0 of that many: per-rank cost of the split, no peer traffic
+            comm.debug_rehearse(args.rehearse_world, args.rehearse_rank)   # this GPU plays that rank: per-rank cost of the split, no peer traffic
         comm_mode = _hip.RESIDENT_TRIANGLES_SHADOW if triangles else _hip.RESIDENT_OCTREE
 
     def backend():
@@ -743,7 +745,7 @@ def main(argv=None):
                             f"{W}x{H} primary rays{', Marching-Cubes leaf triangles + 1 shadow ray per hit' if triangles else ''}, {camtxt}, fov 45",
                 "parallelism": (("1 GPU" + (f", {fpl} consecutive frames per kernel launch ({'rto_render_triangles_batch_device' if triangles else 'rto_render_batch_device'})" if fpl > 1 else "") + (f", launches replayed from a HIP graph of {gframes} consecutive frames" if use_graph else ", plain stream launches")) if fif == 1 else f"1 GPU, {fif} frames in flight on {fif} HIP streams") if world == 1 else
                                (f"screen split over {world} GPUs, {args.band_rows}-row bands round-robin, rto_comm_submit: ONE grouped RCCL send/recv per {'frame' if fpg == 1 else f'{fpg} frames'} "
-                                f"into rank 0 (4-byte Lambert term per pixel), batch k's gather overlaps batch k+1's render" if use_comm else "") + ("" if use_comm else f"screen split over {world} GPUs, {args.band_rows}-row bands "
+                                f"into rank 0 (4-byte Lambert term per pixel, the columns of the geometry's rectangle only{'; rank 0 gathers and assembles, ranks 1..N-1 render' if (args.rehearse_world or world) >= 4 else ''}), batch k's gather overlaps batch k+1's render" if use_comm else "") + ("" if use_comm else f"screen split over {world} GPUs, {args.band_rows}-row bands "
                                                           f"round-robin, 1 RCCL gather per {'frame' if fpg == 1 else f'{fpg} frames'} ({'4-byte Lambert term' if args.payload == 'shade' else 'RGBA32F'} per pixel"
                                                           f"{', gather k overlaps render k+1' if pipelined else ''}"
                                                           f"{f', {fpg} consecutive frames per gather' if fpg > 1 else ''}"
@@ -787,8 +789,9 @@ def main(argv=None):
                                                   "what": "one kernel launch per frame (rto_render_device / rto_render_triangles_device), replayed from a HIP graph: a frame's kernel is as long as its "
                                                           "deepest tile's chain of dependent node visits; `value` launches several frames together instead"}
         if args.rehearse_world > 1:
-            result["rehearsal"] = {"as_rank_0_of": args.rehearse_world,
-                                   "what": "ONE GPU doing what rank 0 of that many does per frame (render its bands, grouped send/recv with itself, assemble); "
+            result["rehearsal"] = {"as_rank": args.rehearse_rank, "of": args.rehearse_world,
+                                   "what": "ONE GPU doing what that rank does per frame (render its bands, grouped send/recv with itself) plus the assembly "
+                                           "(in a rehearsal the one GPU is also the assembling rank 0); "
                                            "value / ms_per_step are the per-rank pipeline rate of the split, not a frame rate of this machine"}
         if roofline is not None:
             result["roofline"] = roofline

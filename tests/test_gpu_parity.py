@@ -1383,12 +1383,14 @@ def test_comm_one_rank_through_the_c_abi(ctx, orc, scenes):
             assert_bit_exact(one.cpu().numpy(), wtri, f"comm triangles mode {mode}")
         with pytest.raises(rto.RtoError):
             comm.submit(arr4, 0, 0)                                     # rank 0 without a frame buffer
-        # every rank of a 2-, 3- and 8-GPU split, played in turn by this GPU (rto_comm_debug_rehearse): the bands rank r
-        # renders, ships and assembles must be the oracle's rows b*16 .. b*16+15 with b % world == r -- together the whole frame
+        # every rank of a 2-, 3-, 4- and 8-GPU split, played in turn by this GPU (rto_comm_debug_rehearse): the bands rank r
+        # renders, ships and assembles must be the oracle's rows of the bands it owns -- together the whole frame
         upload(ctx, s)
-        for world in (2, 3, 8):
+        for world in (2, 3, 4, 8):
             got = np.zeros((H, W, 4), np.float32)
-            owner = (np.arange(H) // 16) % world
+            band = np.arange(H) // 16
+            # from 4 GPUs on rank 0 only gathers and assembles; the frame is split over ranks 1 .. world-1
+            owner = band % world if world < 4 else 1 + band % (world - 1)
             for r in range(world):
                 comm.debug_rehearse(world, r)
                 two = torch.full((2, H, W, 4), 7.0, dtype=torch.float32, device="cuda")
@@ -1401,14 +1403,15 @@ def test_comm_one_rank_through_the_c_abi(ctx, orc, scenes):
         # the same for config 5's path: the parts of two frames in one launch of the triangle kernel
         ctx.build_leaf_triangles(s.grid.data)
         wtris = [orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, cams[i].get_view(), cams[i].get_pos(), W / H, 45.0, W, H, shadow=True)[0] for i in (1, 2)]
-        owner = (np.arange(H) // 16) % 3
-        for r in range(3):
-            comm.debug_rehearse(3, r)
-            two = torch.full((2, H, W, 4), 7.0, dtype=torch.float32, device="cuda")
-            comm.submit(hip.Context.frame_array([frames[1], frames[2]]), two.data_ptr(), two.stride(0) * 4, hip.RESIDENT_TRIANGLES_SHADOW)
-            comm.flush()
-            for q in range(2):
-                assert_bit_exact(two[q].cpu().numpy()[owner == r], wtris[q][owner == r], f"triangle rehearsal rank {r} of 3, frame {q}")
+        for world in (3, 5):
+            owner = (np.arange(H) // 16) % 3 if world == 3 else 1 + (np.arange(H) // 16) % 4
+            for r in range(world):
+                comm.debug_rehearse(world, r)
+                two = torch.full((2, H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+                comm.submit(hip.Context.frame_array([frames[1], frames[2]]), two.data_ptr(), two.stride(0) * 4, hip.RESIDENT_TRIANGLES_SHADOW)
+                comm.flush()
+                for q in range(2):
+                    assert_bit_exact(two[q].cpu().numpy()[owner == r], wtris[q][owner == r], f"triangle rehearsal rank {r} of {world}, frame {q}")
         comm.debug_rehearse(0)
         with pytest.raises(rto.RtoError):
             comm.debug_rehearse(4, 4)
