@@ -210,7 +210,8 @@ int  rto_assemble_batch_all_device(rto_context* ctx, const rto_frame* frames, in
 /* ---- multi-GPU: screen split + ONE gather per batch, below the C boundary ---------------------------------
  * No reference counterpart (the reference is single-GPU).  A communicator binds one context
  * (= one GPU, holding the whole octree) to a rank of a world of GPUs of one node.  rto_comm_submit renders this rank's
- * bands (band b of band_rows rows belongs to rank b % world) of n consecutive frames as the 4-byte payload of
+ * bands (band b of band_rows rows belongs to rank b % world; from 4 ranks on rank 0 only gathers and assembles and band b
+ * belongs to rank 1 + b % (world - 1)) of n consecutive frames as the 4-byte payload of
  * rto_render_shade_device, ships them to rank 0 with ONE grouped ncclSend/ncclRecv (RCCL over xGMI: a direct gather into
  * the root, never a ring) and, on rank 0, re-interleaves and finishes the colours into d_frames + i*frame_stride_bytes
  * (RGBA32F, bit-identical to rto_render_device).  Asynchronous and pipelined: the call returns when the work is

@@ -85,7 +85,8 @@ public:
     int frameHeight() const { return m_frameH; }
     void setDevice(int ordinal) { m_device = ordinal; }                  // before ensureComputeInitialized()
     // Multi-GPU (no upstream counterpart; before ensureComputeInitialized()): the GPUs `m_device .. m_device + n - 1` of this
-    // node each hold the octree and render the bands `b % n` of every frame (bands of bandRows rows); ONE grouped RCCL
+    // node each hold the octree and render the bands `b % n` of every frame (bands of bandRows rows; from 4 GPUs on the first
+    // one only gathers and assembles and the others render the bands `b % (n - 1)`); ONE grouped RCCL
     // send/recv per frame lands the parts on the first GPU, which assembles the image (rto_comm_* in rto_hip.h).  The
     // reference's call sequence stays as it is; framebuffer() reads the assembled frame.
     void setDevices(int n, int bandRows = 16) { m_numDevices = n < 1 ? 1 : n; m_bandRows = bandRows; }
