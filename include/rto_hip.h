@@ -135,7 +135,11 @@ int  rto_forget_stream(rto_context* ctx, void* hip_stream);
  * replaces: the CPU loop + compaction + SSBO re-upload of
  * renderSceneComputeWithCulling(updateFrustum=true) (S/RayTracerBVH.cpp:725-813).
  * The test runs on the GPU over the resident array; rendering afterwards behaves as
- * if the compacted array had been uploaded.  enable=0 restores the full array. */
+ * if the compacted array had been uploaded.  enable=0 restores the full array.
+ * Cost: 0.033 ms at 374,921 nodes including the one read-back (visible count, the root's flag).  The descriptor kernels only
+ * need the visibility bits; the compacted array itself is made when somebody needs it (rto_download_visible_nodes, the generic
+ * kernel, a culled root with surviving descendants).  Frames in flight on the context's own stream are ordered before the
+ * update by the stream; if frames were launched on other streams since the last update, the device is waited for first. */
 int  rto_update_frustum(rto_context* ctx, const float view[16], float fov_deg, float aspect, int enable);
 /* Developer aid: the same update with caller-supplied planes (LEFT, RIGHT, TOP, BOTTOM, NEAR, FAR as nx, ny, nz, d;
  * normalised) and margin instead of the ones S/RT:731-755 derives -- lets a test build situations real cameras cannot,
