@@ -857,6 +857,7 @@ __device__ __forceinline__ void child_axis_terms(float g, float o, float inv, un
     n1 = __uint_as_float(bop3<kSelC>(a1y, a2y, sgn)); f1 = __uint_as_float(bop3<kSelC>(a2y, a1y, sgn));
 }
 
+template <bool FOLD = true>
 __device__ __forceinline__ unsigned child_fail_mask_fast(float gx, float gy, float gz, float vs, float ox, float oy, float oz,
                                                          float ix, float iy, float iz, unsigned sx, unsigned sy, unsigned sz,
                                                          int cx, int cy, int cz, float fh) {
@@ -869,10 +870,15 @@ __device__ __forceinline__ unsigned child_fail_mask_fast(float gx, float gy, flo
     child_axis_terms(gz, oz, iz, sz, cz, fh, vs, sv, nz0, nz1, fz0, fz1);
     // fold "tFar > 0" and "tNear < 1e30" into the x terms (spelled as instructions: behind a bitwise select the compiler
     // would first canonicalise the operand with an extra v_max_f32 x, x)
-    asm("v_max_f32 %0, %1, %2" : "=v"(nx0) : "v"(nx0), "v"(kEps));
-    asm("v_max_f32 %0, %1, %2" : "=v"(nx1) : "v"(nx1), "v"(kEps));
-    asm("v_min_f32 %0, %1, %2" : "=v"(fx0) : "v"(fx0), "v"(kBelow1e30));
-    asm("v_min_f32 %0, %1, %2" : "=v"(fx1) : "v"(fx1), "v"(kBelow1e30));
+    // FOLD = false (see `plainWave` in trace_tile_lean): every ray of the wave starts outside the root box and meets it at
+    // 0 < tNear, tFar < 1e29.  A child's box lies inside the root's (up to an ulp), so whenever its own tNear <= tFar holds,
+    // both lie in the root's interval: tFar > 0 and tNear < 1e30 follow and the two folds change no verdict.
+    if (FOLD) {
+        asm("v_max_f32 %0, %1, %2" : "=v"(nx0) : "v"(nx0), "v"(kEps));
+        asm("v_max_f32 %0, %1, %2" : "=v"(nx1) : "v"(nx1), "v"(kEps));
+        asm("v_min_f32 %0, %1, %2" : "=v"(fx0) : "v"(fx0), "v"(kBelow1e30));
+        asm("v_min_f32 %0, %1, %2" : "=v"(fx1) : "v"(fx1), "v"(kBelow1e30));
+    }
     // verdict of child k = sign bit of (min3 - max3): no NaN can occur here, and a float difference carries the
     // exact sign of the comparison (x - x is +0).  v_alignbit shifts the sign into an accumulator: two 4-deep chains.
 #define RTO_D(kx, ky, kz) __float_as_uint(min3f(fx##kx, fy##ky, fz##kz) - max3f(nx##kx, ny##ky, nz##kz))
@@ -928,17 +934,21 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     Ray r;
     bool alive = false;
     const bool outsideRoot = px < P.rootX0 || px > P.rootX1 || py < P.rootY0 || py > P.rootY1;
+    bool guarded = false;        // this lane's ray needs the tFar > 0 / tNear < 1e30 folds of the child test
     if (inImage && P.rootVisible) {
         steps0 = 1;
         if (!outsideRoot) {
             r = generate_ray_tab(P, px, py);
             float tNear, tFar, a0, a1, a2, a3, a4, a5;
             alive = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+            // the ray starts well outside the root box (its entry is at least 1/1024 of its exit away) and leaves it below 1e29
+            guarded = alive && !(tNear > 0.0f && tNear * 1024.0f >= tFar && tFar < 1e29f);
         }
     }
     const bool risky = alive && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
                                   __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
     const bool anyRisky = __builtin_amdgcn_ballot_w64(risky) != 0ull;   // wave-uniform, fixed for the whole traversal
+    const bool plainWave = __builtin_amdgcn_ballot_w64(guarded) == 0ull;   // wave-uniform: no ray of this wave needs the folds
 
     // The loop is written for gfx950's VALU issue costs (tools/ubench/valu_rate2.hip, valu_rate3.hip: add / sub / mul f32,
     // add / sub u32, and / or / xor, shifts by an immediate and v_bitop3 issue every 2 cycles per SIMD; min / max, cvt,
@@ -967,8 +977,10 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
         unsigned fail8;
         if (anyRisky) fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz,
                                                     r.ix, r.iy, r.iz, cx, cy, cz, 1 << bpos);
-        else fail8 = child_fail_mask_fast(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                          sgnX, sgnY, sgnZ, cx, cy, cz, fh);
+        else if (plainWave) fail8 = child_fail_mask_fast<false>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                                sgnX, sgnY, sgnZ, cx, cy, cz, fh);
+        else fail8 = child_fail_mask_fast<true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                sgnX, sgnY, sgnZ, cx, cy, cz, fh);
         const unsigned vm0 = (d.x >> 16) & 0xffu;
         S += __builtin_popcount(vm0);
         // children that do more than count a pop: visible internal ones and visible solid leaves that pass the slab test
