@@ -844,9 +844,13 @@ constexpr int kReplace = 0x74;    // (a & ~b) | (b & ~c)
 // v_min / v_max up to the sign of a zero, which no later operation observes -- at full rate (v_bitop3) instead of half
 // rate (v_min_f32 / v_max_f32).  sgn[a] = all ones when inv[a] < 0.
 // one axis of child_fail_mask_fast: entry / exit parameters of the low (0) and high (1) child halves
+// BIASED: c arrives as 0x4B000000 | coordinate -- the bits of the float 2^23 + coordinate --, so that the conversion is one
+// full-rate subtraction (exact) instead of a half-rate v_cvt_f32_i32; the same value either way.
+constexpr unsigned kCoordBias = 0x4B000000u;
+template <bool BIASED>
 __device__ __forceinline__ void child_axis_terms(float g, float o, float inv, unsigned sgn, int c, float fh, float vs, float sv,
                                                  float& n0, float& n1, float& f0, float& f1) {
-    const float fc = (float)c;
+    const float fc = BIASED ? __uint_as_float((unsigned)c) - 8388608.0f : (float)c;
     const f32x2 fcc = (f32x2){ fc, fc } + (f32x2){ 0.0f, fh };       // (fc, fc + fh): both exact (integers < 2^24; fc + 0 == fc)
     const f32x2 lo = (f32x2){ g, g } + fcc * vs;                      // nodeMin of the low / high children
     const f32x2 hi = lo + sv;                                         // their nodeMax
@@ -857,7 +861,7 @@ __device__ __forceinline__ void child_axis_terms(float g, float o, float inv, un
     n1 = __uint_as_float(bop3<kSelC>(a1y, a2y, sgn)); f1 = __uint_as_float(bop3<kSelC>(a2y, a1y, sgn));
 }
 
-template <bool FOLD = true>
+template <bool FOLD = true, bool BIASED = false>
 __device__ __forceinline__ unsigned child_fail_mask_fast(float gx, float gy, float gz, float vs, float ox, float oy, float oz,
                                                          float ix, float iy, float iz, unsigned sx, unsigned sy, unsigned sz,
                                                          int cx, int cy, int cz, float fh) {
@@ -865,9 +869,9 @@ __device__ __forceinline__ unsigned child_fail_mask_fast(float gx, float gy, flo
     const float kEps = __uint_as_float(1u);                   // smallest positive float: tFar > 0  <=>  tFar >= kEps
     const float kBelow1e30 = __uint_as_float(0x7149f2c9u);    // largest float < 1e30f:  tNear < 1e30 <=> tNear <= this
     float nx0, nx1, fx0, fx1, ny0, ny1, fy0, fy1, nz0, nz1, fz0, fz1;
-    child_axis_terms(gx, ox, ix, sx, cx, fh, vs, sv, nx0, nx1, fx0, fx1);
-    child_axis_terms(gy, oy, iy, sy, cy, fh, vs, sv, ny0, ny1, fy0, fy1);
-    child_axis_terms(gz, oz, iz, sz, cz, fh, vs, sv, nz0, nz1, fz0, fz1);
+    child_axis_terms<BIASED>(gx, ox, ix, sx, cx, fh, vs, sv, nx0, nx1, fx0, fx1);
+    child_axis_terms<BIASED>(gy, oy, iy, sy, cy, fh, vs, sv, ny0, ny1, fy0, fy1);
+    child_axis_terms<BIASED>(gz, oz, iz, sz, cz, fh, vs, sv, nz0, nz1, fz0, fz1);
     // fold "tFar > 0" and "tNear < 1e30" into the x terms (spelled as instructions: behind a bitwise select the compiler
     // would first canonicalise the operand with an extra v_max_f32 x, x)
     // FOLD = false (see `plainWave` in trace_tile_lean): every ray of the wave starts outside the root box and meets it at
@@ -957,7 +961,7 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     // b = depth-1-level (what the arithmetic needs) and the stack write is unconditional (a lane owns its LDS column;
     // a finished lane's column is never read again except by its own identity-(2) walk, which a hit keeps valid).
     unsigned cur = 0;
-    int cx = 0, cy = 0, cz = 0;
+    int cx = (int)kCoordBias, cy = (int)kCoordBias, cz = (int)kCoordBias;   // node position, biased (child_axis_terms): the bit operations below never touch the bias
     int bpos = P.depth - 1;                                             // log2 of the edge of the current node's children
     unsigned lvlPending = 0;                                            // bit b: the entry of exponent b still has unpopped candidates
     const unsigned sentinel = 1u << P.depth;                            // entry `depth` is a dummy: what "nothing pending" reads
@@ -976,11 +980,11 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
         const float fh = __uint_as_float((unsigned)(bpos + 127) << 23);        // (float)(1 << bpos), exact
         unsigned fail8;
         if (anyRisky) fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz,
-                                                    r.ix, r.iy, r.iz, cx, cy, cz, 1 << bpos);
-        else if (plainWave) fail8 = child_fail_mask_fast<false>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                                sgnX, sgnY, sgnZ, cx, cy, cz, fh);
-        else fail8 = child_fail_mask_fast<true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                sgnX, sgnY, sgnZ, cx, cy, cz, fh);
+                                                    r.ix, r.iy, r.iz, cx & 0x7fffff, cy & 0x7fffff, cz & 0x7fffff, 1 << bpos);
+        else if (plainWave) fail8 = child_fail_mask_fast<false, true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                                      sgnX, sgnY, sgnZ, cx, cy, cz, fh);
+        else fail8 = child_fail_mask_fast<true, true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                      sgnX, sgnY, sgnZ, cx, cy, cz, fh);
         const unsigned vm0 = (d.x >> 16) & 0xffu;
         S += __builtin_popcount(vm0);
         // children that do more than count a pop: visible internal ones and visible solid leaves that pass the slab test
@@ -1013,6 +1017,7 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     }
     if (P.tileCost && lane == 0 && ty < P.tilesY) P.tileCost[tile] = trips;
     const int leafShift = bpos + 1;                                      // on a hit: log2 of the leaf's edge
+    cx &= 0x7fffff; cy &= 0x7fffff; cz &= 0x7fffff;                      // plain coordinates for the epilogue
 
     // identity (2): pops at the accepted leaf.  Needed for every hit when steps are reported, else only when the
     // upper bound 1 + S does not already clear the cap.
