@@ -45,8 +45,8 @@ NODE_BYTES = 60                # struct GPUNodes, the reference's node record (S
 PIXEL_BYTES = 16               # RGBA32F
 SIMDS, CLOCK_GHZ, VALU_CYCLES_PER_WAVE_INST = 1024, 2.4, 2   # 256 CUs x 4 SIMD-32: a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
 VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INST   # 1228.8 G wave-instructions/s
-LEAN_LOOP_CYCLES_PER_INST = 424.0 / 124.0   # k_trace_lean's loop trip: 124 VALU instructions, 424 issue cycles at the measured per-opcode
-                                            # costs (profiles/r02_valu_issue_rates.txt)
+LEAN_LOOP_CYCLES_PER_INST = 401.5 / 120.0   # k_trace_lean's loop trip (rays that start outside the root box): 120 VALU instructions,
+                                            # 401.5 issue cycles at the measured per-opcode costs (profiles/r02_valu_issue_rates.txt)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_counters.json")
 
 CONFIGS = {
