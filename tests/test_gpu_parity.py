@@ -1468,3 +1468,27 @@ def test_cpp_class_set_devices(orc, scenes):
         rt2.renderSceneCompute(cam, W, H, W / H, 45.0)
         assert rt2.framebuffer() is None or len(rt2.framebuffer()) == 0
     rto.freeOctree(root)
+
+
+def test_bench_line_contract_small_run():
+    """bench.py end to end on a small scene: one JSON line with the keys the driver reads, a verified frame, a roofline object
+    and a CPU baseline (the default sizes are exercised by the driver itself; this guards the contract, not the numbers)."""
+    import json
+    import subprocess
+    import sys
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--dim", "64", "--width", "320", "--height", "200",
+           "--cpu-frames", "1", "--ramp-ms", "0", "--orbit-frames", "8"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["verified_against_oracle"] is True and d["value"] > 0 and d["ms_per_step"] > 0
+    assert "workload" in d["config"] and d["roofline"]["bound"] == "valu_issue" and d["roofline"]["hbm_algorithmic"]["achieved"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert d["one_frame_per_launch"]["ms_per_frame"] > 0 and d["orbit"]["frames"] == 8
