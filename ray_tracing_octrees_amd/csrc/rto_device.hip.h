@@ -874,9 +874,10 @@ __device__ __forceinline__ unsigned child_fail_mask_fast(float gx, float gy, flo
     child_axis_terms<BIASED>(gz, oz, iz, sz, cz, fh, vs, sv, nz0, nz1, fz0, fz1);
     // fold "tFar > 0" and "tNear < 1e30" into the x terms (spelled as instructions: behind a bitwise select the compiler
     // would first canonicalise the operand with an extra v_max_f32 x, x)
-    // FOLD = false (see `plainWave` in trace_tile_lean): every ray of the wave starts outside the root box and meets it at
-    // 0 < tNear, tFar < 1e29.  A child's box lies inside the root's (up to an ulp), so whenever its own tNear <= tFar holds,
-    // both lie in the root's interval: tFar > 0 and tNear < 1e30 follow and the two folds change no verdict.
+    // FOLD = false (see `plainWave` in trace_tile_lean): every ray of the wave starts outside the root box, more than a few ulps
+    // of its coordinates away, and meets it at 0 < tNear, tFar < 1e29.  A child's box lies inside the root's (up to an ulp), so
+    // whenever its own tNear <= tFar holds, both lie in the root's interval: tFar > 0 and tNear < 1e30 follow and the two
+    // folds change no verdict.
     if (FOLD) {
         asm("v_max_f32 %0, %1, %2" : "=v"(nx0) : "v"(nx0), "v"(kEps));
         asm("v_max_f32 %0, %1, %2" : "=v"(nx1) : "v"(nx1), "v"(kEps));
@@ -945,8 +946,14 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
             r = generate_ray_tab(P, px, py);
             float tNear, tFar, a0, a1, a2, a3, a4, a5;
             alive = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
-            // the ray starts well outside the root box (its entry is at least 1/1024 of its exit away) and leaves it below 1e29
-            guarded = alive && !(tNear > 0.0f && tNear * 1024.0f >= tFar && tFar < 1e29f);
+            // The ray starts well outside the root box: its entry is at least 1/1024 of its exit away, leaves it below 1e29,
+            // and lies more than 8 ulps of the largest coordinate involved -- as a ray parameter, on the steepest axis --
+            // from the origin: a child's planes may differ from the root's by an ulp, which then cannot move a child's
+            // parameters across zero.
+            const float reach = 0x1p-20f * gmax(gmax(gmax(__builtin_fabsf(a0), __builtin_fabsf(a3)), __builtin_fabsf(r.ox)) * __builtin_fabsf(r.ix),
+                                                gmax(gmax(gmax(__builtin_fabsf(a1), __builtin_fabsf(a4)), __builtin_fabsf(r.oy)) * __builtin_fabsf(r.iy),
+                                                     gmax(gmax(__builtin_fabsf(a2), __builtin_fabsf(a5)), __builtin_fabsf(r.oz)) * __builtin_fabsf(r.iz)));
+            guarded = alive && !(tNear > reach && tNear * 1024.0f >= tFar && tFar < 1e29f);
         }
     }
     const bool risky = alive && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&

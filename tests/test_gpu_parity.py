@@ -1492,3 +1492,49 @@ def test_bench_line_contract_small_run():
     assert "workload" in d["config"] and d["roofline"]["bound"] == "valu_issue" and d["roofline"]["hbm_algorithmic"]["achieved"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     assert d["one_frame_per_launch"]["ms_per_frame"] > 0 and d["orbit"]["frames"] == 8
+
+
+def test_camera_a_hair_outside_the_root_box(ctx, orc):
+    """Ray origins a few ulps outside the root box, near its edges and corners, on a grid far from the world origin (coordinates
+    ~1000, voxels of 500 ulps): child boxes may stick out of the root's by an ulp, so their planes can pass such an origin.
+    The fold-free child test (waves whose rays all start outside the root box) must not be chosen then -- every kernel has to
+    reproduce the oracle's pixels, step counts and counters."""
+    rng = np.random.default_rng(77)
+    dims = (32, 32, 32)
+    data = (rng.random((32, 32, 32)) < 0.25).astype(np.uint8)
+    data[8:24, 8:24, 8:24] = 1
+    gmin = np.array([1000.0, -2000.0, 500.0], np.float32)
+    voxel = np.float32(0.03125)
+    g = orc.Grid(dims, gmin, voxel, data)
+    s = Scene(g, orc.build_flat_octree(g))
+    upload(ctx, s)
+    W, H = 96, 64
+    lo, hi = gmin, gmin + np.float32(32) * voxel
+    centre = 0.5 * (lo + hi)
+    for k in (1, 2, 3, 8, 40, 1000):
+        for corner in ((0, 0, 0), (1, 0, 1), (1, 1, 1), (0, 1, 0)):
+            pos = np.array([hi[a] if corner[a] else lo[a] for a in range(3)], np.float32)
+            for a in range(3):                                           # k ulps outside on one axis, a little inside the faces of the others
+                step = np.spacing(pos[a]) * np.float32(k)
+                pos[a] = pos[a] + step if corner[a] else pos[a] - step
+                if a != k % 3:
+                    pos[a] = pos[a] - np.float32(0.2) if corner[a] else pos[a] + np.float32(0.2)
+            cam = orc.Camera(0.0, 0.0, 1.0)
+            cam.set_target(*[float(x) for x in centre])
+            view = orc.look_at(pos, centre) if hasattr(orc, "look_at") else None
+            if view is None:
+                # a view matrix looking from pos towards the centre: reuse the oracle's camera at the same direction
+                d = centre - pos
+                r = float(np.linalg.norm(d))
+                cam = orc.Camera(float(np.arcsin(np.clip(-d[1] / r, -1, 1))), float(np.arctan2(-d[0], -d[2])), r)
+                cam.set_target(*[float(x) for x in centre])
+                view = cam.get_view()
+            f = rto.make_frame(view, pos, W / H, 60.0, W, H)
+            want, st = oracle_frame(orc, s, view, pos, W, H, fov=60.0)
+            steps = orc.render_steps(s.nodes, s.min, s.voxel, view, pos, W / H, 60.0, W, H)
+            for kname, kernel in KERNELS:
+                ctx.set_kernel(kernel)
+                what = f"{k} ulps outside corner {corner}, {kname}"
+                assert_bit_exact(ctx.render_host(f), want, what)
+                np.testing.assert_array_equal(ctx.render_steps(f), steps, err_msg=what)
+    ctx.set_kernel(rto.KERNEL_AUTO)
