@@ -248,6 +248,42 @@ int  rto_comm_debug_rehearse(rto_comm* comm, int as_world, int as_rank);
 int  rto_comm_debug_last_payload(const rto_comm* comm, int64_t* packed_floats, int64_t* full_floats);
 void* rto_comm_stream(rto_comm* comm);            /* hipStream_t the gathers and (rank 0) the assembled frames are ordered on */
 
+/* ---- multi-GPU: the split plan (pure host arithmetic, no GPU needed) -----------------------------------------
+ * Everything the ranks of a screen split must agree on BEFORE they post sends and receives -- who renders, which part a
+ * rank owns, the rows every part's buffer is padded to, the column window of each frame of the batch that travels (only
+ * the columns of the geometry's screen rectangle do), the offsets inside a packed part and the float count per rank --
+ * is derived by ONE function from the frames and the scene's bounds.  rto_comm_submit calls it on every rank; tests call
+ * the same function from N processes and compare the plans byte for byte (tests/_tilesplit_worker.py), so a mismatch
+ * cannot first appear as a hang inside RCCL.  No reference counterpart (the reference is single-GPU). */
+typedef struct rto_scene_bounds {
+    float   grid_min[3];
+    float   voxel_size;
+    int32_t root_size;             /* octree root edge in voxels (power of two)                      */
+    int32_t solid_lo[3], solid_hi[3];  /* bounding box of the solid leaves, voxel units; lo > hi: nothing solid */
+} rto_scene_bounds;
+int  rto_scene_bounds_get(const rto_context* ctx, rto_scene_bounds* out);
+/* the same from a GPUNodes array on the host (what rto_upload_octree derives) */
+int  rto_scene_bounds_of_nodes(const rto_node* nodes, int64_t num_nodes, const float grid_min[3], float voxel_size, rto_scene_bounds* out);
+
+#define RTO_SPLIT_MAX_FRAMES 32    /* frames of one batch whose windows the plan can hold; larger batches ship whole rows */
+typedef struct rto_split_plan {
+    int32_t world, band_rows, width, height, n_frames;
+    int32_t render_parts;          /* parts a frame is cut into: world, or world - 1 when rank 0 only gathers (world >= 4) */
+    int32_t first_render_rank;     /* 0, or 1 when rank 0 only gathers and assembles                 */
+    int32_t rows_part0;            /* rows of part 0 = rows every part's buffer is padded to          */
+    int32_t cropped;               /* 1: only the window columns of each frame travel                 */
+    int32_t win_x0[RTO_SPLIT_MAX_FRAMES], win_w[RTO_SPLIT_MAX_FRAMES];   /* window of frame i: columns [x0, x0 + w) */
+    int64_t win_off[RTO_SPLIT_MAX_FRAMES];   /* float offset of frame i inside a rank's packed part (rows_part0 x win_w each) */
+    int64_t frame_floats;          /* rows_part0 * width: one frame of a part, unpacked               */
+    int64_t full_floats;           /* frame_floats * n_frames                                         */
+    int64_t pack_floats;           /* floats every rendering rank ships == stride between the parts on rank 0 */
+} rto_split_plan;
+int  rto_split_plan_make(const rto_scene_bounds* scene, const rto_frame* frames, int n, int world, int band_rows, rto_split_plan* out);
+int  rto_split_part_of_rank(const rto_split_plan* plan, int rank);      /* part that rank renders, -1: it renders nothing */
+int  rto_split_rows_of_part(const rto_split_plan* plan, int part);      /* rows part owns (<= rows_part0)                */
+/* Where row `row` of an assembled frame comes from: *part and the row inside that part's compact buffer. */
+int  rto_split_row_source(const rto_split_plan* plan, int row, int* part, int* local_row);
+
 /* ---- N2: leaf triangles + shadow ray (BASELINE config 5) -------------------------
  * No upstream counterpart: the reference has no ray/triangle code (its MC triangles are rasterised).  The
  * triangles are those MarchingCubesRenderer emits per leaf (localMC, S/OctreeVoxel.cpp:780-879;

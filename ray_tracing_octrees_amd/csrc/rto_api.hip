@@ -128,6 +128,22 @@ static int fail(rto_context* ctx, int code, const std::string& msg) {
             return fail(ctx, RTO_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
+// Test hook: RTO_FAULT_ALLOC=<k> makes the k-th (1-based) buffer allocation of the frustum-update buffers / rto_comm buffers
+// fail, so that the all-or-nothing clean-up below can be exercised (tests/test_gpu_parity.py); unset: never.
+static hipError_t fallible_malloc(void** p, size_t bytes) {
+    static long countdown = []() { const char* e = std::getenv("RTO_FAULT_ALLOC"); return e ? std::atol(e) : 0L; }();
+    if (countdown > 0 && --countdown == 0) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipMalloc(p, bytes);
+}
+
+static void free_cull_buffers(rto_context* c) {
+    (void)hipFree(c->d_vis); c->d_vis = nullptr;
+    (void)hipFree(c->d_remap); c->d_remap = nullptr;
+    (void)hipFree(c->d_blockCount); c->d_blockCount = nullptr;
+    (void)hipFree(c->d_blockBase); c->d_blockBase = nullptr;
+    (void)hipFree(c->d_compact); c->d_compact = nullptr;
+}
+
 static void free_octree(rto_context* c) {
     if (c->asyncPooled) {
         (void)hipDeviceSynchronize();          // like hipFree: frames on caller streams may still read the arrays
@@ -138,11 +154,7 @@ static void free_octree(rto_context* c) {
     c->d_nodes = nullptr; c->d_desc = nullptr; c->asyncPooled = false;
     if (!c->descPooled) (void)hipFree(c->d_descFirstChild);
     c->d_descFirstChild = nullptr; c->descPooled = false;
-    (void)hipFree(c->d_vis); c->d_vis = nullptr;
-    (void)hipFree(c->d_remap); c->d_remap = nullptr;
-    (void)hipFree(c->d_blockCount); c->d_blockCount = nullptr;
-    (void)hipFree(c->d_blockBase); c->d_blockBase = nullptr;
-    (void)hipFree(c->d_compact); c->d_compact = nullptr;
+    free_cull_buffers(c);
     (void)hipFree(c->d_tris); c->d_tris = nullptr;
     (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
     (void)hipFree(c->d_triRec); c->d_triRec = nullptr;
@@ -279,6 +291,8 @@ static bool build_descriptors(const rto_node* nodes, int64_t n, std::vector<uint
     return true;
 }
 
+static void bounds_from_nodes(const rto_node* nodes, int64_t n, const float grid_min[3], float voxel_size, rto_scene_bounds* b);   // rto_split.inc
+
 extern "C" {
 
 int rto_upload_octree(rto_context* c, const rto_node* nodes, int64_t n, const float grid_min[3], float voxel_size) {
@@ -296,19 +310,12 @@ int rto_upload_octree(rto_context* c, const rto_node* nodes, int64_t n, const fl
     RTO_HIP(c, hipMemcpy(c->d_nodes, nodes, (size_t)n * sizeof(rto_node), hipMemcpyHostToDevice));
 
     {   // where the geometry is: tiles nearest its projection are launched first (heavy waves early)
-        long lo[3] = { 1L << 40, 1L << 40, 1L << 40 }, hi[3] = { -(1L << 40), -(1L << 40), -(1L << 40) };
-        for (int64_t i = 0; i < n; i++) {
-            const rto_node& nd = nodes[i];
-            if (!is_terminal(nd) || nd.isSolid != 1) continue;
-            const long mn[3] = { nd.x, nd.y, nd.z };
-            for (int a = 0; a < 3; a++) {
-                if (mn[a] < lo[a]) lo[a] = mn[a];
-                if (mn[a] + nd.size > hi[a]) hi[a] = mn[a] + nd.size;
-            }
-        }
+        rto_scene_bounds sb;
+        bounds_from_nodes(nodes, n, grid_min, voxel_size, &sb);
+        const bool any = sb.solid_lo[0] <= sb.solid_hi[0];
         for (int a = 0; a < 3; a++) {
-            c->solidCentre[a] = lo[a] <= hi[a] ? 0.5f * (float)(lo[a] + hi[a]) : 0.5f * (float)nodes[0].size;
-            c->solidLo[a] = lo[a] <= hi[a] ? (int)lo[a] : 1; c->solidHi[a] = lo[a] <= hi[a] ? (int)hi[a] : 0;
+            c->solidCentre[a] = any ? 0.5f * (float)((long)sb.solid_lo[a] + (long)sb.solid_hi[a]) : 0.5f * (float)nodes[0].size;
+            c->solidLo[a] = sb.solid_lo[a]; c->solidHi[a] = sb.solid_hi[a];
         }
     }
     std::vector<uint2> desc;
@@ -726,11 +733,16 @@ static int update_frustum_planes(rto_context* c, const float planes[24], float m
     const int nb = (int)((n + kBlock - 1) / kBlock);
     const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
     if (!c->d_vis) {
-        RTO_HIP(c, hipMalloc(&c->d_vis, (size_t)n));
-        RTO_HIP(c, hipMalloc(&c->d_remap, (size_t)n * sizeof(int)));
-        RTO_HIP(c, hipMalloc(&c->d_blockCount, (size_t)nb * sizeof(int)));
-        RTO_HIP(c, hipMalloc(&c->d_blockBase, (size_t)nb * sizeof(int)));
-        RTO_HIP(c, hipMalloc(&c->d_compact, (size_t)n * sizeof(rto_node)));
+        // all or nothing: a failed allocation leaves none of the five behind (the next update starts over)
+        hipError_t e = fallible_malloc(reinterpret_cast<void**>(&c->d_vis), (size_t)n);
+        if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_remap), (size_t)n * sizeof(int));
+        if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_blockCount), (size_t)nb * sizeof(int));
+        if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_blockBase), (size_t)nb * sizeof(int));
+        if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_compact), (size_t)n * sizeof(rto_node));
+        if (e != hipSuccess) {
+            free_cull_buffers(c);
+            return fail(c, RTO_E_HIP, std::string("rto_update_frustum: buffer allocation: ") + hipGetErrorString(e));
+        }
     }
     CullParams C;
     std::memcpy(C.planes, planes, sizeof C.planes);
@@ -828,9 +840,10 @@ static bool stream_is_capturing(hipStream_t s);
 // for certain.  Valid only when all 8 corners are strictly in front of the eye (then the box projects onto the convex
 // hull of its projected corners); computed in double with a margin of 2 pixels plus the box's float rounding, far above
 // any float error of the per-pixel ray directions.  Otherwise: the whole image.  x0 > x1 or y0 > y1: nothing can hit.
-static void screen_rectangle(const rto_frame* f, const RenderParams& P, const double lo[3], const double hi[3], int out[4]) {
+static void screen_rectangle(const rto_frame* f, float tanHalfFov, const double lo[3], const double hi[3], int out[4]) {
+    struct { int W, H; } P{ f->width, f->height };
     out[0] = 0; out[1] = 0; out[2] = P.W - 1; out[3] = P.H - 1;
-    const double tanH = (double)P.tanHalfFov, asp = (double)P.aspect;
+    const double tanH = (double)tanHalfFov, asp = (double)f->aspect;
     double lox = 1e300, loy = 1e300, hix = -1e300, hiy = -1e300;
     bool allInFront = tanH > 0.0 && asp > 0.0 && std::isfinite(hi[0] - lo[0]) && std::isfinite(hi[1] - lo[1]) && std::isfinite(hi[2] - lo[2]);
     // the kernels build the boxes in float (gridMin + float(c) * voxel): widen by a few float ulps of the largest coordinate
@@ -854,6 +867,37 @@ static void screen_rectangle(const rto_frame* f, const RenderParams& P, const do
         out[1] = (int)std::max(0.0, std::min(y0, (double)P.H));
         out[3] = (int)std::max(-1.0, std::min(y1, (double)P.H - 1.0));
     }
+}
+
+// What the screen rectangles and the multi-GPU split plan need to know of a scene (rto_scene_bounds, include/rto_hip.h).
+static rto_scene_bounds bounds_of(const rto_context* c) {
+    rto_scene_bounds b;
+    std::memcpy(b.grid_min, c->gridMin, sizeof b.grid_min);
+    b.voxel_size = c->voxelSize;
+    b.root_size = c->rootSize;
+    for (int a = 0; a < 3; a++) { b.solid_lo[a] = c->solidLo[a]; b.solid_hi[a] = c->solidHi[a]; }
+    return b;
+}
+
+// Pixel rectangles (inclusive) of the root box and of the solid leaves' bounding box for one frame: pure host arithmetic on
+// the frame and the scene's bounds, so every rank of a screen split derives the same numbers (rto_split_plan_make).
+static void frame_rectangles(const rto_scene_bounds& S, const rto_frame* f, float tanHalfFov, int root[4], int solid[4]) {
+    const double ext = (double)S.root_size * (double)S.voxel_size;
+    const double rlo[3] = { S.grid_min[0], S.grid_min[1], S.grid_min[2] };
+    const double rhi[3] = { rlo[0] + ext, rlo[1] + ext, rlo[2] + ext };
+    screen_rectangle(f, tanHalfFov, rlo, rhi, root);
+    if (S.solid_lo[0] > S.solid_hi[0]) { solid[0] = solid[1] = 0; solid[2] = solid[3] = -1; return; }     // nothing solid: nothing to hit
+    double slo[3], shi[3];
+    for (int a = 0; a < 3; a++) {
+        // widened by one voxel: the Marching-Cubes triangles of the surface cells (config 5) reach half a voxel beyond
+        // the solid leaves; one rectangle serves both paths
+        slo[a] = (double)S.grid_min[a] + (double)(S.solid_lo[a] - 1) * (double)S.voxel_size;
+        shi[a] = (double)S.grid_min[a] + (double)(S.solid_hi[a] + 1) * (double)S.voxel_size;
+    }
+    int r[4];
+    screen_rectangle(f, tanHalfFov, slo, shi, r);
+    solid[0] = std::max(r[0], root[0]); solid[1] = std::max(r[1], root[1]);
+    solid[2] = std::min(r[2], root[2]); solid[3] = std::min(r[3], root[3]);
 }
 
 // Launch geometry "one wave per tile of the whole image, every wave stores all its pixels" (generic / V1 / triangle kernels,
@@ -968,25 +1012,10 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     P.rayX = c->d_rayX; P.rayY = c->d_rayY;
     P.tileOrder = nullptr; P.tileCost = nullptr;
     {   // rays through pixels outside these rectangles miss the root box / every solid leaf for certain
-        int r[4];
-        const double ext = (double)c->rootSize * (double)c->voxelSize;
-        const double rlo[3] = { c->gridMin[0], c->gridMin[1], c->gridMin[2] };
-        const double rhi[3] = { rlo[0] + ext, rlo[1] + ext, rlo[2] + ext };
-        screen_rectangle(f, P, rlo, rhi, r);
-        P.rootX0 = r[0]; P.rootY0 = r[1]; P.rootX1 = r[2]; P.rootY1 = r[3];
-        if (c->solidLo[0] > c->solidHi[0]) { P.solidX0 = P.solidY0 = 0; P.solidX1 = P.solidY1 = -1; }     // nothing solid: nothing to hit
-        else {
-            double slo[3], shi[3];
-            for (int a = 0; a < 3; a++) {
-                // widened by one voxel: the Marching-Cubes triangles of the surface cells (config 5) reach half a voxel beyond
-                // the solid leaves; one rectangle serves both paths
-                slo[a] = (double)c->gridMin[a] + (double)(c->solidLo[a] - 1) * (double)c->voxelSize;
-                shi[a] = (double)c->gridMin[a] + (double)(c->solidHi[a] + 1) * (double)c->voxelSize;
-            }
-            screen_rectangle(f, P, slo, shi, r);
-            P.solidX0 = std::max(r[0], P.rootX0); P.solidY0 = std::max(r[1], P.rootY0);
-            P.solidX1 = std::min(r[2], P.rootX1); P.solidY1 = std::min(r[3], P.rootY1);
-        }
+        int rr[4], sr[4];
+        frame_rectangles(bounds_of(c), f, P.tanHalfFov, rr, sr);
+        P.rootX0 = rr[0]; P.rootY0 = rr[1]; P.rootX1 = rr[2]; P.rootY1 = rr[3];
+        P.solidX0 = sr[0]; P.solidY0 = sr[1]; P.solidX1 = sr[2]; P.solidY1 = sr[3];
     }
     {   // project the centre of the solid geometry; any value is valid, it only orders the launch
         const rtmath::mat4 V = rtmath::mat4::from(f->view);
@@ -1856,4 +1885,5 @@ int rto_synchronize(rto_context* c) {
 
 }  // extern "C"
 
+#include "rto_split.inc"
 #include "rto_comm.inc"

@@ -2963,12 +2963,21 @@ __global__ __launch_bounds__(kBlock) void k_block_exclusive_scan(const int* __re
 // One block row per image row (the band arithmetic is per row, not per pixel), blockIdx.z = frame of the batch; a frame of
 // the batch starts srcFrameStride elements after the previous one inside every part, and dstFrameStride bytes after it in
 // the output.  HBM-bound: 16 B (4 B) read and 16 B written per pixel.
+// Row y of a frame cut into bands of bandRows rows, band b owned by part b % numParts: which part holds it and at which row of
+// that part's compact buffer (a part's bands lie back to back).  ONE definition for the assembly kernels and for the exported
+// planner (rto_split_row_source), which the multi-process tests drive.
+__host__ __device__ inline void band_row_source(int y, int numParts, int bandRows, int& part, int& localRow) {
+    const int gband = y / bandRows, r = y - gband * bandRows;
+    part = gband % numParts;
+    localRow = (gband / numParts) * bandRows + r;
+}
+
 __global__ void k_assemble(const float4* __restrict__ gathered, char* __restrict__ frames, size_t srcFrameStride, size_t dstFrameStride,
                            int W, int H, int numParts, int bandRows, size_t partStride) {
     const int y = blockIdx.y;
-    const int gband = y / bandRows, r = y - gband * bandRows;
-    const int part = gband % numParts, band = gband / numParts;
-    const float4* src = gathered + (size_t)blockIdx.z * srcFrameStride + (size_t)part * partStride + ((size_t)band * bandRows + r) * W;
+    int part, lrow;
+    band_row_source(y, numParts, bandRows, part, lrow);
+    const float4* src = gathered + (size_t)blockIdx.z * srcFrameStride + (size_t)part * partStride + (size_t)lrow * W;
     float4* dst = reinterpret_cast<float4*>(frames + (size_t)blockIdx.z * dstFrameStride) + (size_t)y * W;
     for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < W; x += gridDim.x * blockDim.x) store_pixel(dst + x, src[x]);
 }
@@ -2977,9 +2986,9 @@ __global__ void k_assemble(const float4* __restrict__ gathered, char* __restrict
 __global__ void k_assemble_shade(const float* __restrict__ gathered, char* __restrict__ frames, size_t srcFrameStride, size_t dstFrameStride,
                                  int W, int H, int numParts, int bandRows, size_t partStride) {
     const int y = blockIdx.y;
-    const int gband = y / bandRows, r = y - gband * bandRows;
-    const int part = gband % numParts, band = gband / numParts;
-    const float* src = gathered + (size_t)blockIdx.z * srcFrameStride + (size_t)part * partStride + ((size_t)band * bandRows + r) * W;
+    int part, lrow;
+    band_row_source(y, numParts, bandRows, part, lrow);
+    const float* src = gathered + (size_t)blockIdx.z * srcFrameStride + (size_t)part * partStride + (size_t)lrow * W;
     float4* dst = reinterpret_cast<float4*>(frames + (size_t)blockIdx.z * dstFrameStride) + (size_t)y * W;
     // consecutive lanes take consecutive pixels: 256 B read, 1 KB written per wave instruction, whole lines either way
     for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < W; x += gridDim.x * blockDim.x) store_pixel(dst + x, shade_color(src[x]));
@@ -3009,10 +3018,10 @@ __global__ void k_pack_columns(const float* __restrict__ src, float* __restrict_
 __global__ void k_assemble_shade_crop(const float* __restrict__ gathered, char* __restrict__ frames, CropInfo C, size_t dstFrameStride,
                                       int W, int H, int numParts, int bandRows, size_t partStride) {
     const int i = blockIdx.z, y = blockIdx.y;
-    const int gband = y / bandRows, r = y - gband * bandRows;
-    const int part = gband % numParts, band = gband / numParts;
+    int part, lrow;
+    band_row_source(y, numParts, bandRows, part, lrow);
     const int x0 = C.x0[i], w = C.w[i];
-    const float* src = gathered + (size_t)part * partStride + C.off[i] + ((size_t)band * bandRows + r) * w;
+    const float* src = gathered + (size_t)part * partStride + C.off[i] + (size_t)lrow * w;
     float4* dst = reinterpret_cast<float4*>(frames + (size_t)i * dstFrameStride) + (size_t)y * W;
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
         const unsigned rel = (unsigned)(x - x0);

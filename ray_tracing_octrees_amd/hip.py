@@ -33,7 +33,9 @@ SYMBOLS = (
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_debug_sort_violations", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
     "rto_comm_unique_id", "rto_comm_create", "rto_comm_create_all", "rto_comm_destroy", "rto_comm_last_error", "rto_comm_submit",
     "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_comm_debug_last_payload", "rto_render_triangles_batch_device",
+    "rto_scene_bounds_get", "rto_scene_bounds_of_nodes", "rto_split_plan_make", "rto_split_part_of_rank", "rto_split_rows_of_part", "rto_split_row_source",
 )
+SPLIT_MAX_FRAMES = 32
 COMM_ID_BYTES = 128
 RESIDENT_OCTREE, RESIDENT_TRIANGLES, RESIDENT_TRIANGLES_SHADOW = 0, 1, 2
 
@@ -61,6 +63,20 @@ class OctreeInfo(C.Structure):
     _fields_ = [("num_nodes", C.c_int64), ("num_internal", C.c_int64), ("root_size", C.c_int32),
                 ("depth", C.c_int32), ("canonical", C.c_int32), ("culling_active", C.c_int32),
                 ("visible_nodes", C.c_int64)]
+
+
+class SceneBounds(C.Structure):
+    """rto_scene_bounds: what the screen rectangles and the split plan need to know of a scene."""
+    _fields_ = [("grid_min", C.c_float * 3), ("voxel_size", C.c_float), ("root_size", C.c_int32),
+                ("solid_lo", C.c_int32 * 3), ("solid_hi", C.c_int32 * 3)]
+
+
+class SplitPlan(C.Structure):
+    """rto_split_plan (include/rto_hip.h): everything the ranks of a screen split must agree on."""
+    _fields_ = [("world", C.c_int32), ("band_rows", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("n_frames", C.c_int32),
+                ("render_parts", C.c_int32), ("first_render_rank", C.c_int32), ("rows_part0", C.c_int32), ("cropped", C.c_int32),
+                ("win_x0", C.c_int32 * SPLIT_MAX_FRAMES), ("win_w", C.c_int32 * SPLIT_MAX_FRAMES), ("win_off", C.c_int64 * SPLIT_MAX_FRAMES),
+                ("frame_floats", C.c_int64), ("full_floats", C.c_int64), ("pack_floats", C.c_int64)]
 
 
 _lib = None
@@ -153,6 +169,12 @@ def load():
     L.rto_render_triangles_batch_device.argtypes = [vp, C.POINTER(Frame), C.c_int, C.POINTER(Partition), C.c_int, C.c_int, vp, C.c_size_t, vp]
     L.rto_comm_stream.argtypes = [vp]
     L.rto_comm_stream.restype = vp
+    L.rto_scene_bounds_get.argtypes = [vp, C.POINTER(SceneBounds)]
+    L.rto_scene_bounds_of_nodes.argtypes = [vp, C.c_int64, C.POINTER(C.c_float), C.c_float, C.POINTER(SceneBounds)]
+    L.rto_split_plan_make.argtypes = [C.POINTER(SceneBounds), C.POINTER(Frame), C.c_int, C.c_int, C.c_int, C.POINTER(SplitPlan)]
+    L.rto_split_part_of_rank.argtypes = [C.POINTER(SplitPlan), C.c_int]
+    L.rto_split_rows_of_part.argtypes = [C.POINTER(SplitPlan), C.c_int]
+    L.rto_split_row_source.argtypes = [C.POINTER(SplitPlan), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -442,6 +464,11 @@ class Context:
         if n.value:
             self._check(self._L.rto_timing_read(self._h, out.ctypes.data, n.value, C.byref(n)))
         return out
+
+    def scene_bounds(self) -> SceneBounds:
+        b = SceneBounds()
+        self._check(self._L.rto_scene_bounds_get(self._h, C.byref(b)))
+        return b
 
     @property
     def stream(self) -> int:

@@ -110,6 +110,8 @@ def load():
     L.rtoh_rt_num_nodes.argtypes = [_vp]
     L.rtoh_rt_num_nodes.restype = C.c_int64
     L.rtoh_rt_framebuffer.argtypes = [_vp, _vp, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.rtoh_rt_finish.argtypes = [_vp]
+    L.rtoh_rt_finish.restype = None
     L.rtoh_rt_context.argtypes = [_vp]
     L.rtoh_rt_context.restype = _vp
     L.rtoh_rt_last_error.argtypes = [_vp]
@@ -363,6 +365,10 @@ class RayTracerBVH:
         out = np.empty((h.value, w.value, 4), np.float32)
         load().rtoh_rt_framebuffer(self._h, out.ctypes.data, out.size, C.byref(w), C.byref(h))
         return out
+
+    def finish(self):
+        """Wait for the GPU(s): the counterpart of glFinish for timing loops (renders are asynchronous)."""
+        load().rtoh_rt_finish(self._h)
 
     @property
     def numNodes(self) -> int:

@@ -169,6 +169,7 @@ int rtoh_rt_framebuffer(const RayTracerBVH* rt, float* out, int64_t capacityFloa
     if (out && capacityFloats >= (int64_t)fb.size()) std::memcpy(out, fb.data(), fb.size() * sizeof(float));
     return 1;
 }
+void rtoh_rt_finish(const RayTracerBVH* rt) { rt->finish(); }
 void* rtoh_rt_context(const RayTracerBVH* rt) { return rt->context(); }
 const char* rtoh_rt_last_error(const RayTracerBVH* rt) { return rt->lastError().c_str(); }
 

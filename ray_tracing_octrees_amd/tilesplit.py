@@ -1,272 +1,152 @@
-"""Screen-space split of one frame across the GPUs of a node + ONE gather for the final image.
+"""The split plan of the multi-GPU path, as seen from Python: a caller of the C ABI's planner.
 
-No reference counterpart (the reference is single-GPU).  Every rank holds the whole
-octree (<= 90 MB) and renders the bands `b % world == rank` of the image (bands of `band_rows` rows,
-round-robin so that the lit centre rows are spread over all ranks) into a compact buffer; a single
-`torch.distributed.gather` to rank 0 (RCCL over xGMI: 7 point-to-point links into the root) delivers the
-buffers, and rank 0 re-interleaves them with one kernel.
+The product's screen split lives below the C boundary (`rto_comm_*`, csrc/rto_comm.inc); everything its ranks must agree
+on -- who renders, which part a rank owns, the column window of every frame that travels, offsets and float counts -- is
+derived by ONE exported function, `rto_split_plan_make` (csrc/rto_split.inc, pure host arithmetic).  This module binds
+it and adds what a rehearsal WITHOUT GPUs needs on top: numpy statements of the two data-movement kernels
+(`k_pack_columns`, `k_assemble_shade_crop`) and the send/recv pattern of `comm_exchange` over any torch.distributed
+process group (gloo on CPU).  Nothing here decides anything about the split: every index comes out of the C functions,
+so `tests/_tilesplit_worker.py` (world 2, 3, 4, 5, 8 over gloo) exercises the planner the GPUs use.
 
-Two things keep the xGMI links and the root GPU off the critical path:
-  payload   "shade" (default): a part ships ONE float per pixel -- the Lambert term of the hit, -1 for a miss
-            (rto_render_shade_device) -- and rank 0 finishes the colour expression while it re-interleaves
-            (rto_assemble_shade_device): W*H*4/N bytes per link instead of W*H*16/N, bit-identical frame.
-            "rgba": the plain RGBA32F pixels (rto_render_device / rto_assemble_device).
-  pipeline  submit()/flush(): the gather of frame k runs on RCCL's stream while this rank already renders its
-            part of frame k+1 (double-buffered local buffers); render() is the one-frame-at-a-time form.
-
-The class is backend-agnostic so the rank/partition/gather logic can be exercised with gloo on CPU:
-  HipBackend     device buffers + the C ABI (the product path)
-  any object with the same three methods (tests supply a CPU stand-in)
+No reference counterpart: the reference is single-GPU.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+import ctypes as C
 
 import numpy as np
 
 from . import hip
 
-
-def partition_rows(height: int, num_parts: int, part: int, band_rows: int) -> int:
-    """Rows owned by `part` (same arithmetic as rto_partition_rows)."""
-    if num_parts <= 1:
-        return height
-    bands = (height + band_rows - 1) // band_rows
-    rows = 0
-    for b in range(part, bands, num_parts):
-        rows += min((b + 1) * band_rows, height) - b * band_rows
-    return rows
+F = np.float32
 
 
-def partition_row_map(height: int, num_parts: int, part: int, band_rows: int) -> np.ndarray:
-    """Global row index of every local row of `part`, in compact-buffer order."""
-    if num_parts <= 1:
-        return np.arange(height)
-    bands = (height + band_rows - 1) // band_rows
-    rows = []
-    for b in range(part, bands, num_parts):
-        rows.extend(range(b * band_rows, min((b + 1) * band_rows, height)))
-    return np.asarray(rows, dtype=np.int64)
+def scene_bounds_of_nodes(nodes: np.ndarray, grid_min, voxel_size) -> hip.SceneBounds:
+    """rto_scene_bounds_of_nodes: the bounds rto_upload_octree derives from a GPUNodes array (no GPU needed)."""
+    nodes = np.ascontiguousarray(nodes)
+    gm = (C.c_float * 3)(*[float(F(x)) for x in grid_min])
+    b = hip.SceneBounds()
+    rc = hip.load().rto_scene_bounds_of_nodes(nodes.ctypes.data, len(nodes), gm, float(F(voxel_size)), C.byref(b))
+    if rc != hip.RTO_OK:
+        raise hip.RtoError(rc, "rto_scene_bounds_of_nodes")
+    return b
 
 
-class HipBackend:
-    """Product backend: torch CUDA(HIP) tensors as device buffers, kernels through the C ABI on torch's
-    current stream (so RCCL collectives issued by torch order themselves behind the render)."""
+def make_plan(bounds: hip.SceneBounds, frames, world: int, band_rows: int = 16) -> hip.SplitPlan:
+    """rto_split_plan_make for a batch of frames (a list of hip.Frame)."""
+    arr = hip.Context.frame_array(list(frames))
+    plan = hip.SplitPlan()
+    rc = hip.load().rto_split_plan_make(C.byref(bounds), arr, len(arr), world, band_rows, C.byref(plan))
+    if rc != hip.RTO_OK:
+        raise hip.RtoError(rc, "rto_split_plan_make: frames of one batch share a positive width / height; band_rows % 8 == 0")
+    return plan
 
-    def __init__(self, ctx: hip.Context, triangles: bool = False, shadow: bool = True):
-        """triangles=True renders BASELINE config 5's path (leaf triangles + `shadow` ray; upload or build the triangle
-        buffer on every rank's context first) instead of the solid-leaf octree path."""
-        import torch
 
-        self.torch = torch
-        self.ctx = ctx
-        self.device = torch.device("cuda", ctx.device)
-        self.triangles = triangles
-        self.shadow = shadow
-        self._bound = 0
+def plan_bytes(plan: hip.SplitPlan) -> bytes:
+    """The plan as the bytes every rank must hold identically."""
+    return bytes(C.string_at(C.addressof(plan), C.sizeof(plan)))
 
-    def bind_stream(self):
-        """Look torch's current stream up once per batch (the lookup costs about as much as a kernel launch)."""
-        self._bound = self.torch.cuda.current_stream(self.device).cuda_stream
 
-    def _stream(self) -> int:
-        return self._bound
+def part_of_rank(plan: hip.SplitPlan, rank: int) -> int:
+    return hip.load().rto_split_part_of_rank(C.byref(plan), rank)
 
-    def empty(self, shape):
-        return self.torch.empty(shape, dtype=self.torch.float32, device=self.device)
 
-    def render_part(self, frame: hip.Frame, part: hip.Partition | None, out, payload: str = "rgba"):
-        if self.triangles:
-            if payload == "shade":
-                self.ctx.render_triangles_shade_device(frame, out.data_ptr(), self.shadow, part, self._stream())
+def rows_of_part(plan: hip.SplitPlan, part: int) -> int:
+    return hip.load().rto_split_rows_of_part(C.byref(plan), part)
+
+
+def row_sources(plan: hip.SplitPlan):
+    """(part, local_row) of every row of an assembled frame, from rto_split_row_source."""
+    L = hip.load()
+    part = np.empty(plan.height, np.int64)
+    local = np.empty(plan.height, np.int64)
+    p, r = C.c_int(), C.c_int()
+    for y in range(plan.height):
+        rc = L.rto_split_row_source(C.byref(plan), y, C.byref(p), C.byref(r))
+        if rc != hip.RTO_OK:
+            raise hip.RtoError(rc, "rto_split_row_source")
+        part[y], local[y] = p.value, r.value
+    return part, local
+
+
+def row_map(plan: hip.SplitPlan, part: int) -> np.ndarray:
+    """Global row of every local row of `part`, in compact-buffer order (the inverse of row_sources)."""
+    src_part, src_local = row_sources(plan)
+    rows = np.nonzero(src_part == part)[0]
+    out = np.empty(len(rows), np.int64)
+    out[src_local[rows]] = rows
+    return out
+
+
+# ---- numpy statements of the two data-movement kernels (host-staged rehearsal only) ---------------------------------
+def pack_columns(plan: hip.SplitPlan, local: np.ndarray) -> np.ndarray:
+    """k_pack_columns: local is [n_frames][rows_part0][width] float32 -> the packed part (pack_floats floats)."""
+    if not plan.cropped:
+        return np.ascontiguousarray(local, F).reshape(-1)
+    out = np.zeros(plan.pack_floats, F)
+    for i in range(plan.n_frames):
+        x0, w, off = plan.win_x0[i], plan.win_w[i], plan.win_off[i]
+        out[off: off + plan.rows_part0 * w] = local[i][:, x0: x0 + w].reshape(-1)
+    return out
+
+
+def shade_color(s: np.ndarray) -> np.ndarray:
+    """shade_color() of the kernels in float32, one rounding per operation: vec3(1, .8, .6) * term + .1, miss -> black."""
+    s = s.astype(F)
+    px = np.empty(s.shape + (4,), F)
+    px[..., 0] = F(1.0) * s + F(0.1)
+    px[..., 1] = F(0.8) * s + F(0.1)
+    px[..., 2] = F(0.6) * s + F(0.1)
+    px[..., 3] = F(1.0)
+    px[s < 0] = (0.0, 0.0, 0.0, 1.0)
+    return px
+
+
+def assemble(plan: hip.SplitPlan, gathered: np.ndarray) -> np.ndarray:
+    """k_assemble_shade_crop / k_assemble_shade: gathered is [render_parts][pack_floats] float32 as rank 0 receives it ->
+    [n_frames][height][width][4] RGBA32F."""
+    src_part, src_local = row_sources(plan)
+    W, H = plan.width, plan.height
+    out = np.empty((plan.n_frames, H, W, 4), F)
+    for i in range(plan.n_frames):
+        shade = np.full((H, W), F(-1.0), F)                      # outside the window: background (kShadeMiss)
+        if plan.cropped:
+            x0, w, off = plan.win_x0[i], plan.win_w[i], plan.win_off[i]
+            for y in range(H):
+                a = off + src_local[y] * w
+                shade[y, x0: x0 + w] = gathered[src_part[y], a: a + w]
+        else:
+            for y in range(H):
+                a = i * plan.frame_floats + src_local[y] * W
+                shade[y] = gathered[src_part[y], a: a + W]
+        out[i] = shade_color(shade)
+    return out
+
+
+def exchange(plan: hip.SplitPlan, rank: int, packed, group=None):
+    """comm_exchange over a torch.distributed group, staged through host tensors: every rendering rank sends pack_floats
+    floats to rank 0; rank 0 receives part p at offset p * pack_floats.  Returns [render_parts][pack_floats] on rank 0."""
+    import torch
+    import torch.distributed as dist
+
+    count = int(plan.pack_floats)
+    mine = part_of_rank(plan, rank)
+    gathered = None
+    reqs = []
+    if rank == 0:
+        gathered = torch.zeros((plan.render_parts, count), dtype=torch.float32)
+        for r in range(plan.world):
+            p = part_of_rank(plan, r)
+            if p < 0:
+                continue                                          # the gatherer itself ships nothing
+            if r == 0:
+                gathered[p].copy_(torch.from_numpy(np.ascontiguousarray(packed, F)))
             else:
-                self.ctx.render_triangles_device(frame, out.data_ptr(), self.shadow, part, self._stream())
-        elif payload == "shade":
-            self.ctx.render_shade_device(frame, out.data_ptr(), part, self._stream())
-        else:
-            self.ctx.render_device(frame, out.data_ptr(), part, self._stream())
-
-    def render_parts(self, frames, part: hip.Partition, local, payload: str):
-        """All frames of a batch with one call through the C ABI (octree path): local is [batch][rows][width(,4)]."""
-        if self.triangles:
-            for f, frame in enumerate(frames):
-                self.render_part(frame, part, local[f], payload)
-            return
-        arr = hip.Context.frame_array(frames)
-        self.ctx.render_batch_device(arr, local.data_ptr(), local.stride(0) * 4, part, payload == "shade", self._stream())
-
-    def assemble_all(self, frames, part0: hip.Partition, gathered, out_frames, payload: str):
-        arr = hip.Context.frame_array(frames)
-        self.ctx.assemble_batch_all_device(arr, part0, gathered.data_ptr(), payload == "shade", out_frames.data_ptr(),
-                                           out_frames.stride(0) * 4, self._stream())
-
-    def assemble(self, frame: hip.Frame, part0: hip.Partition, gathered, out, payload: str = "rgba", batch: int = 1, index: int = 0):
-        """Frame `index` of a gather that carried `batch` frames per rank: gathered is [rank][batch][rows][width(,4)]."""
-        self.ctx.assemble_batch_device(frame, part0, gathered.data_ptr(), batch, index, payload == "shade", out.data_ptr(), self._stream())
-
-
-@dataclass
-class _Buffers:
-    key: tuple
-    local: list          # two compact part buffers [batch][rows][width(,4)] (double-buffered for the pipelined form)
-    gathered: object     # rank 0: world x that, as the gather delivers them
-    frames: object       # rank 0: the assembled RGBA32F frames [batch][H][W][4]
-
-
-@dataclass
-class _InFlight:
-    work: object         # the gather's Work handle
-    frames: list         # the hip.Frame of every image in the batch
-    keep: object         # tensors that must outlive the gather
-
-
-class TileSplitRenderer:
-    """Renders frames cooperatively; rank 0 gets the (H, W, 4) images, the others None.
-
-    render(frame)               one frame at a time (everything stream-ordered, no host sync)
-    submit(frame) / flush()     pipelined: submit(k) returns the image of frame k-1 (None for the first call),
-                                flush() the last one; a returned tensor is overwritten by the next assemble
-    submit_batch(frames) / flush_batch() / render_batch(frames)
-                                the same with SEVERAL consecutive frames per collective: every rank renders its part of
-                                each frame of the batch, ONE gather ships them all ([rank][batch][rows][width]), rank 0
-                                assembles each.  Fewer, larger collectives: the host cost of a torch.distributed call
-                                (tens of microseconds, comparable to a whole 1080p frame) is paid once per batch.
-
-    `stage_through_host=True` moves the gather payload through CPU tensors: only for rehearsing the multi-rank
-    path with the gloo backend (e.g. several ranks sharing one GPU); the product path gathers device to device.
-    `force_collective=True` walks the multi-rank path with a one-rank group (exercising it on a single GPU)."""
-
-    def __init__(self, backend, rank: int, world_size: int, band_rows: int = 16, group=None, stage_through_host: bool = False,
-                 payload: str = "shade", force_collective: bool = False):
-        if band_rows <= 0 or band_rows % 8:
-            raise ValueError("band_rows must be a positive multiple of 8")
-        if payload not in ("shade", "rgba"):
-            raise ValueError("payload must be 'shade' or 'rgba'")
-        self.backend = backend
-        self.rank = rank
-        self.world = world_size
-        self.band_rows = band_rows
-        self.group = group
-        self.stage_through_host = stage_through_host
-        self.payload = payload
-        self.single = world_size == 1 and not force_collective     # then frames are rendered straight into place
-        self._buf: _Buffers | None = None
-        self._seq = 0
-        self._inflight: _InFlight | None = None
-        self._part = hip.Partition(self.world, self.rank, self.band_rows)
-        self._part0 = hip.Partition(self.world, 0, self.band_rows)
-
-    def partition(self, part: int | None = None) -> hip.Partition:
-        return hip.Partition(self.world, self.rank if part is None else part, self.band_rows)
-
-    def _part_shape(self, batch: int, rows: int, width: int) -> tuple:
-        return (batch, rows, width) if self.payload == "shade" else (batch, rows, width, 4)
-
-    def _buffers(self, frame: hip.Frame, batch: int) -> _Buffers:
-        key = (frame.width, frame.height, batch)
-        if self._buf is None or self._buf.key != key:
-            if self._inflight is not None:
-                raise RuntimeError("frame size or batch size changed with frames in flight: call flush() first")
-            gathered = frms = None
-            local = []
-            if self.rank == 0:
-                frms = self.backend.empty((batch, frame.height, frame.width, 4))
-            if not self.single:
-                rows0 = partition_rows(frame.height, self.world, 0, self.band_rows)   # part 0 owns the most rows
-                local = [self.backend.empty(self._part_shape(batch, rows0, frame.width)) for _ in range(2)]
-                if self.rank == 0:
-                    gathered = self.backend.empty((self.world,) + self._part_shape(batch, rows0, frame.width))
-                    self._gather_list = [gathered[i] for i in range(self.world)]
-            self._buf = _Buffers(key, local, gathered, frms)
-        return self._buf
-
-    # ---- the three steps of a batch ---------------------------------------------------------------
-    def _issue_gather(self, b: _Buffers, local, frames) -> _InFlight:
-        import torch.distributed as dist
-
-        if self.stage_through_host:
-            src = local.cpu()
-            parts = [src.new_empty(src.shape) for _ in range(self.world)] if self.rank == 0 else None
-            work = dist.gather(src, parts, dst=0, group=self.group, async_op=True)
-            return _InFlight(work, frames, (src, parts))
-        parts = self._gather_list if self.rank == 0 else None
-        work = dist.gather(local, parts, dst=0, group=self.group, async_op=True)
-        return _InFlight(work, frames, (local, parts))
-
-    def _complete(self, b: _Buffers, fl: _InFlight):
-        fl.work.wait()          # RCCL: the current stream waits for the gather; gloo: the host does
-        if self.rank != 0:
-            return None
-        if self.stage_through_host:
-            for i, p in enumerate(fl.keep[1]):
-                b.gathered[i].copy_(p)
-        n = len(fl.frames)
-        if hasattr(self.backend, "assemble_all"):
-            self.backend.assemble_all(fl.frames, self._part0, b.gathered, b.frames, self.payload)
-        else:
-            for f, frame in enumerate(fl.frames):
-                self.backend.assemble(frame, self._part0, b.gathered, b.frames[f], self.payload, batch=b.key[2], index=f)
-        return [b.frames[f] for f in range(n)]
-
-    # ---- public: batches ----------------------------------------------------------------------------
-    def submit_batch(self, frames):
-        """Render this rank's part of every frame, complete the previous batch (its gather ran meanwhile), start this
-        batch's gather.  Returns the previous batch's images on rank 0 (None on the first call / other ranks).  Every
-        call must carry the same number of frames until flush_batch()."""
-        frames = list(frames)
-        if not frames:
-            raise ValueError("submit_batch: no frames")
-        b = self._buffers(frames[0], len(frames))
-        if hasattr(self.backend, "bind_stream"):
-            self.backend.bind_stream()
-        if self.single:
-            for f, frame in enumerate(frames):
-                self.backend.render_part(frame, None, b.frames[f], "rgba")
-            self._single_last = len(frames)
-            return [b.frames[f] for f in range(len(frames))]
-        local = b.local[self._seq % 2]
-        self._seq += 1
-        if hasattr(self.backend, "render_parts"):               # overlaps the gather in flight
-            self.backend.render_parts(frames, self._part, local, self.payload)
-        else:
-            for f, frame in enumerate(frames):
-                self.backend.render_part(frame, self._part, local[f], self.payload)
-        done = None
-        if self._inflight is not None:
-            done = self._complete(b, self._inflight)            # ... and only now waits for it
-            self._inflight = None
-        self._inflight = self._issue_gather(b, local, frames)
-        return done
-
-    def flush_batch(self):
-        if self.single:
-            if self._buf is None:
-                return None
-            return [self._buf.frames[f] for f in range(getattr(self, "_single_last", 1))]
-        if self._inflight is None:
-            return None
-        fl, self._inflight = self._inflight, None
-        if hasattr(self.backend, "bind_stream"):
-            self.backend.bind_stream()
-        return self._complete(self._buf, fl)
-
-    def render_batch(self, frames):
-        if self._inflight is not None:
-            raise RuntimeError("render with pipelined frames in flight: call flush() first")
-        self.submit_batch(frames)
-        return self.flush_batch()
-
-    # ---- public: one frame per collective -------------------------------------------------------------
-    def submit(self, frame: hip.Frame):
-        out = self.submit_batch([frame])
-        return None if out is None else out[0]
-
-    def flush(self):
-        out = self.flush_batch()
-        return None if out is None else out[-1]
-
-    def render(self, frame: hip.Frame):
-        if self._inflight is not None:
-            raise RuntimeError("render() with a pipelined frame in flight: call flush() first")
-        self.submit(frame)
-        return self.flush()
+                reqs.append(dist.irecv(gathered[p], src=r, group=group))
+    elif mine >= 0:
+        t = torch.from_numpy(np.ascontiguousarray(packed, F))
+        assert t.numel() == count, "a rank ships exactly the plan's pack_floats"
+        reqs.append(dist.isend(t, dst=0, group=group))
+    for q in reqs:
+        q.wait()
+    return None if gathered is None else gathered.numpy()

@@ -1,0 +1,59 @@
+"""Worker for test_partial_allocation_failures_leave_nothing_behind: run with RTO_FAULT_ALLOC=<k> in the environment, which
+makes the k-th buffer allocation of the frustum update / of rto_comm fail (fallible_malloc in csrc/rto_api.hip).  The call
+that hits the failure must report it; the same call repeated must then succeed from scratch and render the oracle's frame
+(all-or-nothing clean-up: no half-allocated state survives)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import ray_tracing_octrees_amd as rto  # noqa: E402
+from oracle import orc  # noqa: E402
+from ray_tracing_octrees_amd import hip  # noqa: E402
+
+
+def main():
+    what = sys.argv[1]
+    W, H = 160, 96
+    g = orc.test_sphere_grid(32)
+    nodes = orc.build_flat_octree(g)
+    cam = orc.Camera(0.5, 0.7, 1.8)
+    want, _ = orc.render(nodes, g.min, g.voxel_size, cam.get_view(), cam.get_pos(), W / H, 45.0, W, H)
+    f = rto.make_frame(cam.get_view(), cam.get_pos(), W / H, 45.0, W, H)
+    ctx = rto.Context(0)
+    ctx.upload_octree(nodes, g.min, g.voxel_size)
+    failed = 0
+    if what == "frustum":
+        for attempt in range(2):
+            try:
+                ctx.update_frustum(cam.get_view(), 45.0, W / H, True)
+                break
+            except rto.RtoError as e:
+                assert "allocation" in str(e), str(e)
+                failed += 1
+        got = ctx.render_host(f)
+    else:
+        comm = hip.Comm(ctx, 1, 0, hip.comm_unique_id(), band_rows=16)
+        out = torch.full((H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+        arr = hip.Context.frame_array([f])
+        for attempt in range(2):
+            try:
+                comm.submit(arr, out.data_ptr(), 0)
+                comm.flush()
+                break
+            except rto.RtoError as e:
+                assert "allocation" in str(e), str(e)
+                failed += 1
+        got = out.cpu().numpy()
+        comm.close()
+    ok = failed == 1 and got.tobytes() == np.ascontiguousarray(want, np.float32).tobytes()
+    print(f"fault worker {what}: failed calls {failed}, frame {'ok' if got.tobytes() == want.tobytes() else 'WRONG'}")
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

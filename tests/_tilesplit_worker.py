@@ -1,6 +1,12 @@
-"""Worker for test_tilesplit_gloo.py: run under torch.distributed.run with the gloo backend (CPU).
-The TileSplitRenderer logic (partition, single gather, rank-0 reassembly) is the product's; the pixel
-producer is a CPU stand-in backed by the oracle, because there is no GPU here."""
+"""Worker for test_tilesplit_gloo.py: run under torch.distributed.run with the gloo backend (CPU, no GPU).
+
+What is under test is the PRODUCT's split arithmetic: every rank calls the C ABI's planner (rto_split_plan_make,
+rto_split_part_of_rank, rto_split_row_source -- csrc/rto_split.inc, the functions rto_comm_* itself uses) on its own copy
+of the frames and the scene bounds; the ranks compare their plans byte for byte, then ship exactly the plan's float
+counts to rank 0 with the send/recv pattern of comm_exchange, and rank 0 re-interleaves with the plan's offsets.  The
+assembled frames must be the oracle's, bit for bit.  The pixel producer is a CPU stand-in backed by the oracle (there is
+no GPU here); packing and assembly are the numpy statements of k_pack_columns / k_assemble_shade_crop in
+ray_tracing_octrees_amd.tilesplit."""
 import os
 import sys
 
@@ -14,63 +20,54 @@ sys.path.insert(0, ROOT)
 from oracle import orc  # noqa: E402
 from ray_tracing_octrees_amd import hip, tilesplit  # noqa: E402
 
-
 F = np.float32
 
 
-def decode_shade(s: np.ndarray) -> np.ndarray:
-    """numpy statement of the kernels' shade_color(): float32 operations, one rounding each."""
-    s = s.astype(np.float32)
-    px = np.empty(s.shape + (4,), np.float32)
-    px[..., 0] = F(1.0) * s + F(0.1)
-    px[..., 1] = F(0.8) * s + F(0.1)
-    px[..., 2] = F(0.6) * s + F(0.1)
-    px[..., 3] = F(1.0)
-    px[s < 0] = (0.0, 0.0, 0.0, 1.0)
-    return px
-
-
 def encode_shade(rgba: np.ndarray) -> np.ndarray:
-    """The oracle only produces pixels; recover a Lambert term that decodes to exactly those pixels
-    (search a few ulps around r - 0.1).  Test scaffolding for the CPU stand-in only."""
-    r = rgba[..., 0]
-    out = np.full(r.shape, -1.0, np.float32)
-    hit = ~((rgba[..., 0] == 0) & (rgba[..., 1] == 0) & (rgba[..., 2] == 0))
-    todo = hit.copy()
-    guess = np.maximum(r - F(0.1), F(0.0)).astype(np.float32)
-    for k in range(-8, 9):
-        cand = (guess.view(np.int32) + k).view(np.float32)
-        cand = np.where(cand >= 0, cand, F(0.0)).astype(np.float32)
-        ok = todo & (decode_shade(cand) == rgba).all(axis=-1)
-        out[ok] = cand[ok]
-        todo &= ~ok
-    assert not todo.any(), "stand-in could not encode a pixel"
+    """The oracle only produces pixels; recover a Lambert term that decodes to exactly those pixels: each channel
+    fl(fl(k * s) + 0.1) is monotone in s >= 0, so the terms that decode to a given channel value form an interval of float
+    bit patterns (found by bisection); any term in the intersection of the three intervals will do.  Test scaffolding for
+    the CPU stand-in only."""
+    shape = rgba.shape[:-1]
+    px = np.ascontiguousarray(rgba, F).reshape(-1, 4)
+    hit = ~((px[:, 0] == 0) & (px[:, 1] == 0) & (px[:, 2] == 0))
+    out = np.full(len(px), -1.0, F)
+    t = px[hit]
+    lo_all = np.zeros(len(t), np.int64)
+    hi_all = np.full(len(t), 0x40000000, np.int64)                 # bit pattern of 2.0f: terms lie in [0, 1]
+    for c, k in enumerate((F(1.0), F(0.8), F(0.6))):
+        def first_where(pred):                                        # smallest bit pattern b in [0, 2.0f] with pred(float(b))
+            lo = np.zeros(len(t), np.int64)
+            hi = np.full(len(t), 0x40000000, np.int64)
+            while (lo < hi).any():
+                mid = (lo + hi) // 2
+                val = (k * mid.astype(np.uint32).view(F)).astype(F) + F(0.1)
+                ok = pred(val)
+                hi = np.where(ok & (lo < hi), mid, hi)
+                lo = np.where(~ok & (lo < hi), mid + 1, lo)
+            return lo
+        lo_all = np.maximum(lo_all, first_where(lambda v: v >= t[:, c]))
+        hi_all = np.minimum(hi_all, first_where(lambda v: v > t[:, c]))
+    assert (lo_all < hi_all).all(), "stand-in could not encode a pixel"
+    out[hit] = lo_all.astype(np.uint32).view(F)
+    out = out.reshape(shape)
+    assert (tilesplit.shade_color(out) == np.asarray(rgba, F)).all()
     return out
 
 
-class OracleBackend:
-    def __init__(self, nodes, gmin, voxel):
-        self.nodes, self.gmin, self.voxel = nodes, gmin, voxel
-
-    def empty(self, shape):
-        return torch.full(shape, -7.0, dtype=torch.float32)
-
-    def render_part(self, frame, part, out, payload="rgba"):
-        view = np.array(list(frame.view), np.float32)
-        pos = np.array(list(frame.cam_pos), np.float32)
-        W, H = frame.width, frame.height
-        rows = tilesplit.partition_row_map(H, part.num_parts, part.part, part.band_rows) if part else np.arange(H)
-        full = np.zeros((H, W, 4), np.float32)
-        for y in rows:      # only the rows this part owns are traced
-            orc.render(self.nodes, self.gmin, self.voxel, view, pos, frame.aspect, frame.fov_deg, W, H, rows=(int(y), int(y) + 1), out=full)
-        mine = full[rows]
-        out[: len(rows)] = torch.from_numpy(encode_shade(mine) if payload == "shade" else mine)
-
-    def assemble(self, frame, part0, gathered, out, payload="rgba", batch=1, index=0):
-        for p in range(part0.num_parts):
-            rows = tilesplit.partition_row_map(frame.height, part0.num_parts, p, part0.band_rows)
-            g = gathered[p][index][: len(rows)]
-            out[torch.from_numpy(rows)] = torch.from_numpy(decode_shade(g.numpy())) if payload == "shade" else g
+def render_part(scene, frames, plan, part):
+    """[n_frames][rows_part0][width] Lambert terms of `part`: only its rows are traced (rows beyond its own stay 0: padding)."""
+    nodes, gmin, voxel = scene
+    rows = tilesplit.row_map(plan, part)
+    local = np.zeros((plan.n_frames, plan.rows_part0, plan.width), F)
+    for i, fr in enumerate(frames):
+        view = np.array(list(fr.view), F)
+        pos = np.array(list(fr.cam_pos), F)
+        full = np.zeros((plan.height, plan.width, 4), F)
+        for y in rows:
+            orc.render(nodes, gmin, voxel, view, pos, fr.aspect, fr.fov_deg, plan.width, plan.height, rows=(int(y), int(y) + 1), out=full)
+        local[i, : len(rows)] = encode_shade(full[rows])
+    return local
 
 
 def main():
@@ -78,84 +75,73 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     g = orc.test_sphere_grid(16)
     nodes = orc.build_flat_octree(g)
+    scene = (nodes, g.min, g.voxel_size)
+    bounds = tilesplit.scene_bounds_of_nodes(nodes, g.min, g.voxel_size)
     ok = True
-    for (W, H, band, payload) in ((64, 48, 8, "shade"), (50, 37, 16, "rgba"), (40, 100, 24, "shade")):
-        cam = orc.Camera(0.5, 0.7, 1.8)
-        frame = hip.make_frame(cam.get_view(), cam.get_pos(), W / H, 45.0, W, H)
-        r = tilesplit.TileSplitRenderer(OracleBackend(nodes, g.min, g.voxel_size), rank, world, band_rows=band, payload=payload)
-        img = r.render(frame)
-        rows_all = sum(tilesplit.partition_rows(H, world, p, band) for p in range(world))
-        ok &= rows_all == H
-        ok &= tilesplit.partition_rows(H, world, rank, band) == len(tilesplit.partition_row_map(H, world, rank, band))
-        if rank == 0:
-            want, _ = orc.render(nodes, g.min, g.voxel_size, cam.get_view(), cam.get_pos(), W / H, 45.0, W, H)
-            ok &= img is not None and img.numpy().tobytes() == want.tobytes()
-        else:
-            ok &= img is None
-        # pipelined form: 4 different cameras; submit(k) hands back frame k-1, flush() the last one
-        cams = [orc.Camera(0.5 + 0.4 * k, 0.7 + 0.1 * k, 1.8 + 0.2 * k) for k in range(4)]
-        got = []
-        for c in cams:
-            out = r.submit(hip.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H))
-            got.append(None if out is None else out.numpy().copy())
-        last = r.flush()
-        got.append(None if last is None else last.numpy().copy())
-        ok &= got[0] is None and r.flush() is None
-        for k, c in enumerate(cams):
-            if rank == 0:
-                want, _ = orc.render(nodes, g.min, g.voxel_size, c.get_view(), c.get_pos(), W / H, 45.0, W, H)
-                ok &= got[k + 1] is not None and got[k + 1].tobytes() == want.tobytes()
-            else:
-                ok &= got[k + 1] is None
-        # two pipelines taking the frames in turn (what bench.py does for N > 1): their collectives interleave in the
-        # same order on every rank and never touch each other's buffers
-        pair = [tilesplit.TileSplitRenderer(OracleBackend(nodes, g.min, g.voxel_size), rank, world, band_rows=band, payload=payload)
-                for _ in range(2)]
-        cams2 = [orc.Camera(0.3 + 0.5 * k, 0.6, 1.7 + 0.1 * k) for k in range(5)]
-        got2 = {}
-        for k, c in enumerate(cams2):
-            out = pair[k % 2].submit(hip.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H))
-            if k >= 2:
-                got2[k - 2] = None if out is None else out.numpy().copy()
-        for i in range(2):
-            k_last = max(k for k in range(len(cams2)) if k % 2 == i)
-            out = pair[i].flush()
-            got2[k_last] = None if out is None else out.numpy().copy()
-        for k, c in enumerate(cams2):
-            if rank == 0:
-                want, _ = orc.render(nodes, g.min, g.voxel_size, c.get_view(), c.get_pos(), W / H, 45.0, W, H)
-                ok &= got2[k] is not None and got2[k].tobytes() == want.tobytes()
-            else:
-                ok &= got2[k] is None
-        # several frames per collective: batches of 3 cameras, pipelined (submit_batch hands back the previous batch)
-        rb = tilesplit.TileSplitRenderer(OracleBackend(nodes, g.min, g.voxel_size), rank, world, band_rows=band, payload=payload)
-        cams3 = [orc.Camera(0.2 + 0.3 * k, 0.65 + 0.02 * k, 1.75) for k in range(9)]
-        frames3 = [hip.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H) for c in cams3]
-        outs = []
-        for bi in range(3):
-            o = rb.submit_batch(frames3[3 * bi: 3 * bi + 3])
-            outs.append(None if o is None else [t.numpy().copy() for t in o])
-        o = rb.flush_batch()
-        outs.append(None if o is None else [t.numpy().copy() for t in o])
-        ok &= outs[0] is None and rb.flush_batch() is None
-        for bi in range(3):
-            for f in range(3):
-                c = cams3[3 * bi + f]
-                if rank == 0:
-                    want, _ = orc.render(nodes, g.min, g.voxel_size, c.get_view(), c.get_pos(), W / H, 45.0, W, H)
-                    ok &= outs[bi + 1] is not None and outs[bi + 1][f].tobytes() == want.tobytes()
-                else:
-                    ok &= outs[bi + 1] is None
-        one = rb.render_batch(frames3[:3])                       # unpipelined batch
-        if rank == 0:
-            want, _ = orc.render(nodes, g.min, g.voxel_size, cams3[2].get_view(), cams3[2].get_pos(), W / H, 45.0, W, H)
-            ok &= one is not None and len(one) == 3 and one[2].numpy().tobytes() == want.tobytes()
-        try:                    # mixing the two forms with a frame in flight is refused
-            r.submit(frame)
-            r.render(frame)
+    why = []
+
+    def check(cond, msg):
+        nonlocal ok
+        if not cond:
             ok = False
-        except RuntimeError:
-            r.flush()
+            why.append(msg)
+
+    # (W, H, band rows, cameras of the batch).  Cameras: centred, sphere partly off-screen, looking away (token window),
+    # close up (window = whole width); batches of 1, 2 and 4 frames; heights that are no multiple of the band.
+    away = orc.Camera(0.5, 0.7, 1.8)
+    away.set_target(40.0, 0.0, 40.0)
+    side = orc.Camera(0.5, 0.7, 1.8)
+    side.set_target(0.55, 0.1, 0.0)
+    cases = (
+        (64, 48, 8, [orc.Camera(0.5, 0.7, 1.8)]),
+        (50, 37, 16, [orc.Camera(0.9, 0.6, 2.4), side]),
+        (40, 100, 24, [orc.Camera(0.2, 0.65, 1.75), away, orc.Camera(0.5, 0.7, 0.9), orc.Camera(1.4, 0.75, 3.0)]),
+    )
+    for (W, H, band, cams) in cases:
+        frames = [hip.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H) for c in cams]
+        plan = tilesplit.make_plan(bounds, frames, world, band)
+        # 1. every rank derived the same plan from its own copy of the inputs
+        mine = np.frombuffer(tilesplit.plan_bytes(plan), np.uint8).copy()
+        allp = [torch.zeros(len(mine), dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(allp, torch.from_numpy(mine))
+        check(all(bytes(p.numpy()) == bytes(mine) for p in allp), f"{W}x{H}: plans differ between ranks")
+        # 2. the plan is a partition: every row comes from exactly one (part, local row), parts are contiguous from 0
+        src_part, src_local = tilesplit.row_sources(plan)
+        check(plan.render_parts == (world - 1 if world >= 4 else world), "render_parts")
+        check(tilesplit.part_of_rank(plan, 0) == (-1 if world >= 4 else 0), "rank 0 gathers only from 4 ranks on")
+        seen = set()
+        for p in range(plan.render_parts):
+            rows = tilesplit.row_map(plan, p)
+            check(len(rows) == tilesplit.rows_of_part(plan, p) <= plan.rows_part0, "rows of a part")
+            check(np.array_equal(src_local[rows], np.arange(len(rows))), "local rows of a part are 0..n-1 in global order")
+            seen.update(int(y) for y in rows)
+        check(seen == set(range(H)), "the parts cover every row exactly once")
+        check(plan.cropped == 1 and plan.pack_floats == sum(plan.rows_part0 * plan.win_w[i] for i in range(len(cams))), "pack_floats")
+        for i in range(len(cams)):
+            check(0 <= plan.win_x0[i] and plan.win_x0[i] + plan.win_w[i] <= W and plan.win_w[i] > 0, "window inside the frame")
+        # 3. render my part, pack the plan's windows, exchange the plan's counts, assemble with the plan's offsets
+        part = tilesplit.part_of_rank(plan, rank)
+        packed = None
+        if part >= 0:
+            local = render_part(scene, frames, plan, part)
+            packed = tilesplit.pack_columns(plan, local)
+            check(packed.size == plan.pack_floats, "a rank ships exactly pack_floats floats")
+        gathered = tilesplit.exchange(plan, rank, packed)
+        if rank == 0:
+            imgs = tilesplit.assemble(plan, gathered)
+            for i, c in enumerate(cams):
+                want, _ = orc.render(nodes, g.min, g.voxel_size, c.get_view(), c.get_pos(), W / H, 45.0, W, H)
+                check(imgs[i].tobytes() == np.ascontiguousarray(want, F).tobytes(), f"{W}x{H} band {band} frame {i}: assembled frame differs from the oracle")
+        else:
+            check(gathered is None, "only rank 0 receives")
+    # a batch too large for the window table ships whole rows: same counts on every rank
+    W, H = 24, 16
+    c0 = orc.Camera(0.5, 0.7, 1.8)
+    many = [hip.make_frame(c0.get_view(), c0.get_pos(), W / H, 45.0, W, H)] * (hip.SPLIT_MAX_FRAMES + 1)
+    plan = tilesplit.make_plan(bounds, many, world, 8)
+    check(plan.cropped == 0 and plan.pack_floats == plan.full_floats == plan.rows_part0 * W * len(many), "uncropped batch")
+    if why:
+        print(f"rank {rank}: " + "; ".join(why[:5]), file=sys.stderr, flush=True)
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()

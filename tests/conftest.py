@@ -128,3 +128,13 @@ def assert_bit_exact(got: np.ndarray, want: np.ndarray, what: str = ""):
         bad = int(neq.reshape(neq.shape[0], neq.shape[1], -1).any(axis=-1).sum()) if neq.ndim == 3 else int(neq.sum())
         raise AssertionError(f"{what}: {bad} elements differ bitwise, max abs diff "
                              f"{np.nanmax(np.abs(got.astype(np.float64) - want.astype(np.float64))):g}")
+
+
+def partition_row_map(height: int, num_parts: int, part: int, band_rows: int) -> np.ndarray:
+    """Test helper: global row of every local row of part `part` of an rto_partition (bands of band_rows rows, band b
+    owned by part b % num_parts, a part's bands back to back) -- the definition in include/rto_hip.h, stated independently
+    of the library to check partial renders against rows of the oracle's frame."""
+    if num_parts <= 1:
+        return np.arange(height)
+    rows = [y for y in range(height) if (y // band_rows) % num_parts == part]
+    return np.asarray(rows, dtype=np.int64)

@@ -12,7 +12,7 @@ import pytest
 
 import ray_tracing_octrees_amd as rto
 from ray_tracing_octrees_amd import hip
-from conftest import Scene, assert_bit_exact
+from conftest import Scene, assert_bit_exact, partition_row_map
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
@@ -528,9 +528,8 @@ def test_partitions_assemble_to_the_full_frame(ctx, orc, scenes, camera):
 def test_shade_payload_assembles_to_the_same_frame(ctx, orc, scenes, camera):
     """The 4-byte multi-GPU payload: every kernel writes the Lambert term (-1 = miss) per pixel of its part,
     rto_assemble_shade_device finishes the colour expression while re-interleaving -- bit-identical to the
-    RGBA32F path and to the oracle, whole-frame and split 2/3/8 ways; also through the TileSplitRenderer."""
+    RGBA32F path and to the oracle, whole-frame and split 2/3/8 ways."""
     torch = pytest.importorskip("torch")
-    from ray_tracing_octrees_amd import tilesplit
 
     for scene, cam in (("sphere64", "sphere"), ("calgary", "calgary_oblique")):
         s = scenes(scene)
@@ -555,12 +554,6 @@ def test_shade_payload_assembles_to_the_same_frame(ctx, orc, scenes, camera):
                     hit = want[..., 0] != 0
                     assert ((sh == -1.0) == ~hit).all() and (sh[hit] >= 0).all()
         ctx.set_kernel(rto.KERNEL_AUTO)
-        # world size 1 through the renderer class (no process group needed): both payload settings give the frame
-        for payload in ("shade", "rgba"):
-            r = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), 0, 1, payload=payload)
-            img = r.render(f)
-            torch.cuda.synchronize()
-            assert_bit_exact(img.cpu().numpy(), want, f"{scene} TileSplitRenderer world 1 {payload}")
 
 
 @pytest.mark.parametrize("scene,cam0,dtheta", [("sphere64", (0.5, 0.7, 1.8), 0.21), ("calgary", (0.6, 0.5, 3500.0), 0.35)])
@@ -594,8 +587,7 @@ def test_temporal_launch_order_is_only_a_schedule(ctx, orc, scenes, scene, cam0,
                         pb = torch.full((rows, W, 4), 7.0, dtype=torch.float32, device="cuda")
                         ctx.render_device(f, pb.data_ptr(), part)
                         ctx.synchronize()
-                        from ray_tracing_octrees_amd import tilesplit
-                        assert_bit_exact(pb.cpu().numpy(), want[tilesplit.partition_row_map(H, 2, 1, 16)], f"{scene} part 1/2 mid-sequence")
+                        assert_bit_exact(pb.cpu().numpy(), want[partition_row_map(H, 2, 1, 16)], f"{scene} part 1/2 mid-sequence")
         # caller-supplied tables: reversed and random permutations
         W, H = 400, 240
         c = orc.Camera(*cam0)
@@ -822,10 +814,8 @@ def test_frames_captured_in_a_hip_graph_replay_exactly(ctx, orc, scenes):
 
 def test_batched_gather_layout_assembles_every_frame(ctx, orc, scenes):
     """Several frames per collective: every part renders `batch` frames into [batch][rows][width], the gather delivers
-    [rank][batch][rows][width], rto_assemble_batch_device rebuilds frame `index` -- both payloads, 3 parts, 4 cameras;
-    and through TileSplitRenderer.render_batch at world size 1."""
+    [rank][batch][rows][width], rto_assemble_batch_device rebuilds frame `index` -- both payloads, 3 parts, 4 cameras."""
     torch = pytest.importorskip("torch")
-    from ray_tracing_octrees_amd import tilesplit
 
     s = scenes("sphere64")
     upload(ctx, s)
@@ -847,23 +837,6 @@ def test_batched_gather_layout_assembles_every_frame(ctx, orc, scenes):
             assert_bit_exact(out.cpu().numpy(), wants[f], f"batched gather, frame {f}, shade={shade}")
     with pytest.raises(rto.RtoError):
         ctx.assemble_batch_device(frames[0], hip.Partition(nparts, 0, band), gathered.data_ptr(), batch, batch, False, out.data_ptr())
-    r = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx), 0, 1)
-    imgs = r.render_batch(frames)
-    torch.cuda.synchronize()
-    for f in range(batch):
-        assert_bit_exact(imgs[f].cpu().numpy(), wants[f], f"render_batch, world 1, frame {f}")
-
-
-def test_tile_split_over_rccl_with_one_rank():
-    """The device-to-device multi-rank path (nccl backend = RCCL, async gathers, batches, three pipelines) with a one-rank
-    group on this GPU, in its own process."""
-    import subprocess
-    import sys
-
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29598")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_one_rank_worker.py")], env=env, capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    assert "nccl one-rank worker: ok" in p.stdout
 
 
 def test_render_device_on_a_caller_stream(ctx, scenes, camera):
@@ -1250,12 +1223,6 @@ def test_config5_shadows_exist_and_partitions_agree(ctx, orc, scenes):
         ctx.synchronize()
         assert_bit_exact(frame.cpu().numpy(), shd, f"triangle path, 3 parts, shade payload, {kname}")
     ctx.set_kernel(rto.KERNEL_AUTO)
-    # the renderer class drives the same path (world size 1 needs no process group)
-    from ray_tracing_octrees_amd import tilesplit
-    r = tilesplit.TileSplitRenderer(tilesplit.HipBackend(ctx, triangles=True, shadow=True), 0, 1)
-    img = r.render(f)
-    torch.cuda.synchronize()
-    assert_bit_exact(img.cpu().numpy(), shd, "TileSplitRenderer, triangle backend")
     # error paths
     fresh = rto.Context(0)
     fresh.upload_octree(scenes("sphere16").nodes, scenes("sphere16").min, scenes("sphere16").voxel)
@@ -1419,6 +1386,95 @@ def test_comm_one_rank_through_the_c_abi(ctx, orc, scenes):
         comm.close()
 
 
+def _rehearse_every_rank(ctx, comm, frames, wants, worlds, mode, what):
+    """Every rank r of an N-GPU split, played in turn by this GPU through the whole pipeline (render its bands, pack the plan's
+    windows, grouped send/recv, assembly): the rows the PLAN gives to rank r must be the oracle's, and together they are the
+    whole frame.  The plan comes from the exported planner, i.e. this also checks that rto_comm_* does what rto_split_plan_make says."""
+    import torch
+    from ray_tracing_octrees_amd import tilesplit
+
+    H, W = wants[0].shape[:2]
+    n = len(frames)
+    arr = hip.Context.frame_array(frames)
+    for world in worlds:
+        plan = tilesplit.make_plan(ctx.scene_bounds(), frames, world, 16)
+        src_part, _ = tilesplit.row_sources(plan)
+        owner = src_part + plan.first_render_rank
+        got = [np.zeros((H, W, 4), np.float32) for _ in range(n)]
+        for r in range(world):
+            comm.debug_rehearse(world, r)
+            out = torch.full((n, H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+            comm.submit(arr, out.data_ptr(), out.stride(0) * 4, mode)
+            comm.flush()
+            sent, whole = comm.debug_last_payload()
+            assert (sent, whole) == (plan.pack_floats, plan.full_floats), f"{what} world {world}: the communicator ships what the plan says"
+            res = out.cpu().numpy()
+            mine = owner == r
+            if tilesplit.part_of_rank(plan, r) < 0:
+                assert not mine.any(), "the gatherer owns no rows"
+            for i in range(n):
+                assert_bit_exact(res[i][mine], wants[i][mine], f"{what}: world {world} rank {r} frame {i}: its bands")
+                got[i][mine] = res[i][mine]
+        for i in range(n):
+            assert_bit_exact(got[i], wants[i], f"{what}: world {world} frame {i}: the ranks' bands together")
+            assert int((got[i][..., 0] != 0).sum()) == int((wants[i][..., 0] != 0).sum())
+    comm.debug_rehearse(0)
+
+
+def test_config3_every_rank_of_2_4_8_gpus_at_full_size(ctx, orc, scenes, camera):
+    """BASELINE config 3 at its own workload: 256^3 sphere, 1920x1080, the screen split over 2, 4 and 8 GPUs -- each rank's
+    share rendered, shipped and assembled by this GPU (rto_comm_debug_rehearse), two cameras per batch; the union of the
+    ranks' bands is the oracle's frame bit for bit, and the frame's pop / hit counters are the oracle's."""
+    pytest.importorskip("torch")
+    s = scenes("sphere256")
+    upload(ctx, s)
+    W, H = 1920, 1080
+    cams = [orc.Camera(0.5, 0.7, 1.8), orc.Camera(1.1, 0.55, 2.1)]
+    frames = [rto.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H) for c in cams]
+    wants, stats = zip(*[oracle_frame(orc, s, c.get_view(), c.get_pos(), W, H) for c in cams])
+    for f, st in zip(frames, stats):
+        gs = ctx.frame_stats(f)
+        assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"])
+    comm = hip.Comm(ctx, 1, 0, hip.comm_unique_id(), band_rows=16)
+    try:
+        _rehearse_every_rank(ctx, comm, frames, wants, (2, 4, 8), hip.RESIDENT_OCTREE, "config 3")
+    finally:
+        comm.close()
+
+
+def test_config5_every_rank_of_8_gpus_at_full_size(ctx, orc, scenes, camera):
+    """BASELINE config 5's split at its own workload: 512^3 sphere, 3840x2160, leaf triangles + shadow ray, 8 GPUs (rank 0
+    gathers, ranks 1..7 render), every rank played by this GPU."""
+    pytest.importorskip("torch")
+    s = scenes("sphere512")
+    view, pos = camera("sphere")
+    W, H = 3840, 2160
+    ctx.set_kernel(rto.KERNEL_AUTO)
+    ctx.build_octree(s.grid.data, s.min, s.voxel)
+    ctx.build_leaf_triangles(None)
+    wt, wo = orc.build_leaf_triangles(s.grid, s.nodes)
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, st = orc.render_triangles(s.nodes, wt, wo, s.min, s.voxel, view, pos, W / H, 45.0, W, H, shadow=True, nthreads=min(16, orc.max_threads()))
+    comm = hip.Comm(ctx, 1, 0, hip.comm_unique_id(), band_rows=16)
+    try:
+        _rehearse_every_rank(ctx, comm, [f], [want], (8,), hip.RESIDENT_TRIANGLES_SHADOW, "config 5")
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("what,allocs", [("frustum", 5), ("comm", 6)])
+def test_partial_allocation_failures_leave_nothing_behind(what, allocs):
+    """Fault injection (RTO_FAULT_ALLOC=k: the k-th buffer allocation fails): whichever of its allocations fails, a frustum
+    update / a communicator submit reports the failure, keeps no half-allocated state, and the repeated call works."""
+    import subprocess
+    import sys
+
+    for k in range(1, allocs + 1):
+        env = dict(os.environ, RTO_FAULT_ALLOC=str(k), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fault_alloc_worker.py"), what], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, f"{what}, allocation {k}: " + p.stdout[-1500:] + p.stderr[-2500:]
+
+
 def test_comm_group_of_one_gpu_renders_into_the_resident_frame(ctx, orc, scenes, camera):
     """rto_comm_create_all / rto_comm_render_resident_all (what RayTracerBVH::setDevices(n) drives) with the one GPU of
     this box: the frame lands in rank 0's resident framebuffer; a second context on the same device is refused."""
@@ -1478,7 +1534,7 @@ def test_bench_line_contract_small_run():
     import sys
 
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--dim", "64", "--width", "320", "--height", "200",
-           "--cpu-frames", "1", "--ramp-ms", "0", "--orbit-frames", "8"]
+           "--cpu-frames", "1", "--ramp-ms", "0", "--orbit-frames", "8", "--dropin-frames", "10"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
@@ -1491,7 +1547,10 @@ def test_bench_line_contract_small_run():
     assert d["verified_against_oracle"] is True and d["value"] > 0 and d["ms_per_step"] > 0
     assert "workload" in d["config"] and d["roofline"]["bound"] == "valu_issue" and d["roofline"]["hbm_algorithmic"]["achieved"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
-    assert d["one_frame_per_launch"]["ms_per_frame"] > 0 and d["orbit"]["frames"] == 8
+    assert d["frames_per_launch"]["ms_per_frame"] > 0 and d["frames_per_launch"]["frames_equal_the_timed_frame"] is True and d["orbit"]["frames"] == 8
+    assert d["dropin_call"]["ms_per_call"] > 0 and d["dropin_call"]["frame_equals_timed_frame"] is True
+    assert len(d["config"]["workload"]) <= 120 and d["config"]["workload"].startswith("cfg2:") and len(d["config"]["clock_ramp"]) <= 120
+    assert "one kernel launch per frame" in d["config"]["parallelism"] and d["roofline"]["kernel_ms_median"] > 0
 
 
 def test_camera_a_hair_outside_the_root_box(ctx, orc):

@@ -1,5 +1,6 @@
-"""Multi-rank path on CPU: world_size 2 and 3 with the gloo backend (no GPU needed).
-Also checks the partition arithmetic of the Python module against the C ABI's rto_partition_rows."""
+"""Multi-rank path on CPU: world_size 2, 3, 4, 5 and 8 with the gloo backend (no GPU needed).
+The workers call the C ABI's split planner -- the functions rto_comm_* itself uses -- so what is exercised here is the
+product's own arithmetic: identical plans on every rank, the dedicated gatherer from 4 ranks on, the column windows."""
 import ctypes as C
 import os
 import socket
@@ -20,28 +21,95 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 5, 8])
 def test_tile_split_gather_assemble_gloo(world):
     env = dict(os.environ, OMP_NUM_THREADS="1", RTO_NO_TORCH="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_tilesplit_worker.py")]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-def test_partition_arithmetic_matches_c_abi():
+def _bounds():
+    b = hip.SceneBounds()
+    b.grid_min[:] = (-0.5, -0.5, -0.5)
+    b.voxel_size = 1.0 / 16
+    b.root_size = 16
+    b.solid_lo[:] = (2, 2, 2)
+    b.solid_hi[:] = (14, 14, 14)
+    return b
+
+
+def test_plan_rows_agree_with_rto_partition_rows():
+    """The planner's row arithmetic against the render entry points' (rto_partition_rows): a part's rows, the padding to
+    part 0's rows, and every row of the frame owned exactly once -- for the world sizes and heights of every configuration."""
     L = hip.load()
+    b = _bounds()
     for H in (1, 7, 8, 37, 1080, 2160):
-        f = hip.make_frame(np.eye(4, dtype=np.float32), [0, 0, 0], 1.0, 45.0, 64, H)
-        for world in (1, 2, 3, 4, 8):
+        f = hip.make_frame(np.eye(4, dtype=np.float32), [0, 0, 3], 1.0, 45.0, 64, H)
+        for world in (1, 2, 3, 4, 5, 8):
             for band in (8, 16, 64):
+                plan = tilesplit.make_plan(b, [f], world, band)
+                parts = plan.render_parts
+                assert parts == (world - 1 if world >= 4 else world)
+                assert plan.rows_part0 == L.rto_partition_rows(C.byref(f), C.byref(hip.Partition(parts, 0, band)))
+                assert plan.frame_floats == plan.rows_part0 * 64 and plan.full_floats == plan.frame_floats
                 maps = []
-                for p in range(world):
-                    rows = L.rto_partition_rows(C.byref(f), C.byref(hip.Partition(world, p, band)))
-                    assert rows == tilesplit.partition_rows(H, world, p, band)
-                    m = tilesplit.partition_row_map(H, world, p, band)
-                    assert len(m) == rows
+                for p in range(parts):
+                    rows = tilesplit.rows_of_part(plan, p)
+                    assert rows == L.rto_partition_rows(C.byref(f), C.byref(hip.Partition(parts, p, band))) <= plan.rows_part0
+                    m = tilesplit.row_map(plan, p)
+                    assert len(m) == rows and (np.diff(m) > 0).all()
                     maps.append(m)
-                allrows = np.sort(np.concatenate(maps))
-                np.testing.assert_array_equal(allrows, np.arange(H))      # a partition: every row exactly once
+                np.testing.assert_array_equal(np.sort(np.concatenate(maps)), np.arange(H))      # a partition: every row exactly once
+                assert [tilesplit.part_of_rank(plan, r) for r in range(world)] == [r - plan.first_render_rank for r in range(world)]
+                assert tilesplit.part_of_rank(plan, world) == -1 and tilesplit.part_of_rank(plan, -1) == -1
+
+
+def test_plan_windows_follow_the_geometry():
+    """The column window of a frame: the geometry's screen rectangle rounded to 8 pixels; a token window when the camera looks
+    away; the whole width up close; whole rows for batches beyond the table; bad arguments refused."""
+    from oracle import orc
+
+    b = _bounds()
+    W, H = 640, 360
+
+    def frame(cam):
+        return hip.make_frame(cam.get_view(), cam.get_pos(), W / H, 45.0, W, H)
+
+    centred = frame(orc.Camera(0.5, 0.7, 1.8))
+    away_cam = orc.Camera(0.5, 0.7, 1.8)
+    away_cam.set_target(30.0, 0.0, 0.0)            # the scene is in front of the eye but 53 degrees off axis: left of the screen
+    away = frame(away_cam)
+    close = frame(orc.Camera(0.5, 0.7, 0.3))
+    plan = tilesplit.make_plan(b, [centred, away, close], 8, 16)
+    assert plan.cropped == 1 and plan.n_frames == 3
+    x0, w = plan.win_x0[0], plan.win_w[0]
+    assert x0 % 8 == 0 and w % 8 == 0 and 0 < w < W and abs((x0 + w / 2) - W / 2) < 16      # centred sphere: a centred window
+    assert (plan.win_x0[1], plan.win_w[1]) == (0, 8)                                        # nothing on the screen: a token window
+    assert (plan.win_x0[2], plan.win_w[2]) == (0, W)                                        # eye inside the box: every column
+    assert [plan.win_off[i] for i in range(3)] == [0, plan.rows_part0 * w, plan.rows_part0 * (w + 8)]
+    assert plan.pack_floats == plan.rows_part0 * (w + 8 + W) < plan.full_floats
+    L = hip.load()
+    out = hip.SplitPlan()
+    arr = hip.Context.frame_array([centred])
+    assert L.rto_split_plan_make(C.byref(b), arr, 1, 0, 16, C.byref(out)) == hip.RTO_E_INVALID      # world < 1
+    assert L.rto_split_plan_make(C.byref(b), arr, 1, 2, 12, C.byref(out)) == hip.RTO_E_INVALID      # band_rows % 8
+    assert L.rto_split_plan_make(C.byref(b), arr, 0, 2, 16, C.byref(out)) == hip.RTO_E_INVALID      # empty batch
+    other = hip.make_frame(np.eye(4, dtype=np.float32), [0, 0, 3], 1.0, 45.0, 320, 200)
+    assert L.rto_split_plan_make(C.byref(b), hip.Context.frame_array([centred, other]), 2, 2, 16, C.byref(out)) == hip.RTO_E_INVALID
+    p, r = C.c_int(), C.c_int()
+    assert L.rto_split_row_source(C.byref(plan), H, C.byref(p), C.byref(r)) == hip.RTO_E_INVALID
+
+
+def test_scene_bounds_of_nodes_is_what_upload_derives():
+    from oracle import orc
+
+    g = orc.test_sphere_grid(16)
+    nodes = orc.build_flat_octree(g)
+    b = tilesplit.scene_bounds_of_nodes(nodes, g.min, g.voxel_size)
+    solid = nodes[((nodes["isLeaf"] == 1) | (nodes["isUniform"] == 1)) & (nodes["isSolid"] == 1)]
+    for a, k in enumerate(("x", "y", "z")):
+        assert b.solid_lo[a] == solid[k].min() and b.solid_hi[a] == (solid[k] + solid["size"]).max()
+    assert b.root_size == 16 and abs(b.voxel_size - 1 / 16) < 1e-9
