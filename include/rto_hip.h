@@ -136,10 +136,14 @@ int  rto_forget_stream(rto_context* ctx, void* hip_stream);
  * renderSceneComputeWithCulling(updateFrustum=true) (S/RayTracerBVH.cpp:725-813).
  * The test runs on the GPU over the resident array; rendering afterwards behaves as
  * if the compacted array had been uploaded.  enable=0 restores the full array.
- * Cost: 0.033 ms at 374,921 nodes including the one read-back (visible count, the root's flag).  The descriptor kernels only
- * need the visibility bits; the compacted array itself is made when somebody needs it (rto_download_visible_nodes, the generic
- * kernel, a culled root with surviving descendants).  Frames in flight on the context's own stream are ordered before the
- * update by the stream; if frames were launched on other streams since the last update, the device is waited for first. */
+ * For canonical BFS octrees (what setOctree / rto_build_octree produce) the update is ONE kernel on rto_stream(ctx) and reads
+ * nothing back: the visibility flags, the descriptors' visibility bits, the number of surviving nodes and the node traversals
+ * start at (the root; the first visible node when the root itself was culled, S/RT:765-812) stay on the device, where the
+ * traversal kernels read them; rto_octree_info_get / rto_download_visible_nodes fetch the count when asked (they wait for the
+ * device).  The compacted array itself is made when somebody needs it (rto_download_visible_nodes, the generic kernel).
+ * Ordering: frames on the context's own stream are ordered around the update by the stream; if frames were launched on other
+ * streams since the last update (or ever captured on one), the device is waited for first.  Other arrays: per-node test,
+ * one read-back (synchronous). */
 int  rto_update_frustum(rto_context* ctx, const float view[16], float fov_deg, float aspect, int enable);
 /* Developer aid: the same update with caller-supplied planes (LEFT, RIGHT, TOP, BOTTOM, NEAR, FAR as nx, ny, nz, d;
  * normalised) and margin instead of the ones S/RT:731-755 derives -- lets a test build situations real cameras cannot,
@@ -163,8 +167,11 @@ int  rto_render_device(rto_context* ctx, const rto_frame* frame, const rto_parti
  * _shade / _triangles variants) allocate nothing and never synchronise on it, so a sequence of frames may be captured
  * with hipStreamBeginCapture and replayed; a captured launch that WOULD have to allocate or synchronise (first frame of
  * a new size on that stream) fails with RTO_E_UNSUPPORTED instead of invalidating the capture (the runtime needs ~9 us between dependent plain launches but ~1 us between
- * graph nodes: 70 -> 61 us per frame at BASELINE config 2).  While a stream is being captured its launch-order table is
- * frozen (no cost recording, no rebuild): a replay finds the device state it was captured with. */
+ * graph nodes: 70 -> 61 us per frame at BASELINE config 2).  Captured launches use a launch-order table of their own (plain
+ * launches never read it), and the first frame a capture records on a stream always carries a table-rebuild node, so a replay
+ * never depends on what plain launches, other graphs or its own last frame left behind.  Replay a graph on the stream it was
+ * captured on: the tables belong to that stream.  rto_update_frustum (canonical octrees, after one plain call) and
+ * rto_render_resident can be captured on rto_stream(ctx) the same way: the update reads nothing back. */
 /* Synchronous convenience: whole frame into host memory (the one API addition the
  * reference lacks: its texture is never read back). */
 int  rto_render_host(rto_context* ctx, const rto_frame* frame, float* host_rgba);

@@ -48,7 +48,17 @@ struct rto_context {
     rto_node* d_compact = nullptr;
     bool compactValid = false;       // d_compact / d_remap hold the compaction of the CURRENT visibility flags (made on demand)
     bool otherStreams = false;       // a frame was launched on a stream other than c->stream since the last device-wide wait
+    bool foreignCaptured = false;    // a frame was CAPTURED on another stream: its replays are the caller's, every later update waits for the device
     int64_t visibleNodes = 0;
+    // canonical trees: the update is one kernel and reads nothing back (k_cull_desc); where traversals start and how many nodes
+    // survived stay on the device (d_start) and reach the host only when somebody asks (sync_cull_state)
+    int4* d_descPos = nullptr;       // position + size of every internal node, descriptor order
+    int* d_cullBlockCount = nullptr; // k_cull_desc: per-block partials
+    int* d_cullBlockFirst = nullptr;
+    StartState* d_start = nullptr;
+    bool cullAsync = false;          // the flags in force come from k_cull_desc
+    bool cullStateStale = false;     // rootVisible / visibleNodes below are older than d_start
+    bool cullCaptured = false;       // an update was stream-captured: replays change d_start behind the host's back
 
     // temporal launch order (packed kernel): an earlier frame's per-tile cost -> this frame's slot->tile table.
     // The tables are written and read by kernels in stream order, so every launch stream owns a set of its own:
@@ -60,14 +70,18 @@ struct rto_context {
                                     // 8 or 16 beat 4 for a static, an orbiting and a fast-moving camera alike)
     struct OrderState {
         int* d_tileCost = nullptr;      // tile -> trip count of the last colour / shade frame that rendered it (row-major over all tiles)
-        int* d_tileOrder = nullptr;     // launch slot -> tile: a permutation of the tiles of `box`
+        // launch slot -> tile: a permutation of the tiles of `box`.  TWO tables: [0] for plain launches, [1] for launches that are
+        // being stream-captured.  A graph replay re-runs its k_order_build nodes and rewrites its table behind the host's back, so
+        // plain launches never read table [1]; and every capture starts with a rebuild node of its own (capId), so a replay never
+        // depends on what plain launches, another graph or its own tail left in the table.
+        struct Table { int* d = nullptr; bool valid = false; int box[4] = { 0, 0, 0, 0 }; int age = 0; };
+        Table tab[2];
+        int active = 0;                 // the table the launch being prepared uses
+        unsigned long long capId = 0;   // id of the capture table [1] was last (re)built in
         int tiles = 0;                  // tile count the buffers are sized for
         long key[7] = { 0, 0, 0, 0, 0, 0, 0 };   // W, H, numParts, part, bandRows, tiles, path (0 octree / 1 triangles) of the frames the history belongs to
         bool costValid = false;         // a frame of this geometry has recorded its costs
-        bool valid = false;             // d_tileOrder holds a table for `box`
-        int box[4] = { 0, 0, 0, 0 };    // the tile box the table enumerates
         bool fixed = false;             // debug: the caller supplied the table (over ALL tiles), do not rebuild it
-        int age = 0;                    // frames rendered since the table was built
         int* d_queue = nullptr;         // persistent-threads variant: the slot counter (zeroed in front of every launch)
         unsigned long lastUse = 0;      // orderClock value of the last launch on this stream (eviction order)
     };
@@ -137,6 +151,10 @@ static hipError_t fallible_malloc(void** p, size_t bytes) {
 }
 
 static void free_cull_buffers(rto_context* c) {
+    (void)hipFree(c->d_descPos); c->d_descPos = nullptr;
+    (void)hipFree(c->d_cullBlockCount); c->d_cullBlockCount = nullptr;
+    (void)hipFree(c->d_cullBlockFirst); c->d_cullBlockFirst = nullptr;
+    c->cullAsync = false; c->cullStateStale = false; c->cullCaptured = false;
     (void)hipFree(c->d_vis); c->d_vis = nullptr;
     (void)hipFree(c->d_remap); c->d_remap = nullptr;
     (void)hipFree(c->d_blockCount); c->d_blockCount = nullptr;
@@ -161,7 +179,7 @@ static void free_octree(rto_context* c) {
     (void)hipFree(c->d_vox); c->d_vox = nullptr;
     c->voxDim[0] = c->voxDim[1] = c->voxDim[2] = 0;
     c->numTris = 0;
-    for (auto& kv : c->orders) { kv.second.valid = false; kv.second.costValid = false; }
+    for (auto& kv : c->orders) { kv.second.tab[0].valid = kv.second.tab[1].valid = false; kv.second.costValid = false; }
     c->numNodes = c->numInternal = 0;
     c->canonical = false; c->culling = false; c->rootVisible = 1; c->visibleNodes = 0;
 }
@@ -202,6 +220,7 @@ int rto_create(int device_ordinal, rto_context** out) {
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipMalloc(&c->d_counters, sizeof(Counters))) != hipSuccess ||
         (e = hipMalloc(&c->d_visibleCount, 2 * sizeof(int64_t))) != hipSuccess ||     // [0] count of visible nodes, [1] the root's flag
+        (e = hipMalloc(&c->d_start, sizeof(StartState))) != hipSuccess || (e = hipMemset(c->d_start, 0, sizeof(StartState))) != hipSuccess ||
         (e = hipMalloc(&c->d_sortViolations, sizeof(int))) != hipSuccess || (e = hipMemset(c->d_sortViolations, 0, sizeof(int))) != hipSuccess) {
         std::string msg = std::string("rto_create: ") + hipGetErrorString(e);
         rto_destroy(c);
@@ -221,12 +240,13 @@ void rto_destroy(rto_context* c) {
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_rayX);
     (void)hipFree(c->d_rayY);
-    for (auto& kv : c->orders) { (void)hipFree(kv.second.d_tileCost); (void)hipFree(kv.second.d_tileOrder); (void)hipFree(kv.second.d_queue); }
+    for (auto& kv : c->orders) { (void)hipFree(kv.second.d_tileCost); (void)hipFree(kv.second.tab[0].d); (void)hipFree(kv.second.tab[1].d); (void)hipFree(kv.second.d_queue); }
     c->orders.clear();
     (void)hipFree(c->d_mcCases);
     (void)hipFree(c->d_steps);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_visibleCount);
+    (void)hipFree(c->d_start);
     (void)hipFree(c->d_sortViolations);
     for (hipEvent_t e : c->ringStart) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ringStop) (void)hipEventDestroy(e);
@@ -637,10 +657,10 @@ int rto_debug_set_tile_order(rto_context* c, const int32_t* host_order, int64_t 
     if (!host_order) {
         if (it == c->orders.end()) return RTO_OK;
         rto_context::OrderState& o = it->second;
-        o.fixed = false; o.valid = false;
+        o.fixed = false; o.tab[0].valid = false;
         return RTO_OK;
     }
-    if (it == c->orders.end() || n != it->second.tiles || !it->second.d_tileOrder)
+    if (it == c->orders.end() || n != it->second.tiles || !it->second.tab[0].d)
         return fail(c, RTO_E_INVALID, "rto_debug_set_tile_order: render one frame first; n must equal the tile count");
     const int tilesX = (int)((it->second.key[0] + 7) / 8);                 // key[0] = W of the frames the tables belong to
     if (tilesX <= 0 || tilesX > 0xffff || n / tilesX > 0xffff) return fail(c, RTO_E_INVALID, "rto_debug_set_tile_order: frame too large for packed entries");
@@ -650,8 +670,8 @@ int rto_debug_set_tile_order(rto_context* c, const int32_t* host_order, int64_t 
         packed[(size_t)i] = (host_order[i] % tilesX) | ((host_order[i] / tilesX) << 16);      // the kernels' slot table holds tx | ty << 16
     }
     RTO_HIP(c, hipDeviceSynchronize());
-    RTO_HIP(c, hipMemcpy(it->second.d_tileOrder, packed.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-    it->second.fixed = true; it->second.valid = true;
+    RTO_HIP(c, hipMemcpy(it->second.tab[0].d, packed.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    it->second.fixed = true; it->second.tab[0].valid = true;
     return RTO_OK;
 }
 
@@ -661,7 +681,7 @@ int rto_set_launch_order(rto_context* c, int policy, int refresh_period) {
     if (refresh_period < 0) return fail(c, RTO_E_INVALID, "rto_set_launch_order: refresh_period must be >= 0 (0 keeps the current one)");
     c->orderPolicy = policy;
     if (refresh_period > 0) c->orderPeriod = refresh_period;
-    for (auto& kv : c->orders) { if (!kv.second.fixed) kv.second.valid = false; kv.second.age = 0; }
+    for (auto& kv : c->orders) { if (!kv.second.fixed) kv.second.tab[0].valid = false; kv.second.tab[1].valid = false; kv.second.tab[0].age = kv.second.tab[1].age = 0; }
     return RTO_OK;
 }
 
@@ -671,7 +691,7 @@ int rto_forget_stream(rto_context* c, void* hip_stream) {
     if (it == c->orders.end()) return RTO_OK;
     RTO_HIP(c, hipSetDevice(c->device));
     RTO_HIP(c, hipDeviceSynchronize());          // no kernel still reads the tables
-    (void)hipFree(it->second.d_tileCost); (void)hipFree(it->second.d_tileOrder); (void)hipFree(it->second.d_queue);
+    (void)hipFree(it->second.d_tileCost); (void)hipFree(it->second.tab[0].d); (void)hipFree(it->second.tab[1].d); (void)hipFree(it->second.d_queue);
     if (c->lastOrderStream == it->first) c->lastOrderStream = nullptr;
     c->orders.erase(it);
     return RTO_OK;
@@ -685,8 +705,11 @@ int rto_debug_sort_violations(rto_context* c, int* count) {
     return RTO_OK;
 }
 
+static int sync_cull_state(rto_context* c);
+
 int rto_octree_info_get(const rto_context* c, rto_octree_info* out) {
     if (!c || !out) return RTO_E_INVALID;
+    (void)sync_cull_state(const_cast<rto_context*>(c));   // visible_nodes of an asynchronous frustum update is fetched when asked for
     out->num_nodes = c->numNodes;
     out->num_internal = c->numInternal;
     out->root_size = c->rootSize;
@@ -711,15 +734,37 @@ int rto_set_kernel(rto_context* c, int kernel) {
 // One frustum update for the given planes (LEFT, RIGHT, TOP, BOTTOM, NEAR, FAR; normalised) and margin.
 static bool stream_is_capturing(hipStream_t s);
 
-// remap + compaction of the current visibility flags into d_compact, on stream s (ordered behind the frustum update, which
-// ran on c->stream and was waited for)
+// What the last (asynchronous) frustum update left on the device -> the host's copies (rootVisible, visibleNodes).  Only the
+// paths that need them on the host call this: the A/B kernels, the generic kernel, compaction, info queries.
+static int sync_cull_state(rto_context* c) {
+    if (!c->culling || !c->cullAsync || !c->cullStateStale) return RTO_OK;
+    if (stream_is_capturing(c->stream))
+        return fail(c, RTO_E_UNSUPPORTED, "the result of a frustum update cannot be read while the context's stream is being captured");
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipDeviceSynchronize());
+    StartState st;
+    RTO_HIP(c, hipMemcpy(&st, c->d_start, sizeof st, hipMemcpyDeviceToHost));
+    c->rootVisible = st.rootVisible ? 1 : 0;
+    c->visibleNodes = st.visibleCount;
+    if (!c->cullCaptured) c->cullStateStale = false;       // a captured update may be replayed at any time: always ask again
+    return RTO_OK;
+}
+
+// remap + compaction of the current visibility flags into d_compact, on stream s
 static int ensure_compact(rto_context* c, hipStream_t s) {
-    if (!c->culling || c->compactValid) return RTO_OK;
+    if (!c->culling) return RTO_OK;
     if (stream_is_capturing(s))
         return fail(c, RTO_E_UNSUPPORTED, "render: the compacted node array of the last frustum update is made on first use; "
                                           "render one frame with this kernel before hipStreamBeginCapture");
+    const int rcState = sync_cull_state(c);                // also orders this stream behind the update (device-wide wait)
+    if (rcState != RTO_OK) return rcState;
+    if (c->compactValid) return RTO_OK;
     const int64_t n = c->numNodes;
     const int nb = (int)((n + kBlock - 1) / kBlock);
+    if (c->cullAsync) {                                    // k_cull_desc leaves flags only: count and scan them now
+        hipLaunchKernelGGL(k_vis_block_counts, dim3(nb), dim3(kBlock), 0, s, c->d_vis, n, c->d_blockCount);
+        hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, s, c->d_blockCount, nb, c->d_blockBase, c->d_visibleCount);
+    }
     hipLaunchKernelGGL(k_cull_remap, dim3(nb), dim3(kBlock), 0, s, c->d_vis, n, c->d_blockBase, c->d_remap);
     hipLaunchKernelGGL(k_cull_compact, dim3(nb), dim3(kBlock), 0, s, c->d_nodes, n, c->d_remap, c->d_compact);
     RTO_HIP(c, hipGetLastError());
@@ -732,16 +777,29 @@ static int update_frustum_planes(rto_context* c, const float planes[24], float m
     const int64_t n = c->numNodes;
     const int nb = (int)((n + kBlock - 1) / kBlock);
     const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
+    const bool canon = c->canonical && nbInt > 0;
+    const bool capturing = stream_is_capturing(c->stream);
     if (!c->d_vis) {
-        // all or nothing: a failed allocation leaves none of the five behind (the next update starts over)
+        if (capturing)
+            return fail(c, RTO_E_UNSUPPORTED, "rto_update_frustum: the first update of an octree allocates its buffers; call it once before hipStreamBeginCapture");
+        // all or nothing: a failed allocation leaves none of them behind (the next update starts over)
         hipError_t e = fallible_malloc(reinterpret_cast<void**>(&c->d_vis), (size_t)n);
         if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_remap), (size_t)n * sizeof(int));
         if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_blockCount), (size_t)nb * sizeof(int));
         if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_blockBase), (size_t)nb * sizeof(int));
         if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_compact), (size_t)n * sizeof(rto_node));
+        if (canon) {
+            if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_descPos), (size_t)c->numInternal * sizeof(int4));
+            if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_cullBlockCount), (size_t)nbInt * sizeof(int));
+            if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_cullBlockFirst), (size_t)nbInt * sizeof(int));
+        }
         if (e != hipSuccess) {
             free_cull_buffers(c);
             return fail(c, RTO_E_HIP, std::string("rto_update_frustum: buffer allocation: ") + hipGetErrorString(e));
+        }
+        if (canon) {
+            hipLaunchKernelGGL(k_desc_pos, dim3(nbInt), dim3(kBlock), 0, c->stream, c->d_nodes, c->d_descFirstChild, c->numInternal, c->d_descPos);
+            RTO_HIP(c, hipMemsetAsync(c->d_start, 0, sizeof(StartState), c->stream));      // the ticket starts at zero
         }
     }
     CullParams C;
@@ -749,21 +807,30 @@ static int update_frustum_planes(rto_context* c, const float planes[24], float m
     std::memcpy(C.gridMin, c->gridMin, sizeof C.gridMin);
     C.voxelSize = c->voxelSize;
     C.margin = margin;
+    // The compacted array itself (S/RT:765-802: remap + copy, 2 x 22 MB of traffic at config 2) is made when somebody asks for
+    // it -- rto_download_visible_nodes, the generic kernel: ensure_compact().  The packed kernels render from the visibility
+    // bits in the descriptors, which is all a frustum update has to refresh for them.
+    c->compactValid = false;
+    if (canon) {
+        // one launch, nothing read back, capturable: flags, descriptor masks, and -- on the device -- where traversals start
+        hipLaunchKernelGGL(k_cull_desc, dim3(nbInt), dim3(kBlock), 0, c->stream, C, c->d_descPos, c->d_descFirstChild, c->d_nodes, c->numInternal, c->depth,
+                           c->d_desc, c->d_vis, c->d_cullBlockCount, c->d_cullBlockFirst, c->d_start);
+        RTO_HIP(c, hipGetLastError());
+        c->culling = true; c->cullAsync = true; c->cullStateStale = true;
+        if (capturing) c->cullCaptured = true;
+        return RTO_OK;
+    }
+    // arbitrary arrays (generic kernel): per-node flags + scan, the count and the root's flag come back in one copy
+    if (capturing) return fail(c, RTO_E_UNSUPPORTED, "rto_update_frustum: capturable for canonical BFS octrees only");
     hipLaunchKernelGGL(k_cull_flags, dim3(nb), dim3(kBlock), 0, c->stream, C, c->d_nodes, n, c->d_vis, c->d_blockCount, c->d_visibleCount + 1);
     hipLaunchKernelGGL(k_scan_block_counts, dim3(1), dim3(1024), 0, c->stream, c->d_blockCount, nb, c->d_blockBase, c->d_visibleCount);
-    // The compacted array itself (S/RT:765-802: remap + copy, 2 x 22 MB of traffic at config 2) is made when somebody asks for
-    // it -- rto_download_visible_nodes, the generic kernel, the culled-root edge: ensure_compact().  The packed kernels render
-    // from the visibility bits in the descriptors, which is all a frustum update has to refresh for them.
-    c->compactValid = false;
-    if (c->canonical && nbInt > 0)
-        hipLaunchKernelGGL(k_desc_vismask, dim3(nbInt), dim3(kBlock), 0, c->stream, c->d_vis, c->d_descFirstChild, c->numInternal, c->d_desc);
     RTO_HIP(c, hipGetLastError());
     int64_t back[2] = { 0, 0 };                     // visible nodes, the root's flag: one read-back
     RTO_HIP(c, hipMemcpyAsync(back, c->d_visibleCount, sizeof back, hipMemcpyDeviceToHost, c->stream));
     RTO_HIP(c, hipStreamSynchronize(c->stream));
     c->visibleNodes = back[0];
     c->rootVisible = back[1] ? 1 : 0;
-    c->culling = true;
+    c->culling = true; c->cullAsync = false; c->cullStateStale = false;
     return RTO_OK;
 }
 
@@ -771,18 +838,18 @@ int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, floa
     if (!c) return RTO_E_INVALID;
     if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_update_frustum: no octree uploaded");
     RTO_HIP(c, hipSetDevice(c->device));
-    // the visibility masks live in the descriptors every traversal kernel reads: frames still in flight on caller
-    // streams must be done before they change, and the change must be complete before this returns.  Frames on the
-    // context's own stream (rto_render_resident: what RayTracerBVH uses) are ordered before the update by the stream itself.
-    if (c->otherStreams) { RTO_HIP(c, hipDeviceSynchronize()); c->otherStreams = false; }
+    // The visibility masks live in the descriptors every traversal kernel reads.  Frames on the context's own stream
+    // (rto_render_resident: what RayTracerBVH uses) are ordered around the update by the stream itself: nothing is waited for.
+    // Frames launched on OTHER streams since the last update must be done before the masks change: the device is waited for
+    // (always, once a frame was captured on another stream: its replays are not seen here).  Not while capturing.
+    if ((c->otherStreams || c->foreignCaptured) && !stream_is_capturing(c->stream)) { RTO_HIP(c, hipDeviceSynchronize()); c->otherStreams = false; }
     if (!enable) {
         const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
         if (c->culling && c->canonical && nbInt > 0) {
             hipLaunchKernelGGL(k_desc_visall, dim3(nbInt), dim3(kBlock), 0, c->stream, c->numInternal, c->d_desc);
             RTO_HIP(c, hipGetLastError());
-            RTO_HIP(c, hipStreamSynchronize(c->stream));
         }
-        c->culling = false; c->rootVisible = 1; c->visibleNodes = c->numNodes;
+        c->culling = false; c->cullAsync = false; c->cullStateStale = false; c->rootVisible = 1; c->visibleNodes = c->numNodes;
         return RTO_OK;
     }
     if (!view) return fail(c, RTO_E_INVALID, "rto_update_frustum: view is NULL");
@@ -807,6 +874,8 @@ int rto_download_visible_nodes(rto_context* c, rto_node* out, int64_t capacity, 
     if (!c || !count) return RTO_E_INVALID;
     if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_download_visible_nodes: no octree uploaded");
     RTO_HIP(c, hipSetDevice(c->device));
+    const int rcState = sync_cull_state(c);
+    if (rcState != RTO_OK) return rcState;
     *count = c->visibleNodes;
     if (!out) return RTO_OK;
     if (capacity < c->visibleNodes) return fail(c, RTO_E_INVALID, "rto_download_visible_nodes: capacity too small");
@@ -1011,6 +1080,7 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     }
     P.rayX = c->d_rayX; P.rayY = c->d_rayY;
     P.tileOrder = nullptr; P.tileCost = nullptr;
+    P.start = nullptr;                     // the lean kernels' launchers point it at the device-side start state while culling is active
     {   // rays through pixels outside these rectangles miss the root box / every solid leaf for certain
         int rr[4], sr[4];
         frame_rectangles(bounds_of(c), f, P.tanHalfFov, rr, sr);
@@ -1058,7 +1128,7 @@ static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, bool 
         for (auto jt = c->orders.begin(); jt != c->orders.end(); ++jt)
             if (jt->second.lastUse < victim->second.lastUse) victim = jt;
         (void)hipDeviceSynchronize();
-        (void)hipFree(victim->second.d_tileCost); (void)hipFree(victim->second.d_tileOrder);
+        (void)hipFree(victim->second.d_tileCost); (void)hipFree(victim->second.tab[0].d); (void)hipFree(victim->second.tab[1].d);
         (void)hipFree(victim->second.d_queue);
         if (c->lastOrderStream == victim->first) c->lastOrderStream = nullptr;
         c->orders.erase(victim);
@@ -1089,40 +1159,52 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
                 return fail(c, RTO_E_UNSUPPORTED, "render: the first frame of a new size on a stream allocates its launch-order "
                                                   "tables; render one such frame before hipStreamBeginCapture");
             // hipFree waits for the device: no kernel still reads the old tables
-            (void)hipFree(o->d_tileCost); (void)hipFree(o->d_tileOrder);
-            o->d_tileCost = o->d_tileOrder = nullptr; o->tiles = 0;
+            (void)hipFree(o->d_tileCost); (void)hipFree(o->tab[0].d); (void)hipFree(o->tab[1].d);
+            o->d_tileCost = o->tab[0].d = o->tab[1].d = nullptr; o->tiles = 0;
             RTO_HIP(c, hipMalloc(&o->d_tileCost, (size_t)tiles * sizeof(int)));
-            RTO_HIP(c, hipMalloc(&o->d_tileOrder, (size_t)tiles * sizeof(int)));
-            o->tiles = tiles; o->valid = false; o->costValid = false; o->fixed = false;
+            RTO_HIP(c, hipMalloc(&o->tab[0].d, (size_t)tiles * sizeof(int)));
+            RTO_HIP(c, hipMalloc(&o->tab[1].d, (size_t)tiles * sizeof(int)));
+            o->tiles = tiles; o->tab[0].valid = o->tab[1].valid = false; o->costValid = false; o->fixed = false;
         }
-        if (std::memcmp(key, o->key, sizeof key) != 0) { o->valid = false; o->costValid = false; o->fixed = false; std::memcpy(o->key, key, sizeof key); }
+        if (std::memcmp(key, o->key, sizeof key) != 0) { o->tab[0].valid = o->tab[1].valid = false; o->costValid = false; o->fixed = false; std::memcpy(o->key, key, sizeof key); }
+        o->active = capturing ? 1 : 0;
+        if (capturing) {
+            // a capture's first frame on this stream always gets a rebuild node of its own: whatever plain launches, another
+            // graph or this graph's own tail leave in the table, a replay starts from a table built for ITS first frame's box
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            unsigned long long id = 0;
+            if (hipStreamGetCaptureInfo(s, &cs, &id) != hipSuccess) id = ~0ull;
+            if (id != o->capId || id == ~0ull) { o->tab[1].valid = false; o->capId = id; }
+        }
     }
+    const bool fixedOrder = o && o->fixed && !capturing;       // the caller's table serves plain launches only
     // launch geometry: frames get waves for the rectangle's tiles only and share the outside region out as wide stores;
     // instrumentation modes and caller-supplied orders keep one wave per tile of the image
-    if ((frameMode || timelineMode) && !(o && o->fixed)) {
+    if ((frameMode || timelineMode) && !fixedOrder) {
         // a frame only needs the pixels that can meet SOLID geometry: every other ray is black whatever it pops on the way
         // (S/RT:363), so the rectangle of the solid leaves' bounding box replaces the root box's
         Q.rootX0 = rect[0]; Q.rootY0 = rect[1]; Q.rootX1 = rect[2]; Q.rootY1 = rect[3];
         root_rectangle_box(Q, 8 * c->numCUs);
     }
     if (o) {
+        rto_context::OrderState::Table& T = o->tab[o->active];
         const int box[4] = { Q.boxX0, Q.boxY0, Q.boxW, Q.boxH };
         // The table is a scheduling hint rebuilt from the costs the previous frames recorded: when the box changed its
         // SIZE (the entries are relative to the box's corner: a box that only moved -- a camera in motion -- keeps using
         // it) or every orderPeriod-th frame.  k_order_build emits a permutation of the box's tiles whatever the
-        // cost array holds and keeps no state between calls, so rebuilding inside a stream capture is safe too.
-        if (!o->fixed && Q.traceWaves > 0 && (!o->valid || box[2] != o->box[2] || box[3] != o->box[3] || o->age >= c->orderPeriod)) {
+        // cost array holds and keeps no state between calls: inside a capture it becomes a node of the graph.
+        if (!fixedOrder && Q.traceWaves > 0 && (!T.valid || box[2] != T.box[2] || box[3] != T.box[3] || T.age >= c->orderPeriod)) {
             if (o->costValid) {
                 const int staged = Q.traceWaves <= kOrderLdsTiles ? 1 : 0;
                 hipLaunchKernelGGL(k_order_build, dim3(1), dim3(kOrderBlock), staged ? (size_t)((Q.traceWaves + 15) & ~15) : 0, s, o->d_tileCost, Q.tilesX,
-                                   Q.boxX0, Q.boxY0, Q.boxW, Q.boxH, staged, o->d_tileOrder, c->d_sortViolations);
-                std::memcpy(o->box, box, sizeof box);
-                o->valid = true; o->age = 0;
-            } else o->valid = false;
+                                   Q.boxX0, Q.boxY0, Q.boxW, Q.boxH, staged, T.d, c->d_sortViolations);
+                std::memcpy(T.box, box, sizeof box);
+                T.valid = true; T.age = 0;
+            } else T.valid = false;
         }
-        Q.tileOrder = (o->valid && Q.traceWaves > 0) ? o->d_tileOrder : nullptr;
-        if (frameMode && !o->fixed) { Q.tileCost = o->d_tileCost; o->costValid = true; }
-        if (frameMode) o->age++;
+        Q.tileOrder = (T.valid && Q.traceWaves > 0) ? T.d : nullptr;
+        if (frameMode && !fixedOrder) { Q.tileCost = o->d_tileCost; o->costValid = true; }
+        if (frameMode) T.age++;
     }
     return RTO_OK;
 }
@@ -1136,23 +1218,32 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     const bool packed = c->kernelMode >= RTO_KERNEL_PACKED || (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
     if (packed && !c->canonical) return fail(c, RTO_E_UNSUPPORTED, "render: packed kernel needs a canonical BFS octree");
     const bool capturing = stream_is_capturing(s);
+    if (capturing && s != c->stream) c->foreignCaptured = true;
     const bool noEvents = capturing || c->eventsOff;     // events inside a capture cannot be timed; each record costs ~2 us between launches
     bool stopRecorded = false;
     hipEvent_t evA = c->ev0, evB = c->ev1;
     // a timing-ring slot is only taken by a launch that records events (events inside a capture cannot be timed)
     if (!noEvents && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
     bool startRecorded = false;
-    // culling edge (S/RT:765-812): the root was culled but descendants survive.  The reference then starts at whatever
-    // node landed at compacted index 0; only the generic kernel over the compacted array can follow that literally.
-    const bool rootCulledEdge = c->culling && !c->rootVisible && c->visibleNodes > 0;
+    // The lean kernels take the result of a frustum update from the device (StartState: visible at all? start at the root
+    // or -- root culled, descendants visible, S/RT:765-812 -- at the first visible node): nothing to know on the host.
+    // Every other kernel needs the host's copy; for them the culled-root edge goes to the generic kernel over the compacted array.
+    const bool leanKernel = packed && c->canonical && (c->kernelMode == RTO_KERNEL_AUTO || c->kernelMode == RTO_KERNEL_PACKED || c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT);
+    const bool deviceStart = leanKernel && c->culling && c->cullAsync;
+    if (c->culling && !deviceStart) { const int rcState = sync_cull_state(c); if (rcState != RTO_OK) return rcState; }
+    const bool rootCulledEdge = !deviceStart && c->culling && !c->rootVisible && c->visibleNodes > 0;
     if (packed && !rootCulledEdge) {
         const size_t lds = (size_t)(kBlock / kWave) * (P.depth + 1) * kWave * sizeof(uint2);   // +1: the lean kernel's dummy entry
         if (c->kernelMode == RTO_KERNEL_PACKED_V1) {
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
             startRecorded = true;
-            hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_steps, c->d_counters);
+            RenderParams Q = P;
+            Q.rootVisible = c->rootVisible;                 // as of sync_cull_state above
+            hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
         } else {
             RenderParams Q = P;
+            if (deviceStart) { Q.start = c->d_start; Q.rootVisible = 1; }       // what is visible is the device's knowledge: waves for the whole rectangle
+            else Q.rootVisible = c->rootVisible;
             const bool frameMode = MODE == kModeColor || MODE == kModeShade;
             rto_context::OrderState* st = nullptr;
             const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
@@ -1253,7 +1344,7 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
     if (s != c->stream) c->otherStreams = true;
     const bool packed = c->kernelMode >= RTO_KERNEL_PACKED || (c->kernelMode == RTO_KERNEL_AUTO && c->canonical);
     const bool lean = packed && c->canonical && (c->kernelMode == RTO_KERNEL_AUTO || c->kernelMode == RTO_KERNEL_PACKED) &&
-                      !(c->culling && !c->rootVisible && c->visibleNodes > 0);
+                      (!c->culling || c->cullAsync);
     bool sameDepth = true;
     for (int i = 1; i < n; i++) sameDepth = sameDepth && Ps[i].depth == Ps[0].depth;
     if (!lean || n == 1 || !sameDepth) {
@@ -1264,6 +1355,7 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
         return RTO_OK;
     }
     const bool capturing = stream_is_capturing(s);
+    if (capturing && s != c->stream) c->foreignCaptured = true;
     const bool noEvents = capturing || c->eventsOff;
     RenderBatch B;
     B.n = n;
@@ -1271,6 +1363,7 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
     rto_context::OrderState* st = nullptr;
     for (int i = 0; i < n; i++) {
         B.P[i] = Ps[i];
+        if (c->culling) { B.P[i].start = c->d_start; B.P[i].rootVisible = 1; }     // the frustum update's result stays on the device (launch_trace)
         B.out[i] = outs[i];
         if (Ps[i].tilesX * Ps[i].tilesY <= 0) { B.P[i].launchWaves = 0; continue; }
         const int solidRect[4] = { Ps[i].solidX0, Ps[i].solidY0, Ps[i].solidX1, Ps[i].solidY1 };
@@ -1283,8 +1376,9 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
     // it resizes it); any other box falls back to the centre-out order (any permutation of a frame's own box renders it)
     for (int i = 0; i < n; i++) {
         if (!st || B.P[i].launchWaves <= 0 || !B.P[i].tileCost) continue;       // tileCost set: the temporal order is in use for this frame
-        const bool fits = st->valid && B.P[i].boxW == st->box[2] && B.P[i].boxH == st->box[3] && B.P[i].traceWaves > 0;
-        B.P[i].tileOrder = fits ? st->d_tileOrder : nullptr;
+        const rto_context::OrderState::Table& T = st->tab[st->active];
+        const bool fits = T.valid && B.P[i].boxW == T.box[2] && B.P[i].boxH == T.box[3] && B.P[i].traceWaves > 0;
+        B.P[i].tileOrder = fits ? T.d : nullptr;
     }
     if (maxWaves <= 0) return RTO_OK;
     hipEvent_t evA = c->ev0, evB = c->ev1;
@@ -1295,6 +1389,7 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
     hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)((waves + (kBlock / kWave) - 1) / (kBlock / kWave))), dim3(kBlock), lds, s, B, c->d_desc);
     RTO_HIP(c, hipGetLastError());
     if (!noEvents) RTO_HIP(c, hipEventRecord(evB, s));
+    c->lastA = evA; c->lastB = evB;                       // what rto_last_kernel_ms reads
     c->timed = !noEvents;
     return RTO_OK;
 }
@@ -1701,8 +1796,9 @@ static int launch_triangles_batch(rto_context* c, const rto_frame* frames, int n
     }
     for (int i = 0; i < n; i++) {                                   // one box-relative order table per stream: see launch_trace_batch
         if (!st || B.P[i].launchWaves <= 0 || !B.P[i].tileCost) continue;
-        const bool fits = st->valid && B.P[i].boxW == st->box[2] && B.P[i].boxH == st->box[3] && B.P[i].traceWaves > 0;
-        B.P[i].tileOrder = fits ? st->d_tileOrder : nullptr;
+        const rto_context::OrderState::Table& T = st->tab[st->active];
+        const bool fits = T.valid && B.P[i].boxW == T.box[2] && B.P[i].boxH == T.box[3] && B.P[i].traceWaves > 0;
+        B.P[i].tileOrder = fits ? T.d : nullptr;
     }
     if (maxWaves <= 0) return RTO_OK;
     if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev0, s));

@@ -53,6 +53,22 @@ constexpr int kBlock = RTO_BLOCK;         // 4 waves, each owns one 8x8 pixel ti
 #endif
 constexpr int kMaxDepth = 20;             // log2(root size) supported by the packed kernel
 
+// Where a traversal starts while a frustum update is active -- kept ON THE DEVICE (written by k_cull_desc, read by the traversal
+// kernels), so that rto_update_frustum needs no read-back and can be stream-captured.  Normally the root.  If the update
+// culled the root but not all of its descendants, the reference's compacted array begins with the first visible node in BFS
+// order and its traversal starts THERE (S/RT:765-812): that node is recorded here.
+struct StartState {
+    int visible;            // 0: no node survived the update -> nothing is traversed, the frame is black
+    unsigned desc;          // descriptor index of the start node (when it is internal)
+    int x, y, z;            // its position, voxel units
+    int shift;              // log2 of its edge
+    int leaf, solid;        // a terminal start node: the traversal is one pop
+    int rootVisible;        // the root's own flag
+    int firstVisible;       // index of the start node in the uploaded array (0x7fffffff: none)
+    long long visibleCount; // nodes the update kept (== m_visibleNodes.size(), S/RT:775)
+    unsigned ticket;        // k_cull_desc: blocks finished (returns to 0 at the end of every launch)
+};
+
 struct RenderParams {
     float invView[16];     // glm::inverse(view), hoisted from S/RT:348 (pixel independent)
     float camPos[3];
@@ -88,6 +104,7 @@ struct RenderParams {
     int fillTopChunks, fillBotChunks, fillLeftPer, fillRightPer;
     const float* rayX;              // [W]  ((px+.5)/W*2-1)*aspect*tanHalfFov, the separable part of S/RT:341-346 (host-computed)
     const float* rayY;              // [H]  (1-(py+.5)/H*2)*tanHalfFov
+    const StartState* start;        // non-null while a frustum update is active on a canonical tree: replaces rootVisible / the root as start node (lean kernels)
 };
 
 // ---------------------------------------------------------------- scalar helpers
@@ -527,7 +544,12 @@ __device__ __forceinline__ void tile_of(const RenderParams& P, int t, int& tx, i
 __device__ __forceinline__ bool resolve_slot(const RenderParams& P, int slot, int& tx, int& ty, int& tile) {
     tx = 0; ty = P.tilesY; tile = 0;
     if (slot >= P.traceWaves) return false;
-    if (P.tileOrder) { const unsigned e = (unsigned)P.tileOrder[slot]; tx = P.boxX0 + (int)(e & 0xffffu); ty = P.boxY0 + (int)(e >> 16); }   // entries: tile inside the box, x | y << 16
+    if (P.tileOrder) {
+        // entries: tile inside the box, x | y << 16.  Clamped to the box (scalar arithmetic: `slot` is wave-uniform): a table is
+        // only ever a schedule, and whatever it holds no wave may leave the frame's tile arrays
+        const unsigned e = (unsigned)P.tileOrder[slot];
+        tx = P.boxX0 + min((int)(e & 0xffffu), P.boxW - 1); ty = P.boxY0 + min((int)(e >> 16), P.boxH - 1);
+    }
     else tile_of(P, slot, tx, ty);
     tile = ty * P.tilesX + tx;
     return true;
@@ -935,17 +957,26 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
 
     const Geo G = geo_of(P);
     bool hit = false;
-    int steps0 = 0;              // the root's own pop (S/RT:254-270 with nodeIdx 0)
+    int steps0 = 0;              // the start node's own pop (S/RT:254-270 with nodeIdx 0)
     Ray r;
     bool alive = false;
     const bool outsideRoot = px < P.rootX0 || px > P.rootX1 || py < P.rootY0 || py > P.rootY1;
     bool guarded = false;        // this lane's ray needs the tFar > 0 / tNear < 1e30 folds of the child test
-    if (inImage && P.rootVisible) {
+    // the start node: the root, unless a frustum update says otherwise (StartState; wave-uniform scalar loads)
+    int startVisible = P.rootVisible, startShift = P.depth, startSize = P.rootSize, startX = 0, startY = 0, startZ = 0;
+    unsigned startDesc = 0;
+    bool startLeaf = false, startSolid = false;
+    if (P.start) {
+        const StartState st = *P.start;
+        startVisible = st.visible; startShift = st.shift; startSize = 1 << st.shift; startX = st.x; startY = st.y; startZ = st.z;
+        startDesc = st.desc; startLeaf = st.leaf != 0; startSolid = st.solid != 0;
+    }
+    if (inImage && startVisible) {
         steps0 = 1;
         if (!outsideRoot) {
             r = generate_ray_tab(P, px, py);
             float tNear, tFar, a0, a1, a2, a3, a4, a5;
-            alive = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+            alive = slab_exact(G, r, startX, startY, startZ, startSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
             // The ray starts well outside the root box: its entry is at least 1/1024 of its exit away, leaves it below 1e29,
             // and lies more than 8 ulps of the largest coordinate involved -- as a ray parameter, on the steepest axis --
             // from the origin: a child's planes may differ from the root's by an ulp, which then cannot move a child's
@@ -967,9 +998,9 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     // with bitwise selects on all-ones masks instead of v_cmp + v_cndmask, levels are indexed by the child-edge exponent
     // b = depth-1-level (what the arithmetic needs) and the stack write is unconditional (a lane owns its LDS column;
     // a finished lane's column is never read again except by its own identity-(2) walk, which a hit keeps valid).
-    unsigned cur = 0;
-    int cx = (int)kCoordBias, cy = (int)kCoordBias, cz = (int)kCoordBias;   // node position, biased (child_axis_terms): the bit operations below never touch the bias
-    int bpos = P.depth - 1;                                             // log2 of the edge of the current node's children
+    unsigned cur = startDesc;
+    int cx = (int)(kCoordBias | (unsigned)startX), cy = (int)(kCoordBias | (unsigned)startY), cz = (int)(kCoordBias | (unsigned)startZ);   // node position, biased (child_axis_terms): the bit operations below never touch the bias
+    int bpos = startShift - 1;                                          // log2 of the edge of the current node's children
     unsigned lvlPending = 0;                                            // bit b: the entry of exponent b still has unpopped candidates
     const unsigned sentinel = 1u << P.depth;                            // entry `depth` is a dummy: what "nothing pending" reads
     int S = 0;                                                          // identity (1): children pushed so far
@@ -978,6 +1009,7 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
                    sgnZ = (unsigned)((int)__float_as_uint(r.iz) >> 31);          // all ones: the reciprocal direction is negative
     const char* descBytes = reinterpret_cast<const char*>(desc);
     int trips = 0;                                                      // wave-uniform trip count = this tile's cost
+    if (startLeaf) { hit = alive && startSolid; alive = false; }        // a terminal start node (culled-root edge only): one pop, S/RT:277-288
     while (alive) {
         trips++;
         const uint2 d = *reinterpret_cast<const uint2*>(descBytes + (cur << 3));
@@ -1031,7 +1063,7 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     int steps = steps0 + S;
     if (hit && (MODE == kModeSteps || steps > kMaxTraversalSteps)) {
         int R = 0;
-        for (int b = P.depth - 1; b > bpos; b--) {                       // the entries of the leaf's ancestors
+        for (int b = startShift - 1; b > bpos; b--) {                    // the entries of the leaf's ancestors (from the start node down)
             const unsigned w = stk[b * kWave].x;
             const unsigned jl = ((cx >> b) & 1) | (((cy >> b) & 1) << 1) | (((cz >> b) & 1) << 2);
             R += __builtin_popcount(__builtin_amdgcn_ubfe(w, 16, 8) & ((1u << jl) - 1u));
@@ -1312,6 +1344,116 @@ __global__ __launch_bounds__(kBlock) void k_desc_vismask(const uint8_t* __restri
 __global__ __launch_bounds__(kBlock) void k_desc_visall(int64_t nInternal, uint2* __restrict__ desc) {
     int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (d < nInternal) desc[d].x |= 0xff0000u;
+}
+
+// position and size of every internal node of a canonical tree (descriptor order): child 0 shares its parent's origin
+__global__ __launch_bounds__(kBlock) void k_desc_pos(const rto_node* __restrict__ nodes, const int* __restrict__ descFirstChild, int64_t nInternal,
+                                                      int4* __restrict__ descPos) {
+    int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (d >= nInternal) return;
+    const rto_node* c0 = nodes + descFirstChild[d];
+    descPos[d] = make_int4(c0->x, c0->y, c0->z, c0->size * 2);
+}
+
+// The whole frustum update of a canonical tree in ONE launch, nothing read back (rto_update_frustum): thread d tests the 8
+// children of internal node d (every node but the root is the child of exactly one internal node; thread 0 adds the root) with
+// the same float operations as k_cull_flags on the same integer coordinates -- positions come from descPos (16 B per internal
+// node, 0.75 MB at config 2) instead of the 60-byte records (22.5 MB) --, writes their flags (`vis`: the visibility map
+// octreeRaySkip and the on-demand compaction read) and the visibility byte of its descriptor.  The block that finishes last
+// (ticket) reduces the blocks' counts / first visible indices and records where traversals start (StartState): the root, or
+// -- root culled, descendants visible: S/RT:765-812 -- the first visible node in BFS order, whose descriptor it finds by
+// walking down from the root along the node's coordinates.  Partials cross XCDs: agent-scope stores / loads around the ticket.
+__global__ __launch_bounds__(kBlock) void k_cull_desc(CullParams C, const int4* __restrict__ descPos, const int* __restrict__ descFirstChild,
+                                                       const rto_node* __restrict__ nodes, int64_t nInternal, int depth,
+                                                       uint2* __restrict__ desc, uint8_t* __restrict__ vis,
+                                                       int* __restrict__ blockCount, int* __restrict__ blockFirst, StartState* __restrict__ start) {
+    __shared__ int redCount[kBlock / kWave], redFirst[kBlock / kWave];
+    __shared__ int isLast;
+    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int cnt = 0, first = 0x7fffffff;
+    if (d < nInternal) {
+        const int4 p = descPos[d];
+        const int half = p.w >> 1;
+        const int c0 = descFirstChild[d];
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool v = node_visible(C, p.x + ((k & 1) ? half : 0), p.y + ((k & 2) ? half : 0), p.z + ((k & 4) ? half : 0), half);
+            m |= v ? (1u << k) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) vis[c0 + k] = (uint8_t)((m >> k) & 1u);      // c0 = 1 (mod 8): byte stores, contiguous across the threads of a wave
+        desc[d].x = (desc[d].x & 0xff00ffffu) | (m << 16);
+        cnt = __builtin_popcount(m);
+        if (m) first = c0 + __builtin_ctz(m);
+        if (d == 0) {                                        // the root itself
+            const bool v = node_visible(C, p.x, p.y, p.z, p.w);
+            vis[0] = v ? 1 : 0;
+            cnt += v ? 1 : 0;
+            if (v) first = 0;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { cnt += __shfl_down(cnt, off); first = min(first, __shfl_down(first, off)); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { redCount[wave] = cnt; redFirst[wave] = first; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0, f = 0x7fffffff;
+        for (int w = 0; w < kBlock / kWave; w++) { c += redCount[w]; f = min(f, redFirst[w]); }
+        __hip_atomic_store(&blockCount[blockIdx.x], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&blockFirst[blockIdx.x], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();                                     // release: the partials before the ticket
+        const unsigned t = atomicAdd(&start->ticket, 1u);
+        isLast = t == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!isLast) return;
+    __threadfence();                                         // acquire: every block's partials
+    long long total = 0;
+    int f = 0x7fffffff;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += kBlock) {
+        total += __hip_atomic_load(&blockCount[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f = min(f, __hip_atomic_load(&blockFirst[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    for (int off = 32; off > 0; off >>= 1) { total += __shfl_down(total, off); f = min(f, __shfl_down(f, off)); }
+    __shared__ long long redTotal[kBlock / kWave];
+    if (lane == 0) { redTotal[wave] = total; redFirst[wave] = f; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    total = 0; f = 0x7fffffff;
+    for (int w = 0; w < kBlock / kWave; w++) { total += redTotal[w]; f = min(f, redFirst[w]); }
+    StartState st;
+    st.visible = total > 0 ? 1 : 0;
+    st.desc = 0; st.x = st.y = st.z = 0; st.shift = depth; st.leaf = 0; st.solid = 0;
+    st.rootVisible = f == 0 ? 1 : 0;
+    st.firstVisible = f;
+    st.visibleCount = total;
+    st.ticket = 0;                                           // the next launch (or graph replay) starts from zero again
+    if (total > 0 && f != 0) {
+        // root culled, descendants visible: the traversal starts at the first visible node in BFS order
+        const rto_node nd = nodes[f];
+        st.x = nd.x; st.y = nd.y; st.z = nd.z;
+        int sh = 0;
+        while ((1 << sh) < nd.size) sh++;
+        st.shift = sh;
+        st.leaf = (nd.isUniform == 1 || nd.isLeaf == 1) ? 1 : 0;
+        st.solid = nd.isSolid == 1 ? 1 : 0;
+        unsigned cur = 0;
+        for (int b = depth - 1; b >= sh; b--) {              // child-edge exponent b: the step from edge 2^(b+1) to 2^b
+            const unsigned j = ((nd.x >> b) & 1) | (((nd.y >> b) & 1) << 1) | (((nd.z >> b) & 1) << 2);
+            const uint2 e = desc[cur];
+            cur = e.y + (unsigned)__builtin_popcount((e.x >> 8) & 0xffu & ((1u << j) - 1u));
+        }
+        st.desc = cur;                                       // meaningful only for an internal start node
+    }
+    *start = st;
+}
+
+// per-block count of visible nodes from the flags (the compaction is made on demand: ensure_compact)
+__global__ __launch_bounds__(kBlock) void k_vis_block_counts(const uint8_t* __restrict__ vis, int64_t n, int* __restrict__ blockCount) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int cnt = __syncthreads_count((i < n && vis[i]) ? 1 : 0);
+    if (threadIdx.x == 0) blockCount[blockIdx.x] = cnt;
 }
 
 // ================================================================ N2: leaf triangles + shadow ray (config 5)

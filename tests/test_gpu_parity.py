@@ -386,13 +386,15 @@ def test_frustum_update_equals_reference_compaction(ctx, orc, scenes, camera, ca
         assert_bit_exact(ctx.render_host(f2), full, f"culling off {kname}")
 
 
-def test_culled_root_with_surviving_descendants_follows_the_reference(ctx, orc):
+@pytest.mark.parametrize("first_survivor", ["solid leaf", "internal node"])
+def test_culled_root_with_surviving_descendants_follows_the_reference(ctx, orc, first_survivor):
     """A7, literally (RayTracerBVH.cpp:765-812): when the frustum test drops the ROOT but keeps descendants, the reference's
     compacted array starts with whatever visible node comes first, and its traversal starts there.  Nested boxes make that
     impossible in exact arithmetic; in float it needs a plane through a corner where the root's nodeMax and a child's differ
     by an ulp (gridMin + 0*vs + size*vs vs (gridMin + x*vs) + half*vs).  The debug hook injects such a plane; every
-    kernel choice must then render what the oracle renders from the compacted array (the packed kernels hand the frame to
-    the generic kernel over the compacted array)."""
+    kernel choice must then render what the oracle renders from the compacted array: the default kernel starts its traversal at
+    the node the update recorded on the device (StartState: a leaf -> one pop; an internal node -> its descriptor), the A/B
+    kernels hand the frame to the generic kernel over the compacted array."""
     rng = np.random.default_rng(4)
     found = None
     for _ in range(4000):
@@ -414,7 +416,10 @@ def test_culled_root_with_surviving_descendants_follows_the_reference(ctx, orc):
     # index 0 of the compacted array, where the reference's traversal starts: make it a solid leaf so that there is something to see
     sl = [slice(0, 8)] * 3                               # data is [z][y][x]
     sl[2 - a] = slice(8, 16)
-    data[tuple(sl)] = 1
+    if first_survivor == "solid leaf":
+        data[tuple(sl)] = 1
+    else:                                                # ... or a mixed cell: the traversal then starts at an internal node
+        data[tuple(sl)] = (rng.random((8, 8, 8)) < 0.5).astype(np.uint8)
     g = orc.Grid((16, 16, 16), gmin, vs, data)
     nodes = orc.build_flat_octree(g)
     s = Scene(g, nodes)
@@ -426,6 +431,7 @@ def test_culled_root_with_surviving_descendants_follows_the_reference(ctx, orc):
     planes[0, 3] = -child_mx                            # n = +axis: the positive vertex is nodeMax[a] (+ margin 0)
     want_nodes, vis = orc.cull_compact_planes(nodes, gmin, vs, planes, 0.0)
     assert not vis[0] and vis.any(), "the construction must cull the root and keep descendants"
+    assert (want_nodes[0]["isLeaf"] == 1) == (first_survivor == "solid leaf")
     ctx.debug_update_frustum_planes(planes, 0.0)
     assert ctx.info().visible_nodes == len(want_nodes)
     assert ctx.download_visible_nodes().tobytes() == want_nodes.tobytes()
@@ -446,6 +452,65 @@ def test_culled_root_with_surviving_descendants_follows_the_reference(ctx, orc):
     finally:
         ctx.set_kernel(rto.KERNEL_AUTO)
         ctx.update_frustum(view, 45.0, W / H, enable=False)
+
+
+def test_frustum_update_reads_nothing_back_and_can_be_captured(ctx, orc, scenes, camera):
+    """rto_update_frustum on a canonical tree is ONE kernel on the context's stream and reads nothing back: where traversals
+    start and how many nodes survived stay on the device (the traversal kernels read them there; rto_octree_info_get fetches
+    the count when asked).  So `update + render` -- the call main.cpp:1357-1363 makes every frame -- can be stream-captured
+    and replayed; plain updates in between do not confuse a replay, and the count follows the state the replay left."""
+    torch = pytest.importorskip("torch")
+    cal = scenes("calgary")
+    W, H = 480, 270
+    aspect = W / H
+    upload(ctx, cal)
+    cams = [camera("calgary_oblique"), (orc.Camera(0.9, 2.5, 3000.0).get_view(), orc.Camera(0.9, 2.5, 3000.0).get_pos())]
+    wants, counts, frames = [], [], []
+    for view, pos in cams:
+        nodes_c, vis = orc.cull_compact(cal.nodes, cal.min, cal.voxel, view, 45.0, aspect)
+        wants.append(orc.render(nodes_c, cal.min, cal.voxel, view, pos, aspect, 45.0, W, H)[0])
+        counts.append(len(nodes_c))
+        frames.append(rto.make_frame(view, pos, aspect, 45.0, W, H))
+    try:
+        ctx.update_frustum(cams[0][0], 45.0, aspect, enable=True)          # the first update of an octree allocates: outside the capture
+        ctx.render_resident(frames[0])
+        assert_bit_exact(ctx.download_resident(), wants[0], "update + resident render, camera 0")
+        assert ctx.info().visible_nodes == counts[0]
+        s = torch.cuda.ExternalStream(ctx.stream)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ctx.update_frustum(cams[1][0], 45.0, aspect, enable=True)
+            ctx.render_resident(frames[1])
+        for _ in range(2):
+            ctx.update_frustum(cams[0][0], 45.0, aspect, enable=True)      # a plain update + frame in between
+            ctx.render_resident(frames[0])
+            assert_bit_exact(ctx.download_resident(), wants[0], "plain update between replays")
+            assert ctx.info().visible_nodes == counts[0]
+            with torch.cuda.stream(s):
+                g.replay()
+            assert_bit_exact(ctx.download_resident(), wants[1], "replayed update + render, camera 1")
+            assert ctx.info().visible_nodes == counts[1], "the count is fetched from the device when asked for"
+        del g
+        # the A/B kernels take the update's result from the host's copy (fetched on demand): same frame
+        ctx.update_frustum(cams[0][0], 45.0, aspect, enable=True)
+        for kname, kernel in KERNELS:
+            ctx.set_kernel(kernel)
+            assert_bit_exact(ctx.render_host(frames[0]), wants[0], f"after an asynchronous update, {kname}")
+    finally:
+        ctx.set_kernel(rto.KERNEL_AUTO)
+        ctx.update_frustum(cams[0][0], 45.0, aspect, enable=False)
+    # a context whose first update would have to allocate refuses inside a capture instead of breaking it
+    fresh = rto.Context(0)
+    try:
+        fresh.upload_octree(scenes("sphere16").nodes, scenes("sphere16").min, scenes("sphere16").voxel)
+        s2 = torch.cuda.ExternalStream(fresh.stream)
+        g2 = torch.cuda.CUDAGraph()
+        with pytest.raises(rto.RtoError) as e:
+            with torch.cuda.graph(g2, stream=s2):
+                fresh.update_frustum(cams[0][0], 45.0, aspect, enable=True)
+        assert e.value.code == hip.RTO_E_UNSUPPORTED
+    finally:
+        fresh.close()
 
 
 def test_persistent_kernel_in_a_graph_with_an_odd_frame_count(ctx, orc, scenes):
@@ -774,8 +839,10 @@ def test_resident_frame_stays_on_the_gpu(ctx, orc, scenes, camera):
 def test_frames_captured_in_a_hip_graph_replay_exactly(ctx, orc, scenes):
     """rto_render_device is stream-capturable after a warm-up frame (no allocation, no synchronisation): 24 frames of 6
     cameras captured once (more frames than a launch-order period, an odd number of would-be rebuilds) and replayed
-    three times give the oracle's pixels every time.  While capturing, the launch-order table is frozen, so a replay
-    finds the device state it was captured with."""
+    three times give the oracle's pixels every time.  Captured launches keep a launch-order table of their own and every
+    capture starts with a rebuild node, so a replay depends on nothing outside its graph: plain frames whose tile box has
+    ANOTHER size (a camera much closer / much further away), a second graph and the graph's own tail in between replays
+    change nothing -- buffers are poisoned before every replay so that a skipped or duplicated tile cannot hide."""
     torch = pytest.importorskip("torch")
     s = scenes("sphere64")
     upload(ctx, s)
@@ -807,6 +874,39 @@ def test_frames_captured_in_a_hip_graph_replay_exactly(ctx, orc, scenes):
             ctx.render_device(frames[1], bufs[1].data_ptr(), None, stream.cuda_stream)
         torch.cuda.synchronize()
         assert_bit_exact(bufs[1].cpu().numpy(), wants[1], "plain launches after the graph")
+        # plain frames with tile boxes of other sizes on the capture stream (each rebuilds the PLAIN table), a second graph of
+        # one far-away camera, then the first graph again: every replay must still render its own cameras exactly
+        near, far = orc.Camera(0.5, 0.7, 1.1), orc.Camera(0.5, 0.7, 4.0)
+        others = []
+        for c in (near, far):
+            fr = rto.make_frame(c.get_view(), c.get_pos(), W / H, 45.0, W, H)
+            others.append((fr, oracle_frame(orc, s, c.get_view(), c.get_pos(), W, H)[0]))
+        scratch = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            for _ in range(4):
+                ctx.render_device(others[1][0], scratch.data_ptr(), None, stream.cuda_stream)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g2, stream=stream):
+                for _ in range(5):
+                    ctx.render_device(others[1][0], scratch.data_ptr(), None, stream.cuda_stream)
+            for rep in range(3):
+                for fr, want in others:                      # plain launches: boxes larger and smaller than the graphs' frames
+                    for _ in range(4):
+                        scratch.fill_(7.0)
+                        ctx.render_device(fr, scratch.data_ptr(), None, stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    assert_bit_exact(scratch.cpu().numpy(), want, f"plain frame with another box, round {rep}")
+                scratch.fill_(7.0)
+                g2.replay()
+                torch.cuda.synchronize()
+                assert_bit_exact(scratch.cpu().numpy(), others[1][1], f"second graph, round {rep}")
+                for b in bufs:
+                    b.fill_(7.0)
+                g.replay()
+                torch.cuda.synchronize()
+                for i in range(6):
+                    assert_bit_exact(bufs[i].cpu().numpy(), wants[i], f"first graph after foreign frames, round {rep}, camera {i}")
         assert ctx.debug_sort_violations() == 0
     finally:
         ctx.set_launch_order(1, 8)
