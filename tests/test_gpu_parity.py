@@ -400,12 +400,14 @@ def test_culled_root_with_surviving_descendants_follows_the_reference(ctx, orc, 
     for _ in range(4000):
         dim = 16
         gmin = rng.uniform(-60, 60, 3).astype(np.float32)
-        vs = np.float32(rng.choice([0.7, 3.3, 0.37, 1.9]))
+        vs = np.float32(rng.choice([0.7, 3.3, 0.37, 1.9])) if first_survivor == "solid leaf" else np.float32(rng.uniform(0.2, 4.0))
         for a in range(3):
             root_mx = np.float32(np.float32(gmin[a] + np.float32(0) * vs) + np.float32(dim) * vs)
             child_mx = np.float32(np.float32(gmin[a] + np.float32(dim // 2) * vs) + np.float32(dim // 2) * vs)
-            if child_mx > root_mx:
-                found = (gmin, vs, a, root_mx, child_mx)
+            # the internal-node variant also needs the far quarter (x = 12, size 4) to stick out of the root: its solid leaves must survive too
+            quarter_mx = np.float32(np.float32(gmin[a] + np.float32(12) * vs) + np.float32(4) * vs)
+            if child_mx > root_mx and (first_survivor == "solid leaf" or quarter_mx > root_mx):
+                found = (gmin, vs, a, root_mx, child_mx if first_survivor == "solid leaf" else min(child_mx, quarter_mx))
                 break
         if found:
             break
@@ -418,8 +420,10 @@ def test_culled_root_with_surviving_descendants_follows_the_reference(ctx, orc, 
     sl[2 - a] = slice(8, 16)
     if first_survivor == "solid leaf":
         data[tuple(sl)] = 1
-    else:                                                # ... or a mixed cell: the traversal then starts at an internal node
+    else:                                                # ... or a mixed cell (near half noise, far half solid): the traversal starts at an internal node
         data[tuple(sl)] = (rng.random((8, 8, 8)) < 0.5).astype(np.uint8)
+        sl[2 - a] = slice(12, 16)
+        data[tuple(sl)] = 1
     g = orc.Grid((16, 16, 16), gmin, vs, data)
     nodes = orc.build_flat_octree(g)
     s = Scene(g, nodes)
