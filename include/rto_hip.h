@@ -344,6 +344,14 @@ int  rto_debug_timeline(rto_context* ctx, const rto_frame* frame, int32_t* host_
  * slot -> tile table (NULL restores the automatic one). */
 int  rto_debug_tile_cost(rto_context* ctx, int32_t* host_cost, int64_t capacity, int64_t* count);
 int  rto_debug_set_tile_order(rto_context* ctx, const int32_t* host_order, int64_t n);
+/* The occupancy mask: in front of every colour / shade frame of the default kernels one small kernel
+ * projects the octree's coarse cells (its internal nodes at one depth + the solid leaves above it) onto the screen and stamps
+ * the 8x8 tiles they can touch; waves of other tiles write black without setting up a single ray (about two thirds of the
+ * rays inside the geometry's screen rectangle miss everything).  A scheduling device like the launch order: pixels never
+ * depend on it.  rto_debug_set_tile_mask(ctx, 0) switches it off (A/B measurements); _info: the depth the cells are taken
+ * from and their number (0: no mask for this octree). */
+int  rto_debug_set_tile_mask(rto_context* ctx, int enabled);
+int  rto_debug_tile_mask_info(const rto_context* ctx, int* level, int* num_cells);
 /* Writes the launch-order sort refused because they fell outside the table (must be 0; synchronises). */
 int  rto_debug_sort_violations(rto_context* ctx, int* count);
 /* Device time in ms of the most recent traversal kernel launched by this context

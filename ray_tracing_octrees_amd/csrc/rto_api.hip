@@ -83,6 +83,8 @@ struct rto_context {
         bool costValid = false;         // a frame of this geometry has recorded its costs
         bool fixed = false;             // debug: the caller supplied the table (over ALL tiles), do not rebuild it
         int* d_queue = nullptr;         // persistent-threads variant: the slot counter (zeroed in front of every launch)
+        unsigned* d_tileMask = nullptr; // occupancy masks of the frames of one launch: kMaxBatch regions of maskWords words (k_tile_mask)
+        size_t maskWords = 0;           // strips * tilesX + 1 of the frame size the buffer was made for
         unsigned long lastUse = 0;      // orderClock value of the last launch on this stream (eviction order)
     };
     std::map<hipStream_t, OrderState> orders;
@@ -90,6 +92,12 @@ struct rto_context {
     static constexpr size_t kMaxOrderStreams = 16;   // a 17th stream evicts the least recently used entry
     unsigned long orderClock = 0;
     int* d_sortViolations = nullptr;            // k_sort_scatter: out-of-range writes refused (must stay 0; rto_debug_sort_violations)
+
+    // occupancy mask: the coarse cells of the tree at level cellLevel, projected per frame by k_tile_mask
+    int4* d_cells = nullptr;
+    int numCells = 0, cellLevel = 0;
+    unsigned maskStamp = 0;                     // one fresh value per frame launched
+    bool maskEnabled = true;                    // rto_debug_set_tile_mask
 
     // voxels retained by rto_build_octree (so that rto_build_leaf_triangles can run without a second upload)
     uint8_t* d_vox = nullptr;
@@ -151,7 +159,6 @@ static hipError_t fallible_malloc(void** p, size_t bytes) {
 }
 
 static void free_cull_buffers(rto_context* c) {
-    (void)hipFree(c->d_descPos); c->d_descPos = nullptr;
     (void)hipFree(c->d_cullBlockCount); c->d_cullBlockCount = nullptr;
     (void)hipFree(c->d_cullBlockFirst); c->d_cullBlockFirst = nullptr;
     c->cullAsync = false; c->cullStateStale = false; c->cullCaptured = false;
@@ -173,6 +180,8 @@ static void free_octree(rto_context* c) {
     if (!c->descPooled) (void)hipFree(c->d_descFirstChild);
     c->d_descFirstChild = nullptr; c->descPooled = false;
     free_cull_buffers(c);
+    (void)hipFree(c->d_descPos); c->d_descPos = nullptr;
+    (void)hipFree(c->d_cells); c->d_cells = nullptr; c->numCells = 0; c->cellLevel = 0;
     (void)hipFree(c->d_tris); c->d_tris = nullptr;
     (void)hipFree(c->d_triOffset); c->d_triOffset = nullptr;
     (void)hipFree(c->d_triRec); c->d_triRec = nullptr;
@@ -240,7 +249,7 @@ void rto_destroy(rto_context* c) {
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_rayX);
     (void)hipFree(c->d_rayY);
-    for (auto& kv : c->orders) { (void)hipFree(kv.second.d_tileCost); (void)hipFree(kv.second.tab[0].d); (void)hipFree(kv.second.tab[1].d); (void)hipFree(kv.second.d_queue); }
+    for (auto& kv : c->orders) { (void)hipFree(kv.second.d_tileCost); (void)hipFree(kv.second.tab[0].d); (void)hipFree(kv.second.tab[1].d); (void)hipFree(kv.second.d_queue); (void)hipFree(kv.second.d_tileMask); }
     c->orders.clear();
     (void)hipFree(c->d_mcCases);
     (void)hipFree(c->d_steps);
@@ -313,6 +322,8 @@ static bool build_descriptors(const rto_node* nodes, int64_t n, std::vector<uint
 
 static void bounds_from_nodes(const rto_node* nodes, int64_t n, const float grid_min[3], float voxel_size, rto_scene_bounds* b);   // rto_split.inc
 
+static int build_cells(rto_context* c);
+
 extern "C" {
 
 int rto_upload_octree(rto_context* c, const rto_node* nodes, int64_t n, const float grid_min[3], float voxel_size) {
@@ -353,7 +364,7 @@ int rto_upload_octree(rto_context* c, const rto_node* nodes, int64_t n, const fl
         c->numInternal = internal;
         c->rootSize = nodes[0].size;
     }
-    return RTO_OK;
+    return build_cells(c);
 }
 
 }  // extern "C"
@@ -383,6 +394,49 @@ struct BuildScratch {
     }
 };
 }  // namespace
+
+// Per-octree derived data of canonical trees, made once after upload / build on the context's stream (synchronises):
+// descPos (position + size of every internal node: the frustum update and the cells read it) and the coarse cells of the
+// occupancy mask -- the deepest level whose cells (internal nodes at that depth + solid leaves at or above it) number at most
+// kMaskMaxCells.
+constexpr int kMaskMaxCells = 32768;
+static int build_cells(rto_context* c) {
+    (void)hipFree(c->d_descPos); c->d_descPos = nullptr;
+    (void)hipFree(c->d_cells); c->d_cells = nullptr; c->numCells = 0; c->cellLevel = 0;
+    if (!c->canonical || c->numInternal <= 0) return RTO_OK;
+    hipStream_t s = c->stream;
+    const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
+    RTO_HIP(c, hipMalloc(&c->d_descPos, (size_t)c->numInternal * sizeof(int4)));
+    hipLaunchKernelGGL(k_desc_pos, dim3(nbInt), dim3(kBlock), 0, s, c->d_nodes, c->d_descFirstChild, c->numInternal, c->d_descPos);
+    BuildScratch scratch(s);
+    int* d_counts = nullptr;
+    constexpr int kN = 2 * (kMaxDepth + 1);
+    RTO_HIP(c, scratch.alloc(&d_counts, (size_t)kN + 1));                    // + the fill cursor
+    RTO_HIP(c, hipMemsetAsync(d_counts, 0, (kN + 1) * sizeof(int), s));
+    hipLaunchKernelGGL(k_cells_count, dim3(nbInt), dim3(kBlock), 0, s, c->d_desc, c->d_descPos, c->numInternal, c->depth, d_counts);
+    RTO_HIP(c, hipGetLastError());
+    int counts[kN];
+    RTO_HIP(c, hipMemcpyAsync(counts, d_counts, sizeof counts, hipMemcpyDeviceToHost, s));
+    RTO_HIP(c, hipStreamSynchronize(s));
+    int level = 0;
+    long long solidAbove = 0, best = 0;
+    for (int L = 1; L <= c->depth && L <= kMaxDepth; L++) {
+        solidAbove += counts[kMaxDepth + 1 + L];
+        const long long n = counts[L] + solidAbove;
+        if (n > kMaskMaxCells) break;
+        level = L; best = n;
+    }
+    if (level == 0 || best <= 0) return RTO_OK;                              // nothing solid, or already too many cells at depth 1
+    RTO_HIP(c, hipMalloc(&c->d_cells, (size_t)best * sizeof(int4)));
+    hipLaunchKernelGGL(k_cells_fill, dim3(nbInt), dim3(kBlock), 0, s, c->d_desc, c->d_descPos, c->numInternal, c->depth, level, c->d_cells, (int)best, d_counts + kN);
+    RTO_HIP(c, hipGetLastError());
+    int filled = 0;
+    RTO_HIP(c, hipMemcpyAsync(&filled, d_counts + kN, sizeof filled, hipMemcpyDeviceToHost, s));
+    RTO_HIP(c, hipStreamSynchronize(s));
+    if (filled != (int)best) return fail(c, RTO_E_HIP, "occupancy cells: count and fill disagree");
+    c->numCells = (int)best; c->cellLevel = level;
+    return RTO_OK;
+}
 
 // The four-launch build (k_mb_*): fills c->d_nodes / d_desc / d_descFirstChild from c->d_vox.  *total / *internal: sizes;
 // solidBox: lo[3], hi[3] of the cells that hold FILLED voxels (level-1 cell precision; lo > hi: nothing solid).
@@ -611,7 +665,7 @@ int rto_build_octree(rto_context* c, const uint8_t* voxels, int dimX, int dimY, 
     c->numNodes = total; c->visibleNodes = total; c->numInternal = internal;
     c->rootSize = 1 << R; c->depth = R;
     c->canonical = internal > 0;                 // a one-node tree is rendered by the generic kernel
-    return RTO_OK;
+    return build_cells(c);
 }
 
 int rto_debug_set_build_path(rto_context* c, int level_by_level) {
@@ -691,9 +745,22 @@ int rto_forget_stream(rto_context* c, void* hip_stream) {
     if (it == c->orders.end()) return RTO_OK;
     RTO_HIP(c, hipSetDevice(c->device));
     RTO_HIP(c, hipDeviceSynchronize());          // no kernel still reads the tables
-    (void)hipFree(it->second.d_tileCost); (void)hipFree(it->second.tab[0].d); (void)hipFree(it->second.tab[1].d); (void)hipFree(it->second.d_queue);
+    (void)hipFree(it->second.d_tileCost); (void)hipFree(it->second.tab[0].d); (void)hipFree(it->second.tab[1].d); (void)hipFree(it->second.d_queue); (void)hipFree(it->second.d_tileMask);
     if (c->lastOrderStream == it->first) c->lastOrderStream = nullptr;
     c->orders.erase(it);
+    return RTO_OK;
+}
+
+int rto_debug_set_tile_mask(rto_context* c, int enabled) {
+    if (!c) return RTO_E_INVALID;
+    c->maskEnabled = enabled != 0;
+    return RTO_OK;
+}
+
+int rto_debug_tile_mask_info(const rto_context* c, int* level, int* num_cells) {
+    if (!c) return RTO_E_INVALID;
+    if (level) *level = c->cellLevel;
+    if (num_cells) *num_cells = c->numCells;
     return RTO_OK;
 }
 
@@ -777,7 +844,7 @@ static int update_frustum_planes(rto_context* c, const float planes[24], float m
     const int64_t n = c->numNodes;
     const int nb = (int)((n + kBlock - 1) / kBlock);
     const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
-    const bool canon = c->canonical && nbInt > 0;
+    const bool canon = c->canonical && nbInt > 0 && c->d_descPos;
     const bool capturing = stream_is_capturing(c->stream);
     if (!c->d_vis) {
         if (capturing)
@@ -789,7 +856,6 @@ static int update_frustum_planes(rto_context* c, const float planes[24], float m
         if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_blockBase), (size_t)nb * sizeof(int));
         if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_compact), (size_t)n * sizeof(rto_node));
         if (canon) {
-            if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_descPos), (size_t)c->numInternal * sizeof(int4));
             if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_cullBlockCount), (size_t)nbInt * sizeof(int));
             if (e == hipSuccess) e = fallible_malloc(reinterpret_cast<void**>(&c->d_cullBlockFirst), (size_t)nbInt * sizeof(int));
         }
@@ -797,10 +863,7 @@ static int update_frustum_planes(rto_context* c, const float planes[24], float m
             free_cull_buffers(c);
             return fail(c, RTO_E_HIP, std::string("rto_update_frustum: buffer allocation: ") + hipGetErrorString(e));
         }
-        if (canon) {
-            hipLaunchKernelGGL(k_desc_pos, dim3(nbInt), dim3(kBlock), 0, c->stream, c->d_nodes, c->d_descFirstChild, c->numInternal, c->d_descPos);
-            RTO_HIP(c, hipMemsetAsync(c->d_start, 0, sizeof(StartState), c->stream));      // the ticket starts at zero
-        }
+        if (canon) RTO_HIP(c, hipMemsetAsync(c->d_start, 0, sizeof(StartState), c->stream));      // the ticket starts at zero
     }
     CullParams C;
     std::memcpy(C.planes, planes, sizeof C.planes);
@@ -1081,6 +1144,8 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     P.rayX = c->d_rayX; P.rayY = c->d_rayY;
     P.tileOrder = nullptr; P.tileCost = nullptr;
     P.start = nullptr;                     // the lean kernels' launchers point it at the device-side start state while culling is active
+    P.tileMask = nullptr; P.maskStamp = 0; P.maskAllIndex = 0;             // prepare_schedule switches the occupancy mask on for lean colour / shade frames
+    for (int r = 0; r < 3; r++) for (int k = 0; k < 4; k++) P.viewRows[r * 4 + k] = f->view[k * 4 + r];   // column-major glm matrix -> rows
     {   // rays through pixels outside these rectangles miss the root box / every solid leaf for certain
         int rr[4], sr[4];
         frame_rectangles(bounds_of(c), f, P.tanHalfFov, rr, sr);
@@ -1129,7 +1194,7 @@ static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, bool 
             if (jt->second.lastUse < victim->second.lastUse) victim = jt;
         (void)hipDeviceSynchronize();
         (void)hipFree(victim->second.d_tileCost); (void)hipFree(victim->second.tab[0].d); (void)hipFree(victim->second.tab[1].d);
-        (void)hipFree(victim->second.d_queue);
+        (void)hipFree(victim->second.d_queue); (void)hipFree(victim->second.d_tileMask);
         if (c->lastOrderStream == victim->first) c->lastOrderStream = nullptr;
         c->orders.erase(victim);
     }
@@ -1143,13 +1208,31 @@ static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, bool 
 // the costs earlier frames recorded.  frameMode: a colour / shade frame (records costs); otherwise (instrumentation) the
 // whole image keeps one wave per tile.  On return Q holds the geometry, the table and the cost pointer.
 static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool frameMode, bool timelineMode, int path, const int rect[4],
-                            RenderParams& Q, rto_context::OrderState** stOut) {
+                            RenderParams& Q, rto_context::OrderState** stOut, int maskRegion = -1) {
     const RenderParams& P = Q;
     const int tiles = P.tilesX * P.tilesY;
     Q.tileOrder = nullptr; Q.tileCost = nullptr;
     const long key[7] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles, path };
     rto_context::OrderState* st = order_state(c, s, capturing);      // this stream's scheduling state
     *stOut = st;
+    // occupancy mask (maskRegion >= 0: the caller runs a lean kernel and launches k_tile_mask for this frame: launch_tile_masks)
+    if (st && maskRegion >= 0 && (frameMode || timelineMode) && c->maskEnabled && c->numCells > 0) {
+        const int strips = (P.H + 7) / 8;
+        const size_t words = (size_t)strips * P.tilesX + 1;
+        if (st->maskWords != words) {
+            if (capturing)
+                return fail(c, RTO_E_UNSUPPORTED, "render: the first frame of a new size on a stream allocates its occupancy mask; "
+                                                  "render one such frame before hipStreamBeginCapture");
+            (void)hipFree(st->d_tileMask); st->d_tileMask = nullptr; st->maskWords = 0;      // hipFree waits for the device
+            RTO_HIP(c, hipMalloc(&st->d_tileMask, words * kMaxBatch * sizeof(unsigned)));
+            RTO_HIP(c, hipMemset(st->d_tileMask, 0, words * kMaxBatch * sizeof(unsigned)));   // stamp 0 is never issued
+            st->maskWords = words;
+        }
+        if (++c->maskStamp == 0) ++c->maskStamp;
+        Q.tileMask = st->d_tileMask + (size_t)maskRegion * words;
+        Q.maskStamp = c->maskStamp;
+        Q.maskAllIndex = (int)(words - 1);
+    }
     rto_context::OrderState* o = (c->orderPolicy == RTO_ORDER_TEMPORAL && (frameMode || timelineMode) &&
                                   P.tilesX <= 0xffff && P.tilesY <= 0x7fff) ? st : nullptr;      // table entries are x | y << 16 inside the box
     if (o) {
@@ -1209,6 +1292,28 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     return RTO_OK;
 }
 
+// k_tile_mask for the frames Qs[0..n-1] whose tileMask prepare_schedule set (one launch for all of them), on stream s, in
+// front of their traversal kernel.
+static int launch_tile_masks(rto_context* c, hipStream_t s, const RenderParams* Qs, int n) {
+    MaskBatch B;
+    B.n = 0;
+    B.gx = c->gridMin[0]; B.gy = c->gridMin[1]; B.gz = c->gridMin[2]; B.vs = c->voxelSize;
+    for (int i = 0; i < n; i++) {
+        const RenderParams& Q = Qs[i];
+        if (!Q.tileMask) continue;
+        MaskCam& M = B.f[B.n++];
+        std::memcpy(M.view, Q.viewRows, sizeof M.view);
+        M.aspTan = Q.aspect * Q.tanHalfFov; M.tanH = Q.tanHalfFov;
+        M.W = Q.W; M.H = Q.H; M.tilesX = Q.tilesX; M.strips = (Q.H + 7) / 8;
+        M.stamp = Q.maskStamp;
+        M.mask = const_cast<unsigned*>(Q.tileMask);
+    }
+    if (B.n == 0) return RTO_OK;
+    hipLaunchKernelGGL(k_tile_mask, dim3((unsigned)((c->numCells + kBlock - 1) / kBlock), (unsigned)B.n), dim3(kBlock), 0, s, B, c->d_cells, c->numCells);
+    RTO_HIP(c, hipGetLastError());
+    return RTO_OK;
+}
+
 template <int MODE>
 static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hipStream_t s) {
     if (s != c->stream) c->otherStreams = true;
@@ -1248,8 +1353,10 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             rto_context::OrderState* st = nullptr;
             const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
             {
-                const int rc = prepare_schedule(c, s, capturing, frameMode, MODE == kModeTimeline, 0, solidRect, Q, &st);
+                int rc = prepare_schedule(c, s, capturing, frameMode, MODE == kModeTimeline, 0, solidRect, Q, &st, leanKernel ? 0 : -1);
                 if (rc != RTO_OK) return rc;
+                if (!(Q.aspect > 0.0f && Q.tanHalfFov > 0.0f)) Q.tileMask = nullptr;      // degenerate projection: no mask
+                if ((rc = launch_tile_masks(c, s, &Q, 1)) != RTO_OK) return rc;
             }
             const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
@@ -1367,9 +1474,14 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
         B.out[i] = outs[i];
         if (Ps[i].tilesX * Ps[i].tilesY <= 0) { B.P[i].launchWaves = 0; continue; }
         const int solidRect[4] = { Ps[i].solidX0, Ps[i].solidY0, Ps[i].solidX1, Ps[i].solidY1 };
-        const int rc = prepare_schedule(c, s, capturing, true, false, 0, solidRect, B.P[i], &st);
+        const int rc = prepare_schedule(c, s, capturing, true, false, 0, solidRect, B.P[i], &st, i);
         if (rc != RTO_OK) return rc;
+        if (!(B.P[i].aspect > 0.0f && B.P[i].tanHalfFov > 0.0f)) B.P[i].tileMask = nullptr;
         maxWaves = std::max(maxWaves, B.P[i].launchWaves);
+    }
+    {
+        const int rc = launch_tile_masks(c, s, B.P, n);
+        if (rc != RTO_OK) return rc;
     }
     // the frames share this stream's launch-order table: its entries are relative to the box's corner, so it serves every
     // frame whose box has the size of the one it was last rebuilt for (a moving camera shifts the box far more often than
@@ -1731,7 +1843,10 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
         // for the rest, costliest tiles of earlier frames first (the instrumented frame keeps one wave per tile)
         rto_context::OrderState* st = nullptr;
         const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
-        if ((rc = prepare_schedule(c, s, capturing, !count, false, 1, solidRect, P, &st)) != RTO_OK) return rc;
+        const bool leanTri = c->d_triRec && c->kernelMode != RTO_KERNEL_PACKED_V3;
+        if ((rc = prepare_schedule(c, s, capturing, !count, false, 1, solidRect, P, &st, leanTri ? 0 : -1)) != RTO_OK) return rc;
+        if (!(P.aspect > 0.0f && P.tanHalfFov > 0.0f)) P.tileMask = nullptr;
+        if ((rc = launch_tile_masks(c, s, &P, 1)) != RTO_OK) return rc;
     }
     const bool noEvents = capturing || c->eventsOff;
     if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev0, s));
@@ -1791,8 +1906,13 @@ static int launch_triangles_batch(rto_context* c, const rto_frame* frames, int n
         B.out[i] = outs[i];
         if (B.P[i].tilesX * B.P[i].tilesY <= 0) { B.P[i].launchWaves = 0; continue; }
         const int solidRect[4] = { B.P[i].solidX0, B.P[i].solidY0, B.P[i].solidX1, B.P[i].solidY1 };
-        if ((rc = prepare_schedule(c, s, capturing, true, false, 1, solidRect, B.P[i], &st)) != RTO_OK) return rc;
+        if ((rc = prepare_schedule(c, s, capturing, true, false, 1, solidRect, B.P[i], &st, i)) != RTO_OK) return rc;
+        if (!(B.P[i].aspect > 0.0f && B.P[i].tanHalfFov > 0.0f)) B.P[i].tileMask = nullptr;
         maxWaves = std::max(maxWaves, B.P[i].launchWaves);
+    }
+    {
+        const int rc = launch_tile_masks(c, s, B.P, n);
+        if (rc != RTO_OK) return rc;
     }
     for (int i = 0; i < n; i++) {                                   // one box-relative order table per stream: see launch_trace_batch
         if (!st || B.P[i].launchWaves <= 0 || !B.P[i].tileCost) continue;

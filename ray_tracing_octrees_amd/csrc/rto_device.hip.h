@@ -105,6 +105,13 @@ struct RenderParams {
     const float* rayX;              // [W]  ((px+.5)/W*2-1)*aspect*tanHalfFov, the separable part of S/RT:341-346 (host-computed)
     const float* rayY;              // [H]  (1-(py+.5)/H*2)*tanHalfFov
     const StartState* start;        // non-null while a frustum update is active on a canonical tree: replaces rootVisible / the root as start node (lean kernels)
+    // Screen-space occupancy mask (k_tile_mask, launched in front of a colour / shade frame of the lean kernels): one word per
+    // 8x8 tile in GLOBAL image rows ([strip = row / 8][tx]); a tile whose word differs from maskStamp -- and with the "whole frame"
+    // word at maskAllIndex also different -- cannot contain a ray that meets a solid leaf: its wave stores black and does nothing else.
+    const unsigned* tileMask;       // null: no mask (instrumented frames, A/B kernels, non-canonical arrays)
+    unsigned maskStamp;
+    int maskAllIndex;
+    float viewRows[12];             // rows 0..2 of the view matrix (host side: what k_tile_mask projects with)
 };
 
 // ---------------------------------------------------------------- scalar helpers
@@ -555,6 +562,14 @@ __device__ __forceinline__ bool resolve_slot(const RenderParams& P, int slot, in
     return true;
 }
 
+// Occupancy mask look-up for the tile (tx, ty) of this part (ty in local tile rows; a local tile lies inside one band, bands
+// being multiples of 8 rows).  tx, ty are wave-uniform.
+__device__ __forceinline__ bool tile_may_hit(const RenderParams& P, int tx, int ty) {
+    if (!P.tileMask || ty >= P.tilesY) return true;
+    const int strip = global_row(P, ty * 8) >> 3;
+    return P.tileMask[strip * P.tilesX + tx] == P.maskStamp || P.tileMask[P.maskAllIndex] == P.maskStamp;
+}
+
 // The fill duty of launch slot `slot`: chunks slot, slot + launchWaves, ... of the region outside the root rectangle.
 // Every pixel there is black after the root's pop (S/RT:254-270, :363): (0,0,0,1), or kShadeMiss in the shade buffer.
 template <int MODE>
@@ -971,7 +986,8 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
         startVisible = st.visible; startShift = st.shift; startSize = 1 << st.shift; startX = st.x; startY = st.y; startZ = st.z;
         startDesc = st.desc; startLeaf = st.leaf != 0; startSolid = st.solid != 0;
     }
-    if (inImage && startVisible) {
+    const bool tileLive = tile_may_hit(P, tx, ty);                      // wave-uniform: scalar loads, no VALU
+    if (inImage && startVisible && tileLive) {
         steps0 = 1;
         if (!outsideRoot) {
             r = generate_ray_tab(P, px, py);
@@ -1852,7 +1868,8 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     bool hitPrimary = false;
     Ray r;
     bool alive = false;            // walking the tree
-    if (inImage) {
+    const bool tileLive = tile_may_hit(P, tx, ty);     // the occupancy mask (colour / shade frames): wave-uniform
+    if (inImage && tileLive) {
         stepsTotal = 1;            // the root's own pop of the primary ray
         if (!outside) {
             r = generate_ray_tab(P, px, py);
@@ -3096,6 +3113,107 @@ __global__ __launch_bounds__(kBlock) void k_block_exclusive_scan(const int* __re
     for (int w = 0; w < wave; w++) base += waveTotal[w];
     if (i < n) out[i] = base + incl - x;
     if (i == 0) out[n] = (int)*total;
+}
+
+// ================================================================ screen-space occupancy mask
+// About two thirds of the rays inside the solid geometry's screen rectangle miss everything (config 2: the corners of the
+// sphere's bounding box, the ring around its silhouette) -- and each still costs its wave the ray set-up (two inversesqrt,
+// three reciprocals, the root test: ~330 VALU instructions, as much as three loop trips).  The mask removes most of them
+// before any ray exists: the "coarse cells" of the tree at one level L -- its internal nodes at depth L and every solid leaf
+// at depth <= L: together they contain every solid leaf -- are projected onto the screen (conservatively: widened by a voxel,
+// which also covers config 5's Marching-Cubes triangles, and by 3 pixels), and every tile a projection touches is stamped.
+// A tile without the frame's stamp cannot contain a hit: its wave writes black (exactly what S/RT:363 gives rays that meet
+// nothing) and exits.  Stamps instead of bits: every launch brings a fresh stamp, so the array is never cleared and all
+// writers of a frame store the same value (no atomics; safe under graph replay: a replayed launch re-stamps its own tiles).
+struct MaskCam {
+    float view[12];            // rows 0..2 of the view matrix
+    float aspTan, tanH;        // aspect * tan(fov/2), tan(fov/2)
+    int W, H, tilesX, strips;
+    unsigned stamp;
+    unsigned* mask;            // strips * tilesX words + the "whole frame" word
+};
+struct MaskBatch { MaskCam f[kMaxBatch]; int n; float gx, gy, gz, vs; };
+constexpr int kMaskMaxRectTiles = 2048;    // a cell that covers more tiles than this stamps the "whole frame" word instead
+
+__global__ __launch_bounds__(kBlock) void k_tile_mask(MaskBatch B, const int4* __restrict__ cells, int numCells) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= numCells) return;
+    const MaskCam& M = B.f[blockIdx.y];
+    const int4 c = cells[i];
+    const float lo[3] = { B.gx + (float)(c.x - 1) * B.vs, B.gy + (float)(c.y - 1) * B.vs, B.gz + (float)(c.z - 1) * B.vs };
+    const float hi[3] = { B.gx + (float)(c.x + c.w + 1) * B.vs, B.gy + (float)(c.y + c.w + 1) * B.vs, B.gz + (float)(c.z + c.w + 1) * B.vs };
+    float lox = 3.0e38f, loy = 3.0e38f, hix = -3.0e38f, hiy = -3.0e38f;
+    bool front = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float wx = (k & 1) ? hi[0] : lo[0], wy = (k & 2) ? hi[1] : lo[1], wz = (k & 4) ? hi[2] : lo[2];
+        const float vx = M.view[0] * wx + M.view[1] * wy + M.view[2] * wz + M.view[3];
+        const float vy = M.view[4] * wx + M.view[5] * wy + M.view[6] * wz + M.view[7];
+        const float vz = M.view[8] * wx + M.view[9] * wy + M.view[10] * wz + M.view[11];
+        // strictly in front of the eye, with room for the float error of the three dot products
+        if (!(vz < -1e-4f * (1.0f + __builtin_fabsf(vx) + __builtin_fabsf(vy) + __builtin_fabsf(vz)))) front = false;
+        const float iz = 1.0f / -vz;
+        const float sx = ((vx * iz) / M.aspTan * 0.5f + 0.5f) * (float)M.W, sy = (0.5f - (vy * iz) / M.tanH * 0.5f) * (float)M.H;
+        lox = __builtin_fminf(lox, sx); hix = __builtin_fmaxf(hix, sx); loy = __builtin_fminf(loy, sy); hiy = __builtin_fmaxf(hiy, sy);
+    }
+    const int all = M.strips * M.tilesX;
+    if (!front || !(hix - lox < 1.0e7f) || !(hiy - loy < 1.0e7f)) { M.mask[all] = M.stamp; return; }       // around / behind the eye, or not finite
+    // 3 pixels of margin: 2 as the host's rectangles + 1 for this float evaluation (their errors are ~1e-3 pixel)
+    const float fx0 = __builtin_floorf(lox) - 3.0f, fx1 = __builtin_ceilf(hix) + 3.0f, fy0 = __builtin_floorf(loy) - 3.0f, fy1 = __builtin_ceilf(hiy) + 3.0f;
+    if (fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(M.W - 1) || fy0 > (float)(M.H - 1)) return;               // off the screen
+    const int tx0 = (int)__builtin_fmaxf(fx0, 0.0f) >> 3, tx1 = (int)__builtin_fminf(fx1, (float)(M.W - 1)) >> 3;
+    const int ty0 = (int)__builtin_fmaxf(fy0, 0.0f) >> 3, ty1 = (int)__builtin_fminf(fy1, (float)(M.H - 1)) >> 3;
+    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kMaskMaxRectTiles) { M.mask[all] = M.stamp; return; }
+    for (int y = ty0; y <= ty1; y++)
+        for (int x = tx0; x <= tx1; x++) M.mask[y * M.tilesX + x] = M.stamp;
+}
+
+// Which level to take the cells from: per depth, the number of internal nodes and of solid leaves (one pass over the descriptors;
+// the children of the node of descriptor d lie one level below it).  counts: [0..kMaxDepth] internal, [kMaxDepth+1 ..] solid leaves.
+__global__ __launch_bounds__(kBlock) void k_cells_count(const uint2* __restrict__ desc, const int4* __restrict__ descPos, int64_t nInternal, int depth,
+                                                         int* __restrict__ counts) {
+    __shared__ int h[2 * (kMaxDepth + 1)];
+    for (int i = threadIdx.x; i < 2 * (kMaxDepth + 1); i += kBlock) h[i] = 0;
+    __syncthreads();
+    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (d < nInternal) {
+        const unsigned w = desc[d].x;
+        const int l = depth - (31 - __builtin_clz((unsigned)descPos[d].w)) + 1;       // depth of the CHILDREN of this node
+        if (l >= 0 && l <= kMaxDepth) {
+            atomicAdd(&h[l], __builtin_popcount((w >> 8) & 0xffu));
+            atomicAdd(&h[kMaxDepth + 1 + l], __builtin_popcount(w & 0xffu));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * (kMaxDepth + 1); i += kBlock) if (h[i]) atomicAdd(&counts[i], h[i]);
+}
+
+// The cells of level L: internal children at depth L, solid-leaf children at depth <= L (position, edge), in any order.
+__global__ __launch_bounds__(kBlock) void k_cells_fill(const uint2* __restrict__ desc, const int4* __restrict__ descPos, int64_t nInternal, int depth, int L,
+                                                        int4* __restrict__ cells, int capacity, int* __restrict__ cursor) {
+    const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    unsigned sel = 0;
+    int4 p = make_int4(0, 0, 0, 0);
+    if (d < nInternal) {
+        const unsigned w = desc[d].x;
+        p = descPos[d];
+        const int l = depth - (31 - __builtin_clz((unsigned)p.w)) + 1;
+        if (l <= L) sel = (w & 0xffu) | (l == L ? ((w >> 8) & 0xffu) : 0u);
+    }
+    const int n = __builtin_popcount(sel);
+    int incl = n;                                              // wave-level prefix sum: one atomic per wave
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    int base = 0;
+    if (lane == kWave - 1 && incl > 0) base = atomicAdd(cursor, incl);
+    base = __shfl(base, kWave - 1) + incl - n;
+    const int half = p.w >> 1;
+    while (sel) {
+        const int k = __builtin_ctz(sel);
+        sel &= sel - 1;
+        if (base < capacity) cells[base] = make_int4(p.x + ((k & 1) ? half : 0), p.y + ((k & 2) ? half : 0), p.z + ((k & 4) ? half : 0), half);
+        base++;
+    }
 }
 
 // ================================================================ multi-GPU reassembly

@@ -33,6 +33,7 @@ SYMBOLS = (
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_debug_sort_violations", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
     "rto_comm_unique_id", "rto_comm_create", "rto_comm_create_all", "rto_comm_destroy", "rto_comm_last_error", "rto_comm_submit",
     "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_comm_debug_last_payload", "rto_render_triangles_batch_device",
+    "rto_debug_set_tile_mask", "rto_debug_tile_mask_info",
     "rto_scene_bounds_get", "rto_scene_bounds_of_nodes", "rto_split_plan_make", "rto_split_part_of_rank", "rto_split_rows_of_part", "rto_split_row_source",
 )
 SPLIT_MAX_FRAMES = 32
@@ -121,6 +122,8 @@ def load():
     L.rto_forget_stream.argtypes = [vp, vp]
     L.rto_debug_update_frustum_planes.argtypes = [vp, C.POINTER(C.c_float), C.c_float]
     L.rto_debug_sort_violations.argtypes = [vp, C.POINTER(C.c_int)]
+    L.rto_debug_set_tile_mask.argtypes = [vp, C.c_int]
+    L.rto_debug_tile_mask_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.rto_update_frustum.argtypes = [vp, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int]
     L.rto_download_visible_nodes.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.rto_render_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp]
@@ -284,6 +287,16 @@ class Context:
     def forget_stream(self, stream: int):
         """Drop the launch-order tables kept for `stream` (call before destroying the stream)."""
         self._check(self._L.rto_forget_stream(self._h, C.c_void_p(stream) if stream else None))
+
+    def debug_set_tile_mask(self, enabled: bool):
+        """Switch the occupancy mask of the default kernels off / on (A/B measurements; pixels never depend on it)."""
+        self._check(self._L.rto_debug_set_tile_mask(self._h, 1 if enabled else 0))
+
+    def debug_tile_mask_info(self):
+        """(depth the mask's cells are taken from, number of cells); (0, 0): no mask for this octree."""
+        lv, n = C.c_int(), C.c_int()
+        self._check(self._L.rto_debug_tile_mask_info(self._h, C.byref(lv), C.byref(n)))
+        return lv.value, n.value
 
     def debug_sort_violations(self) -> int:
         n = C.c_int()

@@ -517,6 +517,59 @@ def test_frustum_update_reads_nothing_back_and_can_be_captured(ctx, orc, scenes,
         fresh.close()
 
 
+def test_occupancy_mask_never_changes_pixels_and_removes_work(ctx, orc, scenes):
+    """The occupancy mask (k_tile_mask in front of every colour / shade frame of the default kernels) is a scheduling device:
+    frames with it, without it and the oracle's are bit-identical -- cameras outside, grazing, far away, with the scene partly
+    or wholly off the screen, and inside the geometry (cells around the eye: the "whole frame" word) -- while the number of
+    tiles whose wave walks the tree drops to little more than the tiles that contain a hit."""
+    torch = pytest.importorskip("torch")
+    for scene, cams in (("sphere64", [(0.5, 0.7, 1.8, (0, 0, 0), 45.0), (0.5, 0.7, 1.8, (0.8, 0.3, 0.0), 45.0), (0.5, 0.7, 6.0, (0, 0, 0), 10.0),
+                                      (0.5, 0.7, 0.3, (0, 0, 0), 45.0), (0.1, 0.2, 0.9, (0.0, 0.9, 0.0), 70.0), (0.5, 0.7, 1.8, (5.0, 5.0, 9.0), 45.0),
+                                      (-1.2, 4.0, 0.75, (0.2, -0.1, 0.1), 120.0)]),
+                        ("calgary", [(0.6, 0.5, 3500.0, None, 45.0), (1.2, 0.1, 900.0, None, 60.0)]),
+                        ("odd", [(0.4, 0.9, 9.0, None, 45.0)])):
+        s = scenes(scene)
+        upload(ctx, s)
+        level, ncells = ctx.debug_tile_mask_info()
+        assert level >= 1 and 0 < ncells <= 32768, (scene, level, ncells)
+        W, H = 640, 360
+        for (t, p, r, tgt, fov) in cams:
+            cam = orc.Camera(t, p, r)
+            if tgt is not None:
+                cam.set_target(*[float(x) for x in tgt])
+            view, pos = cam.get_view(), cam.get_pos()
+            f = rto.make_frame(view, pos, W / H, fov, W, H)
+            want, st = oracle_frame(orc, s, view, pos, W, H, fov=fov)
+            for on in (True, False):
+                ctx.debug_set_tile_mask(on)
+                for _ in range(2):
+                    got = ctx.render_host(f)
+                assert_bit_exact(got, want, f"{scene} cam {(t, p, r, tgt, fov)} mask {'on' if on else 'off'}")
+                out = torch.full((2, H, W, 4), 7.0, dtype=torch.float32, device="cuda")          # the batch kernel and a 3-way partition too
+                ctx.render_batch_device(hip.Context.frame_array([f, f]), out.data_ptr(), out.stride(0) * 4, None, False, 0)
+                torch.cuda.synchronize()
+                assert_bit_exact(out[1].cpu().numpy(), want, f"{scene} batched, mask {'on' if on else 'off'}")
+                part = hip.Partition(3, 1, 16)
+                rows = partition_row_map(H, 3, 1, 16)
+                pb = torch.full((len(rows), W, 4), 7.0, dtype=torch.float32, device="cuda")
+                ctx.render_device(f, pb.data_ptr(), part)
+                ctx.synchronize()
+                assert_bit_exact(pb.cpu().numpy(), want[rows], f"{scene} part 1/3, mask {'on' if on else 'off'}")
+            ctx.debug_set_tile_mask(True)
+            gs = ctx.frame_stats(f)                              # instrumented frames never use the mask: exact pops
+            assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"])
+            if scene == "sphere64" and tgt == (0, 0, 0) and r == 1.8:
+                ctx.render_host(f)
+                cost = ctx.debug_tile_cost().reshape((H + 7) // 8, (W + 7) // 8)
+                hit_tiles = (want[..., 0] != 0)[: H // 8 * 8].reshape(H // 8, 8, W // 8, 8).any(axis=(1, 3))
+                assert (cost[: H // 8, : W // 8][hit_tiles] > 0).all(), "a tile with a hit is never masked out"
+                ys, xs = np.nonzero(hit_tiles)                    # inside the hit tiles' bounding box every entry was written by this frame
+                inner = cost[ys.min(): ys.max() + 1, xs.min(): xs.max() + 1]
+                n_walk, n_hit, n_box = int((inner > 0).sum()), int(hit_tiles.sum()), inner.size
+                assert n_hit <= n_walk <= 1.35 * n_hit + 40 and n_walk < n_box, (n_walk, n_hit, n_box)
+    ctx.debug_set_tile_mask(True)
+
+
 def test_persistent_kernel_in_a_graph_with_an_odd_frame_count(ctx, orc, scenes):
     """The persistent-threads kernel takes launch slots from a global counter; every launch zeroes its own counter with a
     memset node, so a captured sequence of ANY length replays exactly (an odd number of frames used to leave the next
