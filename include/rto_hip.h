@@ -336,7 +336,7 @@ int  rto_frame_stats(rto_context* ctx, const rto_frame* frame, rto_stats* out);
 int  rto_render_steps_host(rto_context* ctx, const rto_frame* frame, int32_t* host_steps);
 /* Developer aid: per-wave timeline of one frame of the packed kernel.  8 int32 per 8x8 tile (row-major
  * tiles): start lo/hi, end lo/hi (100 MHz wall clock), loop iterations, HW_ID, XCC_ID, lanes that entered
- * the tree; all zero for tiles outside the root rectangle's tile box, which get no wave (their pixels are written
+ * the tree | launch slot << 8; all zero for tiles outside the root rectangle's tile box, which get no wave (their pixels are written
  * by the waves of the box as wide stores).  host_records may be NULL to query *num_tiles. */
 int  rto_debug_timeline(rto_context* ctx, const rto_frame* frame, int32_t* host_records, int64_t capacity_tiles,
                         int64_t* num_tiles);
@@ -344,12 +344,15 @@ int  rto_debug_timeline(rto_context* ctx, const rto_frame* frame, int32_t* host_
  * slot -> tile table (NULL restores the automatic one). */
 int  rto_debug_tile_cost(rto_context* ctx, int32_t* host_cost, int64_t capacity, int64_t* count);
 int  rto_debug_set_tile_order(rto_context* ctx, const int32_t* host_order, int64_t n);
-/* The occupancy mask: in front of every colour / shade frame of the default kernels one small kernel
- * projects the octree's coarse cells (its internal nodes at one depth + the solid leaves above it) onto the screen and stamps
- * the 8x8 tiles they can touch; waves of other tiles write black without setting up a single ray (about two thirds of the
- * rays inside the geometry's screen rectangle miss everything).  A scheduling device like the launch order: pixels never
- * depend on it.  rto_debug_set_tile_mask(ctx, 0) switches it off (A/B measurements); _info: the depth the cells are taken
- * from and their number (0: no mask for this octree). */
+/* The occupancy mask: the first few workgroups of every colour / shade frame of the default kernels
+ * project the octree's coarse cells (its internal nodes at one depth + the solid leaves above it) onto the screen and stamp
+ * the 8x8 tiles they can touch; once the mask is complete, waves of unstamped tiles write black without setting up a single
+ * ray (about two thirds of the rays inside the geometry's screen rectangle miss everything).  Nobody waits for the mask: the
+ * previous frame's costliest tiles never look, later waves look only if it is complete -- tiles without work sort to the end
+ * of the launch order, where it always is.  A scheduling device like the launch order: pixels never depend on it.
+ * rto_debug_set_tile_mask: 0 = off, 1 = on (default), 2 = on and built by a launch of its own in front of the frame, every
+ * wave consulting it (tests: the mask decides for every tile).  _info: the depth the cells are taken from and their number
+ * (0: no mask for this octree). */
 int  rto_debug_set_tile_mask(rto_context* ctx, int enabled);
 int  rto_debug_tile_mask_info(const rto_context* ctx, int* level, int* num_cells);
 /* Writes the launch-order sort refused because they fell outside the table (must be 0; synchronises). */

@@ -97,7 +97,7 @@ struct rto_context {
     int4* d_cells = nullptr;
     int numCells = 0, cellLevel = 0;
     unsigned maskStamp = 0;                     // one fresh value per frame launched
-    bool maskEnabled = true;                    // rto_debug_set_tile_mask
+    int maskMode = 1;                           // rto_debug_set_tile_mask: 0 off, 1 on, 2 on + built by a launch of its own in front of the frame (tests)
 
     // voxels retained by rto_build_octree (so that rto_build_leaf_triangles can run without a second upload)
     uint8_t* d_vox = nullptr;
@@ -753,7 +753,8 @@ int rto_forget_stream(rto_context* c, void* hip_stream) {
 
 int rto_debug_set_tile_mask(rto_context* c, int enabled) {
     if (!c) return RTO_E_INVALID;
-    c->maskEnabled = enabled != 0;
+    if (enabled < 0 || enabled > 2) return fail(c, RTO_E_INVALID, "rto_debug_set_tile_mask: 0 off, 1 on, 2 on and complete before the frame starts");
+    c->maskMode = enabled;
     return RTO_OK;
 }
 
@@ -1144,7 +1145,8 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     P.rayX = c->d_rayX; P.rayY = c->d_rayY;
     P.tileOrder = nullptr; P.tileCost = nullptr;
     P.start = nullptr;                     // the lean kernels' launchers point it at the device-side start state while culling is active
-    P.tileMask = nullptr; P.maskStamp = 0; P.maskAllIndex = 0;             // prepare_schedule switches the occupancy mask on for lean colour / shade frames
+    P.tileMask = nullptr; P.maskStamp = 0; P.maskAllIndex = 0; P.maskBlocks = 0; P.maskTrustSlots = 0; P.maskCells = nullptr; P.maskNumCells = 0;
+    P.maskInvAspTan = P.maskInvTanH = 0.0f;                                 // prepare_schedule switches the occupancy mask on for lean colour / shade frames
     for (int r = 0; r < 3; r++) for (int k = 0; k < 4; k++) P.viewRows[r * 4 + k] = f->view[k * 4 + r];   // column-major glm matrix -> rows
     {   // rays through pixels outside these rectangles miss the root box / every solid leaf for certain
         int rr[4], sr[4];
@@ -1215,23 +1217,28 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     const long key[7] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles, path };
     rto_context::OrderState* st = order_state(c, s, capturing);      // this stream's scheduling state
     *stOut = st;
-    // occupancy mask (maskRegion >= 0: the caller runs a lean kernel and launches k_tile_mask for this frame: launch_tile_masks)
-    if (st && maskRegion >= 0 && (frameMode || timelineMode) && c->maskEnabled && c->numCells > 0) {
+    // occupancy mask (maskRegion >= 0: the caller launches a lean kernel; its first maskBlocks workgroups build the mask: mask_block)
+    Q.tileMask = nullptr; Q.maskBlocks = 0;
+    if (st && maskRegion >= 0 && (frameMode || timelineMode) && c->maskMode != 0 && c->numCells > 0 && P.aspect > 0.0f && P.tanHalfFov > 0.0f) {
         const int strips = (P.H + 7) / 8;
-        const size_t words = (size_t)strips * P.tilesX + 1;
+        const size_t words = (size_t)strips * P.tilesX + 3;              // tiles, "whole frame", "complete", ticket
         if (st->maskWords != words) {
             if (capturing)
                 return fail(c, RTO_E_UNSUPPORTED, "render: the first frame of a new size on a stream allocates its occupancy mask; "
                                                   "render one such frame before hipStreamBeginCapture");
             (void)hipFree(st->d_tileMask); st->d_tileMask = nullptr; st->maskWords = 0;      // hipFree waits for the device
             RTO_HIP(c, hipMalloc(&st->d_tileMask, words * kMaxBatch * sizeof(unsigned)));
-            RTO_HIP(c, hipMemset(st->d_tileMask, 0, words * kMaxBatch * sizeof(unsigned)));   // stamp 0 is never issued
+            RTO_HIP(c, hipMemset(st->d_tileMask, 0, words * kMaxBatch * sizeof(unsigned)));   // stamp 0 is never issued; tickets start at 0
             st->maskWords = words;
         }
         if (++c->maskStamp == 0) ++c->maskStamp;
         Q.tileMask = st->d_tileMask + (size_t)maskRegion * words;
         Q.maskStamp = c->maskStamp;
-        Q.maskAllIndex = (int)(words - 1);
+        Q.maskAllIndex = (int)(words - 3);
+        Q.maskBlocks = (c->numCells + kBlock - 1) / kBlock;
+        Q.maskTrustSlots = c->maskMode == 2 ? 0 : kMaskTrustSlots;
+        Q.maskCells = c->d_cells; Q.maskNumCells = c->numCells;
+        Q.maskInvAspTan = 1.0f / (P.aspect * P.tanHalfFov); Q.maskInvTanH = 1.0f / P.tanHalfFov;
     }
     rto_context::OrderState* o = (c->orderPolicy == RTO_ORDER_TEMPORAL && (frameMode || timelineMode) &&
                                   P.tilesX <= 0xffff && P.tilesY <= 0x7fff) ? st : nullptr;      // table entries are x | y << 16 inside the box
@@ -1292,26 +1299,14 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     return RTO_OK;
 }
 
-// k_tile_mask for the frames Qs[0..n-1] whose tileMask prepare_schedule set (one launch for all of them), on stream s, in
-// front of their traversal kernel.
-static int launch_tile_masks(rto_context* c, hipStream_t s, const RenderParams* Qs, int n) {
-    MaskBatch B;
-    B.n = 0;
-    B.gx = c->gridMin[0]; B.gy = c->gridMin[1]; B.gz = c->gridMin[2]; B.vs = c->voxelSize;
-    for (int i = 0; i < n; i++) {
-        const RenderParams& Q = Qs[i];
-        if (!Q.tileMask) continue;
-        MaskCam& M = B.f[B.n++];
-        std::memcpy(M.view, Q.viewRows, sizeof M.view);
-        M.aspTan = Q.aspect * Q.tanHalfFov; M.tanH = Q.tanHalfFov;
-        M.W = Q.W; M.H = Q.H; M.tilesX = Q.tilesX; M.strips = (Q.H + 7) / 8;
-        M.stamp = Q.maskStamp;
-        M.mask = const_cast<unsigned*>(Q.tileMask);
-    }
-    if (B.n == 0) return RTO_OK;
-    hipLaunchKernelGGL(k_tile_mask, dim3((unsigned)((c->numCells + kBlock - 1) / kBlock), (unsigned)B.n), dim3(kBlock), 0, s, B, c->d_cells, c->numCells);
-    RTO_HIP(c, hipGetLastError());
-    return RTO_OK;
+// Experiment knob: RTO_WAVES_PER_SIMD=<n> pads the dynamic LDS request of the lean octree kernels so that at most n waves per SIMD
+// are resident (160 KB of LDS per CU, 4-wave workgroups): with fewer waves resident at the start, more of the frame's waves are
+// handed out dynamically as slots free up.  0 / unset: no padding.
+static size_t lds_for_occupancy(size_t lds) {
+    static const int waves = []() { const char* e = std::getenv("RTO_WAVES_PER_SIMD"); return e ? std::atoi(e) : 0; }();
+    if (waves <= 0) return lds;
+    const size_t perGroup = (size_t)(160 * 1024) / (size_t)waves;          // workgroups per CU == waves per SIMD (4 waves -> 4 SIMDs)
+    return std::max(lds, std::min<size_t>(perGroup, 64 * 1024) & ~(size_t)255);
 }
 
 template <int MODE>
@@ -1338,7 +1333,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     if (c->culling && !deviceStart) { const int rcState = sync_cull_state(c); if (rcState != RTO_OK) return rcState; }
     const bool rootCulledEdge = !deviceStart && c->culling && !c->rootVisible && c->visibleNodes > 0;
     if (packed && !rootCulledEdge) {
-        const size_t lds = (size_t)(kBlock / kWave) * (P.depth + 1) * kWave * sizeof(uint2);   // +1: the lean kernel's dummy entry
+        const size_t lds = lds_for_occupancy((size_t)(kBlock / kWave) * (P.depth + 1) * kWave * sizeof(uint2));   // +1: the lean kernel's dummy entry
         if (c->kernelMode == RTO_KERNEL_PACKED_V1) {
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
             startRecorded = true;
@@ -1353,10 +1348,9 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             rto_context::OrderState* st = nullptr;
             const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
             {
-                int rc = prepare_schedule(c, s, capturing, frameMode, MODE == kModeTimeline, 0, solidRect, Q, &st, leanKernel ? 0 : -1);
+                const bool maskable = leanKernel && c->kernelMode != RTO_KERNEL_PACKED_PERSISTENT;
+                const int rc = prepare_schedule(c, s, capturing, frameMode, MODE == kModeTimeline, 0, solidRect, Q, &st, maskable ? 0 : -1);
                 if (rc != RTO_OK) return rc;
-                if (!(Q.aspect > 0.0f && Q.tanHalfFov > 0.0f)) Q.tileMask = nullptr;      // degenerate projection: no mask
-                if ((rc = launch_tile_masks(c, s, &Q, 1)) != RTO_OK) return rc;
             }
             const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
@@ -1379,7 +1373,10 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             } else if (c->kernelMode == RTO_KERNEL_PACKED_V3) {
                 hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(lblocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             } else {
-                hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(lblocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+                // maskMode 2 (tests): a launch of the mask workgroups alone first, so that every wave of the frame finds the mask complete
+                if (c->maskMode == 2 && Q.maskBlocks > 0)
+                    hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(Q.maskBlocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+                hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(lblocks + Q.maskBlocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             }
         }
     } else {
@@ -1444,6 +1441,15 @@ static int build_triangle_records(rto_context* c, hipStream_t s) {
     return RTO_OK;
 }
 
+// The batch kernels put (mask workgroups per frame) x (frames) workgroups in front of the grid: every frame of a batch brings
+// its mask, or none does (a frame skipped by the loop above, a degenerate projection).
+static void batch_mask_all_or_none(RenderBatch& B) {
+    bool all = true;
+    for (int i = 0; i < B.n; i++) all = all && B.P[i].tileMask != nullptr && B.P[i].maskBlocks == B.P[0].maskBlocks;
+    if (all) return;
+    for (int i = 0; i < B.n; i++) { B.P[i].tileMask = nullptr; B.P[i].maskBlocks = 0; }
+}
+
 // n frames (n <= kMaxBatch) in one launch of k_trace_lean_batch; falls back to n launches when the lean kernel is not the
 // one in use (generic array, another kernel selected, the culled-root edge).  MODE: kModeColor or kModeShade.
 template <int MODE>
@@ -1476,13 +1482,9 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
         const int solidRect[4] = { Ps[i].solidX0, Ps[i].solidY0, Ps[i].solidX1, Ps[i].solidY1 };
         const int rc = prepare_schedule(c, s, capturing, true, false, 0, solidRect, B.P[i], &st, i);
         if (rc != RTO_OK) return rc;
-        if (!(B.P[i].aspect > 0.0f && B.P[i].tanHalfFov > 0.0f)) B.P[i].tileMask = nullptr;
         maxWaves = std::max(maxWaves, B.P[i].launchWaves);
     }
-    {
-        const int rc = launch_tile_masks(c, s, B.P, n);
-        if (rc != RTO_OK) return rc;
-    }
+    batch_mask_all_or_none(B);
     // the frames share this stream's launch-order table: its entries are relative to the box's corner, so it serves every
     // frame whose box has the size of the one it was last rebuilt for (a moving camera shifts the box far more often than
     // it resizes it); any other box falls back to the centre-out order (any permutation of a frame's own box renders it)
@@ -1496,9 +1498,11 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
     hipEvent_t evA = c->ev0, evB = c->ev1;
     if (!noEvents && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
     if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
-    const size_t lds = (size_t)(kBlock / kWave) * (Ps[0].depth + 1) * kWave * sizeof(uint2);
+    const size_t lds = lds_for_occupancy((size_t)(kBlock / kWave) * (Ps[0].depth + 1) * kWave * sizeof(uint2));
     const long long waves = (long long)maxWaves * n;
-    hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)((waves + (kBlock / kWave) - 1) / (kBlock / kWave))), dim3(kBlock), lds, s, B, c->d_desc);
+    if (c->maskMode == 2 && B.P[0].maskBlocks > 0)
+        hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)(B.P[0].maskBlocks * n)), dim3(kBlock), lds, s, B, c->d_desc);
+    hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)((waves + (kBlock / kWave) - 1) / (kBlock / kWave)) + (unsigned)(B.P[0].maskBlocks * n)), dim3(kBlock), lds, s, B, c->d_desc);
     RTO_HIP(c, hipGetLastError());
     if (!noEvents) RTO_HIP(c, hipEventRecord(evB, s));
     c->lastA = evA; c->lastB = evB;                       // what rto_last_kernel_ms reads
@@ -1845,8 +1849,6 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
         const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
         const bool leanTri = c->d_triRec && c->kernelMode != RTO_KERNEL_PACKED_V3;
         if ((rc = prepare_schedule(c, s, capturing, !count, false, 1, solidRect, P, &st, leanTri ? 0 : -1)) != RTO_OK) return rc;
-        if (!(P.aspect > 0.0f && P.tanHalfFov > 0.0f)) P.tileMask = nullptr;
-        if ((rc = launch_tile_masks(c, s, &P, 1)) != RTO_OK) return rc;
     }
     const bool noEvents = capturing || c->eventsOff;
     if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev0, s));
@@ -1856,9 +1858,11 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
             // default: the lean loop on the unified records (8-byte stack entries, shadow rays start inside the loop)
             LeanTriScene S{ c->d_triRec, c->d_tris };
             const size_t lds = (size_t)(kBlock / kWave) * ((P.depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));   // stacks + the keys of the triangle rounds
-            if (shadeOut) hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, true>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
-            else if (count) hipLaunchKernelGGL((k_trace_lean_triangles<kModeSteps, false>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
-            else hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, false>), dim3(lblocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+            if (c->maskMode == 2 && P.maskBlocks > 0 && !count)
+                hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, false>), dim3(P.maskBlocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+            if (shadeOut) hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, true>), dim3(lblocks + P.maskBlocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+            else if (count) hipLaunchKernelGGL((k_trace_lean_triangles<kModeSteps, false>), dim3(lblocks + P.maskBlocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+            else hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, false>), dim3(lblocks + P.maskBlocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
         } else {
             // RTO_KERNEL_PACKED_V3: round 1's form on the descriptors + triOffset (kept in the test matrix)
             PackedTriScene S{ c->d_desc, c->d_descFirstChild, c->d_tris, c->d_triOffset };
@@ -1907,13 +1911,9 @@ static int launch_triangles_batch(rto_context* c, const rto_frame* frames, int n
         if (B.P[i].tilesX * B.P[i].tilesY <= 0) { B.P[i].launchWaves = 0; continue; }
         const int solidRect[4] = { B.P[i].solidX0, B.P[i].solidY0, B.P[i].solidX1, B.P[i].solidY1 };
         if ((rc = prepare_schedule(c, s, capturing, true, false, 1, solidRect, B.P[i], &st, i)) != RTO_OK) return rc;
-        if (!(B.P[i].aspect > 0.0f && B.P[i].tanHalfFov > 0.0f)) B.P[i].tileMask = nullptr;
         maxWaves = std::max(maxWaves, B.P[i].launchWaves);
     }
-    {
-        const int rc = launch_tile_masks(c, s, B.P, n);
-        if (rc != RTO_OK) return rc;
-    }
+    batch_mask_all_or_none(B);
     for (int i = 0; i < n; i++) {                                   // one box-relative order table per stream: see launch_trace_batch
         if (!st || B.P[i].launchWaves <= 0 || !B.P[i].tileCost) continue;
         const rto_context::OrderState::Table& T = st->tab[st->active];
@@ -1925,7 +1925,9 @@ static int launch_triangles_batch(rto_context* c, const rto_frame* frames, int n
     LeanTriScene S{ c->d_triRec, c->d_tris };
     const size_t lds = (size_t)(kBlock / kWave) * ((B.P[0].depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));
     const long long waves = (long long)maxWaves * n;
-    const dim3 grid((unsigned)((waves + (kBlock / kWave) - 1) / (kBlock / kWave)));
+    const dim3 grid((unsigned)((waves + (kBlock / kWave) - 1) / (kBlock / kWave)) + (unsigned)(B.P[0].maskBlocks * n));
+    if (c->maskMode == 2 && B.P[0].maskBlocks > 0)
+        hipLaunchKernelGGL(k_trace_lean_triangles_batch<false>, dim3((unsigned)(B.P[0].maskBlocks * n)), dim3(kBlock), lds, s, B, S, shadow);
     if (shadeOut) hipLaunchKernelGGL(k_trace_lean_triangles_batch<true>, grid, dim3(kBlock), lds, s, B, S, shadow);
     else hipLaunchKernelGGL(k_trace_lean_triangles_batch<false>, grid, dim3(kBlock), lds, s, B, S, shadow);
     RTO_HIP(c, hipGetLastError());

@@ -108,11 +108,17 @@ struct RenderParams {
     // Screen-space occupancy mask (k_tile_mask, launched in front of a colour / shade frame of the lean kernels): one word per
     // 8x8 tile in GLOBAL image rows ([strip = row / 8][tx]); a tile whose word differs from maskStamp -- and with the "whole frame"
     // word at maskAllIndex also different -- cannot contain a ray that meets a solid leaf: its wave stores black and does nothing else.
-    const unsigned* tileMask;       // null: no mask (instrumented frames, A/B kernels, non-canonical arrays)
+    unsigned* tileMask;             // null: no mask (instrumented frames, A/B kernels, non-canonical arrays)
     unsigned maskStamp;
-    int maskAllIndex;
-    float viewRows[12];             // rows 0..2 of the view matrix (host side: what k_tile_mask projects with)
+    int maskAllIndex;               // words of the tile array; behind it: the "whole frame" word, the "mask complete" word, the ticket
+    int maskBlocks;                 // workgroups at the FRONT of the grid that build the mask instead of tracing (0: none)
+    int maskTrustSlots;             // launch slots below this never consult the mask (kMaskTrustSlots; 0 in the tests' forced mode)
+    const int4* maskCells;          // the coarse cells (x, y, z, edge)
+    int maskNumCells;
+    float maskInvAspTan, maskInvTanH;   // 1 / (aspect * tan(fov/2)), 1 / tan(fov/2)
+    float viewRows[12];             // rows 0..2 of the view matrix
 };
+constexpr int kMaskTrustSlots = 1024;   // the first launch slots (the costliest tiles of the previous frame) never consult the mask
 
 // ---------------------------------------------------------------- scalar helpers
 // glm/detail/func_common.inl: min(x,y) = (y<x)?y:x ; max(x,y) = (x<y)?y:x
@@ -563,11 +569,82 @@ __device__ __forceinline__ bool resolve_slot(const RenderParams& P, int slot, in
 }
 
 // Occupancy mask look-up for the tile (tx, ty) of this part (ty in local tile rows; a local tile lies inside one band, bands
-// being multiples of 8 rows).  tx, ty are wave-uniform.
-__device__ __forceinline__ bool tile_may_hit(const RenderParams& P, int tx, int ty) {
-    if (!P.tileMask || ty >= P.tilesY) return true;
+// being multiples of 8 rows).  tx, ty, slot are wave-uniform.  The mask is built by the first workgroups of the SAME launch
+// (mask_block): a wave never waits for it -- the first kMaskTrustSlots launch slots (the previous frame's costliest tiles: live
+// anyway) do not even look, a later wave looks only once the "complete" word carries this frame's stamp and otherwise walks
+// its tile as if there were no mask.  Tiles without work sort to the END of the launch order, and by the time their waves
+// start the mask is long complete.  Agent-scope loads: the words were written by other workgroups, possibly on another XCD.
+__device__ __forceinline__ bool tile_may_hit(const RenderParams& P, int tx, int ty, int slot) {
+    if (!P.tileMask || ty >= P.tilesY || slot < P.maskTrustSlots) return true;
+    if (__hip_atomic_load(P.tileMask + P.maskAllIndex + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.maskStamp) return true;   // not complete (yet)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the tile words below were stored before the "complete" word
     const int strip = global_row(P, ty * 8) >> 3;
-    return P.tileMask[strip * P.tilesX + tx] == P.maskStamp || P.tileMask[P.maskAllIndex] == P.maskStamp;
+    return __hip_atomic_load(P.tileMask + strip * P.tilesX + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp ||
+           __hip_atomic_load(P.tileMask + P.maskAllIndex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp;
+}
+
+// ================================================================ screen-space occupancy mask
+// About two thirds of the rays inside the solid geometry's screen rectangle miss everything (config 2: the corners of the
+// sphere's bounding box, the ring around its silhouette) -- and each still costs its wave the ray set-up (two inversesqrt,
+// three reciprocals, the root test: ~330 VALU instructions, as much as three loop trips).  The mask removes most of them
+// before any ray exists: the "coarse cells" of the tree at one level L -- its internal nodes at depth L and every solid leaf
+// at depth <= L: together they contain every solid leaf -- are projected onto the screen (conservatively: widened by a voxel,
+// which also covers config 5's Marching-Cubes triangles, and by 3 pixels), and every tile a projection touches is stamped.
+// A tile without the frame's stamp cannot contain a hit: its wave writes black (exactly what S/RT:363 gives rays that meet
+// nothing) and exits.  Stamps instead of bits: every launch brings a fresh stamp, so the array is never cleared and all
+// writers of a frame store the same value (no atomics; safe under graph replay: a replayed launch re-stamps its own tiles).
+constexpr int kMaskMaxRectTiles = 2048;    // a cell that covers more tiles than this stamps the "whole frame" word instead
+
+// One workgroup's share of a frame's mask: cell blockInFrame * kBlock + thread.  The workgroup that finishes last (ticket)
+// publishes the "complete" word.
+__device__ __forceinline__ void mask_block(const RenderParams& P, int blockInFrame) {
+    unsigned* mask = P.tileMask;
+    const unsigned stamp = P.maskStamp;
+    const int all = P.maskAllIndex;
+    const int i = blockInFrame * kBlock + (int)threadIdx.x;
+    if (i < P.maskNumCells) {
+        const int4 c = P.maskCells[i];
+        const float vs = P.voxelSize;
+        const float lo[3] = { P.gridMin[0] + (float)(c.x - 1) * vs, P.gridMin[1] + (float)(c.y - 1) * vs, P.gridMin[2] + (float)(c.z - 1) * vs };
+        const float hi[3] = { P.gridMin[0] + (float)(c.x + c.w + 1) * vs, P.gridMin[1] + (float)(c.y + c.w + 1) * vs, P.gridMin[2] + (float)(c.z + c.w + 1) * vs };
+        float lox = 3.0e38f, loy = 3.0e38f, hix = -3.0e38f, hiy = -3.0e38f;
+        bool front = true;
+        const float* V = P.viewRows;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float wx = (k & 1) ? hi[0] : lo[0], wy = (k & 2) ? hi[1] : lo[1], wz = (k & 4) ? hi[2] : lo[2];
+            const float vx = V[0] * wx + V[1] * wy + V[2] * wz + V[3];
+            const float vy = V[4] * wx + V[5] * wy + V[6] * wz + V[7];
+            const float vz = V[8] * wx + V[9] * wy + V[10] * wz + V[11];
+            // strictly in front of the eye, with room for the float error of the three dot products
+            if (!(vz < -1e-4f * (1.0f + __builtin_fabsf(vx) + __builtin_fabsf(vy) + __builtin_fabsf(vz)))) front = false;
+            const float iz = __builtin_amdgcn_rcpf(-vz);          // 1 ulp: the 3-pixel margin below is seven orders of magnitude larger
+            const float sx = ((vx * iz) * P.maskInvAspTan * 0.5f + 0.5f) * (float)P.W, sy = (0.5f - (vy * iz) * P.maskInvTanH * 0.5f) * (float)P.H;
+            lox = __builtin_fminf(lox, sx); hix = __builtin_fmaxf(hix, sx); loy = __builtin_fminf(loy, sy); hiy = __builtin_fmaxf(hiy, sy);
+        }
+        if (!front || !(hix - lox < 1.0e7f) || !(hiy - loy < 1.0e7f)) mask[all] = stamp;        // around / behind the eye, or not finite
+        else {
+            // 3 pixels of margin: 2 as the host's rectangles + 1 for this float evaluation (their errors are ~1e-3 pixel)
+            const float fx0 = __builtin_floorf(lox) - 3.0f, fx1 = __builtin_ceilf(hix) + 3.0f, fy0 = __builtin_floorf(loy) - 3.0f, fy1 = __builtin_ceilf(hiy) + 3.0f;
+            if (!(fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(P.W - 1) || fy0 > (float)(P.H - 1))) {       // else: off the screen
+                const int tx0 = (int)__builtin_fmaxf(fx0, 0.0f) >> 3, tx1 = (int)__builtin_fminf(fx1, (float)(P.W - 1)) >> 3;
+                const int ty0 = (int)__builtin_fmaxf(fy0, 0.0f) >> 3, ty1 = (int)__builtin_fminf(fy1, (float)(P.H - 1)) >> 3;
+                if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kMaskMaxRectTiles) mask[all] = stamp;
+                else
+                    for (int y = ty0; y <= ty1; y++)
+                        for (int x = tx0; x <= tx1; x++) mask[y * P.tilesX + x] = stamp;
+            }
+        }
+    }
+    __syncthreads();                                             // this workgroup's stores are issued
+    if (threadIdx.x == 0) {
+        __threadfence();                                         // release them before the ticket
+        const unsigned last = (unsigned)P.maskBlocks - 1u;
+        if (atomicInc(mask + all + 2, last) == last) {           // the ticket wraps to 0: the next launch / replay starts from zero
+            __threadfence();                                     // acquire the other workgroups' tickets, release the word below
+            __hip_atomic_store(mask + all + 1, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // The fill duty of launch slot `slot`: chunks slot, slot + launchWaves, ... of the region outside the root rectangle.
@@ -986,7 +1063,7 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
         startVisible = st.visible; startShift = st.shift; startSize = 1 << st.shift; startX = st.x; startY = st.y; startZ = st.z;
         startDesc = st.desc; startLeaf = st.leaf != 0; startSolid = st.solid != 0;
     }
-    const bool tileLive = tile_may_hit(P, tx, ty);                      // wave-uniform: scalar loads, no VALU
+    const bool tileLive = tile_may_hit(P, tx, ty, slot);                // wave-uniform
     if (inImage && startVisible && tileLive) {
         steps0 = 1;
         if (!outsideRoot) {
@@ -1109,7 +1186,7 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
                 int* rec = stepsOut + (size_t)tile * 8;
                 rec[0] = (int)(tl0 & 0xffffffffu); rec[1] = (int)(tl0 >> 32);
                 rec[2] = (int)(tl1 & 0xffffffffu); rec[3] = (int)(tl1 >> 32);
-                rec[4] = trips; rec[5] = (int)hwid; rec[6] = (int)xcc; rec[7] = act;
+                rec[4] = trips; rec[5] = (int)hwid; rec[6] = (int)xcc; rec[7] = act | (slot << 8);      // act <= 64; the launch slot above it
             }
         }
     } else {
@@ -1129,7 +1206,8 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean(RenderPar
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64], b in [0, depth]
-    const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x); return; }        // the first workgroups build the occupancy mask
+    const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (kBlock / kWave) + wave);
     if (slot >= P.launchWaves) return;
     trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
 }
@@ -1150,7 +1228,9 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_batch(Ren
     extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    const int mb = B.P[0].maskBlocks;                          // mask workgroups per frame (every frame of a batch: the same octree)
+    if ((int)blockIdx.x < mb * B.n) { const int fm = (int)blockIdx.x / mb; mask_block(B.P[fm], (int)blockIdx.x - fm * mb); return; }
+    const int g = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - mb * B.n) * (kBlock / kWave) + wave);
     const int slot = g / B.n, f = g - slot * B.n;
     const RenderParams& P = B.P[f];
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;
@@ -1868,7 +1948,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     bool hitPrimary = false;
     Ray r;
     bool alive = false;            // walking the tree
-    const bool tileLive = tile_may_hit(P, tx, ty);     // the occupancy mask (colour / shade frames): wave-uniform
+    const bool tileLive = tile_may_hit(P, tx, ty, slot);     // the occupancy mask (colour / shade frames): wave-uniform
     if (inImage && tileLive) {
         stepsTotal = 1;            // the root's own pop of the primary ray
         if (!outside) {
@@ -2074,7 +2154,8 @@ __global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles(
     const int wave = threadIdx.x >> 6;
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64], b in [0, depth]
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds_stack + (size_t)(kBlock / kWave) * (P.depth + 1) * kWave) + wave * kWave;
-    const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x); return; }
+    const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (kBlock / kWave) + wave);
     if (slot >= P.launchWaves) return;
     trace_tile_lean_triangles<MODE, SHADE>(P, Sc, shadow, out, counters, stk, keys, lane, slot);
 }
@@ -2086,7 +2167,9 @@ __global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles_
     extern __shared__ uint2 lds_stack[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + wave);
+    const int mb = B.P[0].maskBlocks;
+    if ((int)blockIdx.x < mb * B.n) { const int fm = (int)blockIdx.x / mb; mask_block(B.P[fm], (int)blockIdx.x - fm * mb); return; }
+    const int g = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - mb * B.n) * (kBlock / kWave) + wave);
     const int slot = g / B.n, f = g - slot * B.n;
     const RenderParams& P = B.P[f];
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;
@@ -3115,59 +3198,7 @@ __global__ __launch_bounds__(kBlock) void k_block_exclusive_scan(const int* __re
     if (i == 0) out[n] = (int)*total;
 }
 
-// ================================================================ screen-space occupancy mask
-// About two thirds of the rays inside the solid geometry's screen rectangle miss everything (config 2: the corners of the
-// sphere's bounding box, the ring around its silhouette) -- and each still costs its wave the ray set-up (two inversesqrt,
-// three reciprocals, the root test: ~330 VALU instructions, as much as three loop trips).  The mask removes most of them
-// before any ray exists: the "coarse cells" of the tree at one level L -- its internal nodes at depth L and every solid leaf
-// at depth <= L: together they contain every solid leaf -- are projected onto the screen (conservatively: widened by a voxel,
-// which also covers config 5's Marching-Cubes triangles, and by 3 pixels), and every tile a projection touches is stamped.
-// A tile without the frame's stamp cannot contain a hit: its wave writes black (exactly what S/RT:363 gives rays that meet
-// nothing) and exits.  Stamps instead of bits: every launch brings a fresh stamp, so the array is never cleared and all
-// writers of a frame store the same value (no atomics; safe under graph replay: a replayed launch re-stamps its own tiles).
-struct MaskCam {
-    float view[12];            // rows 0..2 of the view matrix
-    float aspTan, tanH;        // aspect * tan(fov/2), tan(fov/2)
-    int W, H, tilesX, strips;
-    unsigned stamp;
-    unsigned* mask;            // strips * tilesX words + the "whole frame" word
-};
-struct MaskBatch { MaskCam f[kMaxBatch]; int n; float gx, gy, gz, vs; };
-constexpr int kMaskMaxRectTiles = 2048;    // a cell that covers more tiles than this stamps the "whole frame" word instead
-
-__global__ __launch_bounds__(kBlock) void k_tile_mask(MaskBatch B, const int4* __restrict__ cells, int numCells) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= numCells) return;
-    const MaskCam& M = B.f[blockIdx.y];
-    const int4 c = cells[i];
-    const float lo[3] = { B.gx + (float)(c.x - 1) * B.vs, B.gy + (float)(c.y - 1) * B.vs, B.gz + (float)(c.z - 1) * B.vs };
-    const float hi[3] = { B.gx + (float)(c.x + c.w + 1) * B.vs, B.gy + (float)(c.y + c.w + 1) * B.vs, B.gz + (float)(c.z + c.w + 1) * B.vs };
-    float lox = 3.0e38f, loy = 3.0e38f, hix = -3.0e38f, hiy = -3.0e38f;
-    bool front = true;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const float wx = (k & 1) ? hi[0] : lo[0], wy = (k & 2) ? hi[1] : lo[1], wz = (k & 4) ? hi[2] : lo[2];
-        const float vx = M.view[0] * wx + M.view[1] * wy + M.view[2] * wz + M.view[3];
-        const float vy = M.view[4] * wx + M.view[5] * wy + M.view[6] * wz + M.view[7];
-        const float vz = M.view[8] * wx + M.view[9] * wy + M.view[10] * wz + M.view[11];
-        // strictly in front of the eye, with room for the float error of the three dot products
-        if (!(vz < -1e-4f * (1.0f + __builtin_fabsf(vx) + __builtin_fabsf(vy) + __builtin_fabsf(vz)))) front = false;
-        const float iz = 1.0f / -vz;
-        const float sx = ((vx * iz) / M.aspTan * 0.5f + 0.5f) * (float)M.W, sy = (0.5f - (vy * iz) / M.tanH * 0.5f) * (float)M.H;
-        lox = __builtin_fminf(lox, sx); hix = __builtin_fmaxf(hix, sx); loy = __builtin_fminf(loy, sy); hiy = __builtin_fmaxf(hiy, sy);
-    }
-    const int all = M.strips * M.tilesX;
-    if (!front || !(hix - lox < 1.0e7f) || !(hiy - loy < 1.0e7f)) { M.mask[all] = M.stamp; return; }       // around / behind the eye, or not finite
-    // 3 pixels of margin: 2 as the host's rectangles + 1 for this float evaluation (their errors are ~1e-3 pixel)
-    const float fx0 = __builtin_floorf(lox) - 3.0f, fx1 = __builtin_ceilf(hix) + 3.0f, fy0 = __builtin_floorf(loy) - 3.0f, fy1 = __builtin_ceilf(hiy) + 3.0f;
-    if (fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(M.W - 1) || fy0 > (float)(M.H - 1)) return;               // off the screen
-    const int tx0 = (int)__builtin_fmaxf(fx0, 0.0f) >> 3, tx1 = (int)__builtin_fminf(fx1, (float)(M.W - 1)) >> 3;
-    const int ty0 = (int)__builtin_fmaxf(fy0, 0.0f) >> 3, ty1 = (int)__builtin_fminf(fy1, (float)(M.H - 1)) >> 3;
-    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kMaskMaxRectTiles) { M.mask[all] = M.stamp; return; }
-    for (int y = ty0; y <= ty1; y++)
-        for (int x = tx0; x <= tx1; x++) M.mask[y * M.tilesX + x] = M.stamp;
-}
-
+// ================================================================ occupancy mask: the coarse cells (built once per octree)
 // Which level to take the cells from: per depth, the number of internal nodes and of solid leaves (one pass over the descriptors;
 // the children of the node of descriptor d lie one level below it).  counts: [0..kMaxDepth] internal, [kMaxDepth+1 ..] solid leaves.
 __global__ __launch_bounds__(kBlock) void k_cells_count(const uint2* __restrict__ desc, const int4* __restrict__ descPos, int64_t nInternal, int depth,

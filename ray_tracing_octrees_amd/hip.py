@@ -288,9 +288,10 @@ class Context:
         """Drop the launch-order tables kept for `stream` (call before destroying the stream)."""
         self._check(self._L.rto_forget_stream(self._h, C.c_void_p(stream) if stream else None))
 
-    def debug_set_tile_mask(self, enabled: bool):
-        """Switch the occupancy mask of the default kernels off / on (A/B measurements; pixels never depend on it)."""
-        self._check(self._L.rto_debug_set_tile_mask(self._h, 1 if enabled else 0))
+    def debug_set_tile_mask(self, mode):
+        """0 / False: occupancy mask off; 1 / True: on (default); 2: on, built by a launch of its own in front of the frame and
+        consulted by every wave (tests).  Pixels never depend on it."""
+        self._check(self._L.rto_debug_set_tile_mask(self._h, int(mode)))
 
     def debug_tile_mask_info(self):
         """(depth the mask's cells are taken from, number of cells); (0, 0): no mask for this octree."""

@@ -540,22 +540,22 @@ def test_occupancy_mask_never_changes_pixels_and_removes_work(ctx, orc, scenes):
             view, pos = cam.get_view(), cam.get_pos()
             f = rto.make_frame(view, pos, W / H, fov, W, H)
             want, st = oracle_frame(orc, s, view, pos, W, H, fov=fov)
-            for on in (True, False):
+            for on in (2, 1, 0):
                 ctx.debug_set_tile_mask(on)
                 for _ in range(2):
                     got = ctx.render_host(f)
-                assert_bit_exact(got, want, f"{scene} cam {(t, p, r, tgt, fov)} mask {'on' if on else 'off'}")
+                assert_bit_exact(got, want, f"{scene} cam {(t, p, r, tgt, fov)} mask mode {on}")
                 out = torch.full((2, H, W, 4), 7.0, dtype=torch.float32, device="cuda")          # the batch kernel and a 3-way partition too
                 ctx.render_batch_device(hip.Context.frame_array([f, f]), out.data_ptr(), out.stride(0) * 4, None, False, 0)
                 torch.cuda.synchronize()
-                assert_bit_exact(out[1].cpu().numpy(), want, f"{scene} batched, mask {'on' if on else 'off'}")
+                assert_bit_exact(out[1].cpu().numpy(), want, f"{scene} batched, mask mode {on}")
                 part = hip.Partition(3, 1, 16)
                 rows = partition_row_map(H, 3, 1, 16)
                 pb = torch.full((len(rows), W, 4), 7.0, dtype=torch.float32, device="cuda")
                 ctx.render_device(f, pb.data_ptr(), part)
                 ctx.synchronize()
-                assert_bit_exact(pb.cpu().numpy(), want[rows], f"{scene} part 1/3, mask {'on' if on else 'off'}")
-            ctx.debug_set_tile_mask(True)
+                assert_bit_exact(pb.cpu().numpy(), want[rows], f"{scene} part 1/3, mask mode {on}")
+            ctx.debug_set_tile_mask(2)
             gs = ctx.frame_stats(f)                              # instrumented frames never use the mask: exact pops
             assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"])
             if scene == "sphere64" and tgt == (0, 0, 0) and r == 1.8:
@@ -567,7 +567,7 @@ def test_occupancy_mask_never_changes_pixels_and_removes_work(ctx, orc, scenes):
                 inner = cost[ys.min(): ys.max() + 1, xs.min(): xs.max() + 1]
                 n_walk, n_hit, n_box = int((inner > 0).sum()), int(hit_tiles.sum()), inner.size
                 assert n_hit <= n_walk <= 1.35 * n_hit + 40 and n_walk < n_box, (n_walk, n_hit, n_box)
-    ctx.debug_set_tile_mask(True)
+    ctx.debug_set_tile_mask(1)
 
 
 def test_persistent_kernel_in_a_graph_with_an_odd_frame_count(ctx, orc, scenes):

@@ -29,7 +29,7 @@ t1 = (rec[:, 2].astype(np.uint32).astype(np.uint64) | (rec[:, 3].astype(np.uint3
 base = t0.min()
 s = (t0 - base) / 100.0   # us (100 MHz clock)
 e = (t1 - base) / 100.0
-it = rec[:, 4]; act = rec[:, 7]; xcc = rec[:, 6]; hwid = rec[:, 5].astype(np.uint32)
+it = rec[:, 4]; act = rec[:, 7] & 0xff; xcc = rec[:, 6]; hwid = rec[:, 5].astype(np.uint32)
 dur = e - s
 print(f"waves {len(rec)}  kernel span {e.max():.1f} us  (last start {s.max():.1f} us)")
 print("duration us: mean %.2f  p50 %.2f  p90 %.2f  p99 %.2f  max %.2f" % (dur.mean(), *np.percentile(dur, [50, 90, 99]), dur.max()))
