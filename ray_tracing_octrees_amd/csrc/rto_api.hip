@@ -1299,11 +1299,16 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     return RTO_OK;
 }
 
-// Experiment knob: RTO_WAVES_PER_SIMD=<n> pads the dynamic LDS request of the lean octree kernels so that at most n waves per SIMD
-// are resident (160 KB of LDS per CU, 4-wave workgroups): with fewer waves resident at the start, more of the frame's waves are
-// handed out dynamically as slots free up.  0 / unset: no padding.
-static size_t lds_for_occupancy(size_t lds) {
-    static const int waves = []() { const char* e = std::getenv("RTO_WAVES_PER_SIMD"); return e ? std::atoi(e) : 0; }();
+// Resident waves per SIMD of a lean octree launch, set through its dynamic LDS request (160 KB of LDS per CU, 4-wave workgroups:
+// workgroups per CU == waves per SIMD).  With the occupancy mask a frame has fewer waves with work than the machine has wave
+// slots at 6 per SIMD (config 2: ~5,800 against 6,144): all of them would be resident from the first microsecond, statically
+// spread, and the frame would end when the unluckiest SIMD ends (timeline: SIMD totals of 91 +- 30 loop trips).  At 5 per SIMD
+// the last sixth of the waves is handed out as slots free up -- to whichever SIMD is done first: config 2, one frame per
+// launch: 44.9 -> 38.9 us (4 and 5 per SIMD alike; 2-3: 46.7).  Launches of several frames have waves to spare and keep 6.
+// RTO_WAVES_PER_SIMD=<n> overrides (A/B runs); 0 = never pad.
+static size_t lds_for_occupancy(size_t lds, int wavesDefault) {
+    static const int forced = []() { const char* e = std::getenv("RTO_WAVES_PER_SIMD"); return e ? std::atoi(e) : -1; }();
+    const int waves = forced >= 0 ? forced : wavesDefault;
     if (waves <= 0) return lds;
     const size_t perGroup = (size_t)(160 * 1024) / (size_t)waves;          // workgroups per CU == waves per SIMD (4 waves -> 4 SIMDs)
     return std::max(lds, std::min<size_t>(perGroup, 64 * 1024) & ~(size_t)255);
@@ -1333,13 +1338,13 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
     if (c->culling && !deviceStart) { const int rcState = sync_cull_state(c); if (rcState != RTO_OK) return rcState; }
     const bool rootCulledEdge = !deviceStart && c->culling && !c->rootVisible && c->visibleNodes > 0;
     if (packed && !rootCulledEdge) {
-        const size_t lds = lds_for_occupancy((size_t)(kBlock / kWave) * (P.depth + 1) * kWave * sizeof(uint2));   // +1: the lean kernel's dummy entry
+        const size_t ldsStacks = (size_t)(kBlock / kWave) * (P.depth + 1) * kWave * sizeof(uint2);   // +1: the lean kernel's dummy entry
         if (c->kernelMode == RTO_KERNEL_PACKED_V1) {
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
             startRecorded = true;
             RenderParams Q = P;
             Q.rootVisible = c->rootVisible;                 // as of sync_cull_state above
-            hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+            hipLaunchKernelGGL(k_trace_packed<MODE>, dim3(blocks), dim3(kBlock), ldsStacks, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
         } else {
             RenderParams Q = P;
             if (deviceStart) { Q.start = c->d_start; Q.rootVisible = 1; }       // what is visible is the device's knowledge: waves for the whole rectangle
@@ -1353,6 +1358,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 if (rc != RTO_OK) return rc;
             }
             const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
+            const size_t lds = Q.tileMask ? lds_for_occupancy(ldsStacks, 5) : lds_for_occupancy(ldsStacks, 0);
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
             startRecorded = true;
             const bool persistent = c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT && st && frameMode;
@@ -1498,7 +1504,7 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
     hipEvent_t evA = c->ev0, evB = c->ev1;
     if (!noEvents && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
     if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
-    const size_t lds = lds_for_occupancy((size_t)(kBlock / kWave) * (Ps[0].depth + 1) * kWave * sizeof(uint2));
+    const size_t lds = lds_for_occupancy((size_t)(kBlock / kWave) * (Ps[0].depth + 1) * kWave * sizeof(uint2), 0);
     const long long waves = (long long)maxWaves * n;
     if (c->maskMode == 2 && B.P[0].maskBlocks > 0)
         hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)(B.P[0].maskBlocks * n)), dim3(kBlock), lds, s, B, c->d_desc);

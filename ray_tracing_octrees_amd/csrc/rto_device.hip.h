@@ -577,7 +577,9 @@ __device__ __forceinline__ bool resolve_slot(const RenderParams& P, int slot, in
 __device__ __forceinline__ bool tile_may_hit(const RenderParams& P, int tx, int ty, int slot) {
     if (!P.tileMask || ty >= P.tilesY || slot < P.maskTrustSlots) return true;
     if (__hip_atomic_load(P.tileMask + P.maskAllIndex + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.maskStamp) return true;   // not complete (yet)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the tile words below were stored before the "complete" word
+    // No acquire fence here: it would invalidate the whole CU's L1 (the descriptors!) once per wave.  The loads below are
+    // agent-scope loads themselves (they do not read this CU's or this XCD's stale lines) and are issued after the branch on
+    // the load above has resolved; the words they read were stored, and released, before the "complete" word.
     const int strip = global_row(P, ty * 8) >> 3;
     return __hip_atomic_load(P.tileMask + strip * P.tilesX + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp ||
            __hip_atomic_load(P.tileMask + P.maskAllIndex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp;
