@@ -1857,7 +1857,9 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
         if ((rc = prepare_schedule(c, s, capturing, !count, false, 1, solidRect, P, &st, leanTri ? 0 : -1)) != RTO_OK) return rc;
     }
     const bool noEvents = capturing || c->eventsOff;
-    if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev0, s));
+    hipEvent_t evA = c->ev0, evB = c->ev1;                 // a timing-ring slot per launch that records events (rto_timing_begin)
+    if (!noEvents && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
+    if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
     if (packed) {
         const int lblocks = (P.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
         if (c->d_triRec && c->kernelMode != RTO_KERNEL_PACKED_V3) {
@@ -1884,7 +1886,8 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
         else hipLaunchKernelGGL((k_trace_triangles<kModeColor, false>), dim3(blocks), dim3(kBlock), 0, s, P, S, shadow, d_out, c->d_counters);
     }
     RTO_HIP(c, hipGetLastError());
-    if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev1, s));
+    if (!noEvents) RTO_HIP(c, hipEventRecord(evB, s));
+    c->lastA = evA; c->lastB = evB;
     c->timed = !noEvents;
     return RTO_OK;
 }
@@ -1927,7 +1930,9 @@ static int launch_triangles_batch(rto_context* c, const rto_frame* frames, int n
         B.P[i].tileOrder = fits ? T.d : nullptr;
     }
     if (maxWaves <= 0) return RTO_OK;
-    if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev0, s));
+    hipEvent_t evA = c->ev0, evB = c->ev1;
+    if (!noEvents && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
+    if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
     LeanTriScene S{ c->d_triRec, c->d_tris };
     const size_t lds = (size_t)(kBlock / kWave) * ((B.P[0].depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));
     const long long waves = (long long)maxWaves * n;
@@ -1937,7 +1942,8 @@ static int launch_triangles_batch(rto_context* c, const rto_frame* frames, int n
     if (shadeOut) hipLaunchKernelGGL(k_trace_lean_triangles_batch<true>, grid, dim3(kBlock), lds, s, B, S, shadow);
     else hipLaunchKernelGGL(k_trace_lean_triangles_batch<false>, grid, dim3(kBlock), lds, s, B, S, shadow);
     RTO_HIP(c, hipGetLastError());
-    if (!noEvents) RTO_HIP(c, hipEventRecord(c->ev1, s));
+    if (!noEvents) RTO_HIP(c, hipEventRecord(evB, s));
+    c->lastA = evA; c->lastB = evB;
     c->timed = !noEvents;
     return RTO_OK;
 }
