@@ -154,6 +154,15 @@ def load_voxel_grid(path: str) -> Grid:
                 np.float32(cg.voxelSize), data.reshape(cg.dimZ, cg.dimY, cg.dimX))
 
 
+def save_voxel_grid(path: str, g: Grid) -> bool:
+    """orc_save_voxel_grid: the sceneCache.bin writer (S/CacheUtils.cpp:5-30)."""
+    L = lib()
+    L.orc_save_voxel_grid.argtypes = [C.c_char_p, C.POINTER(_Grid)]
+    L.orc_save_voxel_grid.restype = C.c_int
+    cg = g.c()
+    return bool(L.orc_save_voxel_grid(path.encode(), C.byref(cg)))
+
+
 def build_flat_octree(g: Grid) -> np.ndarray:
     out = C.c_void_p()
     cg = g.c()

@@ -78,6 +78,11 @@ def main():
         "filled": int(cal.data.sum()), "nodes": int(len(a)), "leaves": int((a["isLeaf"] == 1).sum()),
         "solid_leaves": int(((a["isLeaf"] == 1) & (a["isSolid"] == 1)).sum()), "root_size": int(a["size"][0]), "sha256": sha(a)}
     print("calgary", len(a))
+    # the file itself (S/CacheUtils.cpp:5-30 wrote it): 3 x int32 dims, 4 x float32 min / voxel size, uint64 count, count bytes.
+    # Its SHA-256 and 36-byte header pin the product's saveVoxelGrid / loadVoxelGrid to the reference's BYTES, not just its size.
+    raw = open("/root/reference/sceneCache.bin", "rb").read()
+    meta["scene_cache_file"] = {"source": "/root/reference/sceneCache.bin as shipped", "bytes": len(raw), "sha256": hashlib.sha256(raw).hexdigest(),
+                                "header_hex": raw[:36].hex(), "voxel_byte_values": sorted(int(v) for v in np.unique(np.frombuffer(raw[36:], np.uint8)))}
 
     # ---- ref: cameras + glm ---------------------------------------------------------------------
     cams = {"sphere": (SPHERE_CAM, None), "calgary_default": (CALGARY_DEFAULT, (0.0, 100.0)),

@@ -168,12 +168,34 @@ def test_host_frustum_matches_reference(golden):
             np.testing.assert_array_equal(got, z[f"frustum_{cam}_m{int(margin)}"])
 
 
-def test_host_cache_file_roundtrip(tmp_path, scenes, orc):
+def test_host_cache_file_roundtrip(tmp_path, scenes, orc, golden_meta):
+    """N3: the sceneCache.bin format (S/CacheUtils.cpp:5-59) pinned to the reference's BYTES: saveVoxelGrid of the decoded
+    fixture reproduces the SHA-256 of the file the reference ships (recorded by make_golden.py), byte for byte; loadVoxelGrid
+    parses the reference's own 36-byte header."""
+    import hashlib
+    import struct
+
     cal = scenes("calgary")
+    ref = golden_meta["scene_cache_file"]
     g = rto.VoxelGrid.from_array(cal.grid.data, cal.min, cal.voxel)
     path = str(tmp_path / "sceneCache.bin")
     assert rto.saveVoxelGrid(path, g)
-    assert os.path.getsize(path) == 2995011                  # the size of the reference's own sceneCache.bin
+    raw = open(path, "rb").read()
+    assert len(raw) == ref["bytes"] == 2995011                # the size of the reference's own sceneCache.bin
+    assert raw[:36].hex() == ref["header_hex"], "header: 3 x int32 dims, 4 x float32 min / voxel size, uint64 count"
+    assert hashlib.sha256(raw).hexdigest() == ref["sha256"], "the product's writer reproduces the reference's file"
+    dx, dy, dz, mx, my, mz, vs, count = struct.unpack("<3i4fQ", bytes.fromhex(ref["header_hex"]))
+    assert (dx, dy, dz, count) == (425, 243, 29, 425 * 243 * 29) and ref["voxel_byte_values"] == [0, 1]
+    hdr_only = str(tmp_path / "header_then_zeros.bin")       # the reference's header in front of other data: the reader takes every field from it
+    with open(hdr_only, "wb") as f:
+        f.write(bytes.fromhex(ref["header_hex"]))
+        f.write(bytes(count))
+    parsed = rto.loadVoxelGrid(hdr_only)
+    assert parsed.dims == (dx, dy, dz) and float(parsed.voxelSize) == vs and [float(x) for x in parsed.min] == [mx, my, mz]
+    assert int(parsed.data.sum()) == 0
+    opath = str(tmp_path / "oracle.bin")                      # the oracle's writer: the same bytes
+    assert orc.save_voxel_grid(opath, cal.grid)
+    assert hashlib.sha256(open(opath, "rb").read()).hexdigest() == ref["sha256"]
     back = rto.loadVoxelGrid(path)
     assert back.dims == (425, 243, 29) and (back.data == cal.grid.data).all()
     np.testing.assert_array_equal(back.min, cal.min)
