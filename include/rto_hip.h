@@ -329,6 +329,28 @@ int  rto_render_triangles_shade_device(rto_context* ctx, const rto_frame* frame,
 int  rto_octree_ray_skip(rto_context* ctx, const float ro[3], const float* rd, int64_t n, float t_min, float t_max,
                          int use_visibility, float* out_t);
 
+/* The same search as a RENDER MODE (octreeRaySkip "as a second kernel mode = nearest hit"): for every
+ * pixel, the ray of generateRay (S/RayTracerBVH.cpp:338-355, origin = cam_pos) goes through
+ * octreeRaySkip(root, ro, rd, 0, 1e30, grid, visibility) (S/VolumeRaycastRenderer.cpp:50-155).  d_dist (width*height floats,
+ * row 0 = top, may be NULL): the distance it returns, 1e30 = nothing -- bit-identical to the reference's compiled function on
+ * those rays (tests/golden/ref_ray_skip.npz "pixels").  d_rgba (RGBA32F, may be NULL): the reference's shade
+ * (S/RayTracerBVH.cpp:283-285, 331-336: box-centre pseudo-normal, Lambert + 0.1) of the leaf that distance belongs to, at
+ * tHit = that distance; background (0,0,0,1).  Asynchronous on hip_stream, outputs stay on the device; part as in
+ * rto_render_device.  Canonical BFS octrees only.  _host: synchronous convenience (either pointer may be NULL). */
+int  rto_render_skip_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part /* NULL = whole frame */, int use_visibility,
+                            void* d_rgba, void* d_dist, void* hip_stream);
+int  rto_render_skip_host(rto_context* ctx, const rto_frame* frame, int use_visibility, float* host_rgba, float* host_dist);
+/* octreeRaySkip's CONSUMER in drawRaycast (S/VolumeRaycastRenderer.cpp:1602-1663) in one launch, nothing copied: the 7x7 probe
+ * directions through inverse(perspective(45 deg, aspect, 0.1, 5000)) and inverse(view), the 49 traversals, the value std::sort
+ * would leave at index int(n * 0.15f) among the valid distances (0 < t < 1e30) x 0.75, and the temporal blend
+ * *d_skip = *d_skip * 0.4f + that * 0.6f (`static float lastSkipDistance` of :1658 = the float the caller keeps on the device:
+ * set it to 0 before the first frame).  Asynchronous on hip_stream.  _host: the same with a host float (synchronous); probe_t
+ * (may be NULL) receives the 49 distances. */
+int  rto_probe_skip_device(rto_context* ctx, const float view[16], const float cam_pos[3], float aspect, int use_visibility,
+                           void* d_skip /* one float on the device: in = previous value, out = new */, void* hip_stream);
+int  rto_probe_skip_host(rto_context* ctx, const float view[16], const float cam_pos[3], float aspect, int use_visibility,
+                         float* io_skip, float* probe_t /* 49 floats or NULL */);
+
 /* ---- instrumentation ------------------------------------------------------*/
 /* Renders the frame once with counting enabled (synchronous). */
 int  rto_frame_stats(rto_context* ctx, const rto_frame* frame, rto_stats* out);

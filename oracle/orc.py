@@ -296,6 +296,52 @@ def octree_ray_skip_many(nodes, grid_min, voxel_size, ro, rds, tmin=0.0, tmax=1e
     return np.array([octree_ray_skip(nodes, grid_min, voxel_size, ro, rds[i], tmin, tmax, visible) for i in range(len(rds))], np.float32)
 
 
+def generate_rays(view, cam_pos, aspect, fov_deg, W, H) -> np.ndarray:
+    """generateRay (S/RayTracerBVH.cpp:338-355) for every pixel: (H, W, 3) float32, row 0 = top."""
+    L = lib()
+    L.orc_generate_rays.argtypes = [_f32p, _f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    L.orc_generate_rays.restype = None
+    rd = np.zeros((H, W, 3), np.float32)
+    L.orc_generate_rays(_f32(view).reshape(16), _f32(cam_pos), aspect, fov_deg, W, H, rd.ctypes.data)
+    return rd
+
+
+def render_skip(nodes, grid_min, voxel_size, view, cam_pos, aspect, fov_deg, W, H, visible=None, nthreads=1):
+    """Nearest-hit render mode: per pixel octreeRaySkip(root, ro, generateRay(px, py), 0, 1e30) -> (rgba (H, W, 4), dist (H, W))."""
+    L = lib()
+    L.orc_render_skip.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_render_skip.restype = None
+    nodes = np.ascontiguousarray(nodes)
+    v = None if visible is None else np.ascontiguousarray(visible, dtype=np.uint8)
+    rgba = np.zeros((H, W, 4), np.float32)
+    dist = np.zeros((H, W), np.float32)
+    L.orc_render_skip(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size), _f32(view).reshape(16), _f32(cam_pos),
+                      aspect, fov_deg, W, H, None if v is None else v.ctypes.data, rgba.ctypes.data, dist.ctypes.data, nthreads)
+    return rgba, dist
+
+
+def probe_rays(view, eye, aspect) -> np.ndarray:
+    """The 7x7 probe directions of drawRaycast (S/VolumeRaycastRenderer.cpp:1602-1630), restated: (49, 3)."""
+    L = lib()
+    L.orc_probe_rays.argtypes = [_f32p, _f32p, C.c_float, C.c_void_p]
+    L.orc_probe_rays.restype = None
+    rd = np.zeros((49, 3), np.float32)
+    L.orc_probe_rays(_f32(view).reshape(16), _f32(eye), aspect, rd.ctypes.data)
+    return rd
+
+
+def probe_skip_distance(nodes, grid_min, voxel_size, view, eye, aspect, last=0.0, visible=None) -> np.float32:
+    """octreeSkipT as drawRaycast computes it (S/VolumeRaycastRenderer.cpp:1602-1663): probes -> 15th percentile x 0.75 -> blend with `last`."""
+    L = lib()
+    L.orc_probe_skip_distance.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_void_p, C.c_float]
+    L.orc_probe_skip_distance.restype = C.c_float
+    nodes = np.ascontiguousarray(nodes)
+    v = None if visible is None else np.ascontiguousarray(visible, dtype=np.uint8)
+    return np.float32(L.orc_probe_skip_distance(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size), _f32(view).reshape(16), _f32(eye),
+                                                aspect, None if v is None else v.ctypes.data, float(np.float32(last))))
+
+
 def local_mc(g: Grid, x0, y0, z0, size) -> np.ndarray:
     out = C.c_void_p()
     cg = g.c()

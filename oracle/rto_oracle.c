@@ -680,7 +680,7 @@ void orc_render_visits(const orc_node* nodes, int64_t n, const float gridMin[3],
 /* N1: octreeRaySkip (S/VolumeRaycastRenderer.cpp:50-155), on the flat array */
 /* ------------------------------------------------------------------ */
 static float ray_skip_rec(const orc_node* nodes, int32_t idx, const float gridMin[3], float vx,
-                          v3 ro, v3 rd, float tMin, float tMax, const uint8_t* vis) {
+                          v3 ro, v3 rd, float tMin, float tMax, const uint8_t* vis, int32_t* hitLeaf) {
     if (idx < 0) return 1e30f;                                   /* :60-62 */
     if (vis && !vis[idx]) return 1e30f;                          /* :64-67: a node the visibility map holds as false */
     const orc_node* node = &nodes[idx];
@@ -708,6 +708,7 @@ static float ray_skip_rec(const orc_node* nodes, int32_t idx, const float gridMi
     if (enterT > exitT) return 1e30f;                             /* :100-102 */
     if (node->isLeaf) {                                           /* :105-110 */
         if (!node->isSolid) return 1e30f;
+        if (hitLeaf) *hitLeaf = idx;                                 /* (not in the reference: which leaf the distance belongs to) */
         return enterT;
     }
     int dirMask = ((rd.x > 0) ? 1 : 0) | ((rd.y > 0) ? 2 : 0) | ((rd.z > 0) ? 4 : 0);   /* :114-116 */
@@ -719,7 +720,7 @@ static float ray_skip_rec(const orc_node* nodes, int32_t idx, const float gridMi
             if (bitDiff != dist) continue;
             int32_t child = node->child[octant];
             if (child < 0) continue;
-            float childT = ray_skip_rec(nodes, child, gridMin, vx, ro, rd, enterT, exitT, vis);
+            float childT = ray_skip_rec(nodes, child, gridMin, vx, ro, rd, enterT, exitT, vis, hitLeaf);
             if (childT < bestT) {
                 bestT = childT;
                 if (childT < 1e30f) return childT;
@@ -732,14 +733,118 @@ static float ray_skip_rec(const orc_node* nodes, int32_t idx, const float gridMi
 float orc_octree_ray_skip(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
                           const float ro[3], const float rd[3], float tMin, float tMax) {
     if (n <= 0) return 1e30f;
-    return ray_skip_rec(nodes, 0, gridMin, voxelSize, v3_(ro[0], ro[1], ro[2]), v3_(rd[0], rd[1], rd[2]), tMin, tMax, NULL);
+    return ray_skip_rec(nodes, 0, gridMin, voxelSize, v3_(ro[0], ro[1], ro[2]), v3_(rd[0], rd[1], rd[2]), tMin, tMax, NULL, NULL);
 }
 
 /* the same with the reference's visibility map (S/VolumeRaycastRenderer.cpp:64-67) as one flag per node of the flat array */
 float orc_octree_ray_skip_vis(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
                               const float ro[3], const float rd[3], float tMin, float tMax, const uint8_t* vis) {
     if (n <= 0) return 1e30f;
-    return ray_skip_rec(nodes, 0, gridMin, voxelSize, v3_(ro[0], ro[1], ro[2]), v3_(rd[0], rd[1], rd[2]), tMin, tMax, vis);
+    return ray_skip_rec(nodes, 0, gridMin, voxelSize, v3_(ro[0], ro[1], ro[2]), v3_(rd[0], rd[1], rd[2]), tMin, tMax, vis, NULL);
+}
+
+/* The per-pixel ray directions of S/RayTracerBVH.cpp:338-355 (generateRay): W*H x 3 floats, row 0 = top. */
+void orc_generate_rays(const float view[16], const float camPos[3], float aspect, float fovDeg, int W, int H, float* rd) {
+    frame_consts fc;
+    const float zero[3] = { 0, 0, 0 };
+    frame_setup(&fc, zero, 1.0f, view, camPos, aspect, fovDeg, W, H);
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            v3 d;
+            generate_ray(&fc, px, py, &d);
+            float* o = rd + ((size_t)py * W + px) * 3;
+            o[0] = d.x; o[1] = d.y; o[2] = d.z;
+        }
+}
+
+/* N1 as a render mode ("octreeRaySkip as a second kernel mode = nearest-hit"): per pixel, the ray of
+ * generateRay (S/RayTracerBVH.cpp:338-355) goes through octreeRaySkip(root, ro, rd, 0, 1e30, grid, visibility)
+ * (S/VolumeRaycastRenderer.cpp:50-155).  outT: the distance it returns (1e30: nothing).  outRGBA (may be NULL): the
+ * reference's shade (S/RayTracerBVH.cpp:283-285, 331-336) of the leaf that distance belongs to, with tHit = that distance;
+ * (0,0,0,1) without a hit.  The distances are pinned by the reference's compiled function (tests/golden/ref_ray_skip.npz,
+ * "pixels_*"); the colour is this project's combination of the two reference pieces. */
+void orc_render_skip(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                     const float view[16], const float camPos[3], float aspect, float fovDeg, int W, int H,
+                     const uint8_t* vis, float* outRGBA, float* outT, int nthreads) {
+    frame_consts fc;
+    frame_setup(&fc, gridMin, voxelSize, view, camPos, aspect, fovDeg, W, H);
+    v3 ro = v3_(camPos[0], camPos[1], camPos[2]);
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            v3 rd;
+            generate_ray(&fc, px, py, &rd);
+            int32_t leaf = -1;
+            float t = n > 0 ? ray_skip_rec(nodes, 0, gridMin, voxelSize, ro, rd, 0.0f, 1e30f, vis, &leaf) : 1e30f;
+            const size_t pix = (size_t)py * W + px;
+            if (outT) outT[pix] = t;
+            if (!outRGBA) continue;
+            trace_result tr; tr.hit = 0; tr.steps = 0; tr.max_sp = 0; tr.internal = 0; tr.normal = v3_(0, 0, 0);
+            if (t < 1e30f && leaf >= 0) {
+                const orc_node* nd = &nodes[leaf];
+                v3 nodeMin = v3_(gridMin[0] + (float)nd->x * voxelSize, gridMin[1] + (float)nd->y * voxelSize, gridMin[2] + (float)nd->z * voxelSize);
+                float ext = (float)nd->size * voxelSize;
+                v3 nodeMax = v3_(nodeMin.x + ext, nodeMin.y + ext, nodeMin.z + ext);
+                v3 center = v3_(0.5f * (nodeMin.x + nodeMax.x), 0.5f * (nodeMin.y + nodeMax.y), 0.5f * (nodeMin.z + nodeMax.z));
+                v3 p = v3_(ro.x + rd.x * t, ro.y + rd.y * t, ro.z + rd.z * t);
+                tr.hit = 1;
+                tr.normal = v3_normalize(v3_sub(p, center));
+            }
+            shade_store(&tr, outRGBA + pix * 4);
+        }
+}
+
+/* The consumer of octreeRaySkip in drawRaycast (S/VolumeRaycastRenderer.cpp:1602-1663): 7x7 probe directions through
+ * inverse(perspective(45 deg, aspect, 0.1, 5000)) and inverse(view), the traversal, the 15th percentile of the valid
+ * distances x 0.75, and the temporal blend with the previous value (0.4 old + 0.6 new).  rd (may be NULL): the 49 directions. */
+void orc_probe_rays(const float view[16], const float eye[3], float aspect, float* rd) {
+    float P[16], invP[16], invV[16];
+    orc_perspective(orc_radians(45.0f), aspect, 0.1f, 5000.0f, P);
+    orc_mat4_inverse(P, invP);
+    orc_mat4_inverse(view, invV);
+    const int gridSize = 7;
+    const float sampleOffset = 0.2f;
+    for (int y = 0; y < gridSize; y++)
+        for (int x = 0; x < gridSize; x++) {
+            float ndcX = ((float)x / (gridSize - 1) - 0.5f) * 2.0f * sampleOffset;
+            float ndcY = ((float)y / (gridSize - 1) - 0.5f) * 2.0f * sampleOffset;
+            const float c[4] = { ndcX, ndcY, 1.f, 1.f };
+            float vp[4], wp[4];
+            /* glm mat4 * vec4 (type_mat4x4.inl:561-571): (m0*v0 + m1*v1) + (m2*v2 + m3*v3) */
+            for (int r = 0; r < 4; r++) vp[r] = (M(invP, 0, r) * c[0] + M(invP, 1, r) * c[1]) + (M(invP, 2, r) * c[2] + M(invP, 3, r) * c[3]);
+            const float w = vp[3];
+            for (int r = 0; r < 4; r++) vp[r] = vp[r] / w;                     /* viewPos /= viewPos.w */
+            for (int r = 0; r < 4; r++) wp[r] = (M(invV, 0, r) * vp[0] + M(invV, 1, r) * vp[1]) + (M(invV, 2, r) * vp[2] + M(invV, 3, r) * vp[3]);
+            v3 d = v3_normalize(v3_(wp[0] - eye[0], wp[1] - eye[1], wp[2] - eye[2]));
+            float* o = rd + 3 * (y * gridSize + x);
+            o[0] = d.x; o[1] = d.y; o[2] = d.z;
+        }
+}
+
+static int cmp_float(const void* a, const void* b) { float x = *(const float*)a, y = *(const float*)b; return (x > y) - (x < y); }
+
+float orc_probe_skip_distance(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                              const float view[16], const float eye[3], float aspect, const uint8_t* vis, float lastSkipDistance) {
+    float rd[49 * 3], valid[49];
+    int nv = 0;
+    orc_probe_rays(view, eye, aspect, rd);
+    for (int i = 0; i < 49; i++) {
+        float t = n > 0 ? ray_skip_rec(nodes, 0, gridMin, voxelSize, v3_(eye[0], eye[1], eye[2]), v3_(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]), 0.0f, 1e30f, vis, NULL) : 1e30f;
+        if (t < 1e30f && t > 0.0f) valid[nv++] = t;                            /* :1640-1642 */
+    }
+    float skipDistance = 0.0f;
+    if (nv > 0) {
+        qsort(valid, (size_t)nv, sizeof(float), cmp_float);                    /* :1649 */
+        int safeIndex = (int)((float)nv * 0.15f);                              /* :1650 */
+        if (safeIndex < 0) safeIndex = 0;
+        skipDistance = valid[safeIndex];
+        skipDistance *= 0.75f;                                                 /* :1654 */
+    }
+    const float blendFactor = 0.4f;                                            /* :1659-1661 */
+    return lastSkipDistance * blendFactor + skipDistance * (1.0f - blendFactor);
 }
 
 /* ------------------------------------------------------------------ */

@@ -118,6 +118,16 @@ float orc_octree_ray_skip(const orc_node* nodes, int64_t n, const float gridMin[
 float orc_octree_ray_skip_vis(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
                               const float ro[3], const float rd[3], float tMin, float tMax, const uint8_t* vis);
 
+/* generateRay for every pixel (W*H x 3), the nearest-hit render mode built on octreeRaySkip, and octreeRaySkip's consumer in
+ * drawRaycast (S/VolumeRaycastRenderer.cpp:1602-1663): see rto_oracle.c. */
+void orc_generate_rays(const float view[16], const float camPos[3], float aspect, float fovDeg, int W, int H, float* rd);
+void orc_render_skip(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                     const float view[16], const float camPos[3], float aspect, float fovDeg, int W, int H,
+                     const uint8_t* vis, float* outRGBA, float* outT, int nthreads);
+void orc_probe_rays(const float view[16], const float eye[3], float aspect, float* rd);
+float orc_probe_skip_distance(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                              const float view[16], const float eye[3], float aspect, const uint8_t* vis, float lastSkipDistance);
+
 /* ---- N2: leaf triangles + shadow ray (BASELINE config 5) -------------------------------------------
  * localMC is a restatement of S/OctreeVoxel.cpp:780-879 and IS pinned by the reference's own triangles
  * (tests/golden/ref_localmc_sphere16.npz, ref_mc_cases.npz).  The renderer below has NO reference counterpart

@@ -2066,6 +2066,92 @@ int rto_octree_ray_skip(rto_context* c, const float ro[3], const float* rd, int6
     return RTO_OK;
 }
 
+// ---- N1 as a render mode + N1's consumer ------------------------------------------------------------------------------
+static int launch_skip_render(rto_context* c, const rto_frame* f, const rto_partition* p, int use_visibility, float4* d_rgba, float* d_dist, hipStream_t s) {
+    if (!d_rgba && !d_dist) return fail(c, RTO_E_INVALID, "rto_render_skip: neither output given");
+    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_render_skip: no octree uploaded");
+    if (!(c->canonical && c->numInternal > 0)) return fail(c, RTO_E_UNSUPPORTED, "rto_render_skip: needs a canonical BFS octree (what setOctree / rto_build_octree produce)");
+    if (s != c->stream) c->otherStreams = true;
+    RenderParams P;
+    int rc = fill_params(c, f, p, P, s);
+    if (rc != RTO_OK) return rc;
+    const int tiles = P.tilesX * P.tilesY;
+    if (tiles <= 0) return RTO_OK;
+    const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint4);
+    if (lds > 64 * 1024) return fail(c, RTO_E_UNSUPPORTED, "rto_render_skip: octree too deep for the LDS frames");
+    const uint8_t* vis = (use_visibility && c->culling) ? c->d_vis : nullptr;
+    const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
+    hipLaunchKernelGGL(k_skip_render, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, vis, vis ? 1 : 0, d_rgba, d_dist);
+    RTO_HIP(c, hipGetLastError());
+    return RTO_OK;
+}
+
+int rto_render_skip_device(rto_context* c, const rto_frame* f, const rto_partition* p, int use_visibility, void* d_rgba, void* d_dist, void* hip_stream) {
+    if (!c) return RTO_E_INVALID;
+    RTO_HIP(c, hipSetDevice(c->device));
+    return launch_skip_render(c, f, p, use_visibility, (float4*)d_rgba, (float*)d_dist, (hipStream_t)hip_stream);
+}
+
+int rto_render_skip_host(rto_context* c, const rto_frame* f, int use_visibility, float* host_rgba, float* host_dist) {
+    if (!c) return RTO_E_INVALID;
+    if (!f || (!host_rgba && !host_dist)) return fail(c, RTO_E_INVALID, "rto_render_skip_host: NULL argument");
+    RTO_HIP(c, hipSetDevice(c->device));
+    if (f->width <= 0 || f->height <= 0) return fail(c, RTO_E_INVALID, "render: width/height must be positive");
+    const size_t pixels = (size_t)f->width * f->height;
+    int rc = ensure_frame(c, pixels + (pixels + 3) / 4);           // RGBA frame + the distances behind it
+    if (rc != RTO_OK) return rc;
+    float* d_dist = reinterpret_cast<float*>(c->d_frame + pixels);
+    if ((rc = launch_skip_render(c, f, nullptr, use_visibility, host_rgba ? c->d_frame : nullptr, host_dist ? d_dist : nullptr, c->stream)) != RTO_OK) return rc;
+    if (host_rgba) RTO_HIP(c, hipMemcpyAsync(host_rgba, c->d_frame, pixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (host_dist) RTO_HIP(c, hipMemcpyAsync(host_dist, d_dist, pixels * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    return RTO_OK;
+}
+
+static int launch_probe_skip(rto_context* c, const float view[16], const float cam_pos[3], float aspect, int use_visibility, float* d_skip, float* d_probeT, hipStream_t s) {
+    if (!view || !cam_pos || !d_skip) return fail(c, RTO_E_INVALID, "rto_probe_skip: NULL argument");
+    if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_probe_skip: no octree uploaded");
+    if (!(c->canonical && c->numInternal > 0)) return fail(c, RTO_E_UNSUPPORTED, "rto_probe_skip: needs a canonical BFS octree");
+    if (s != c->stream) c->otherStreams = true;
+    ProbeParams Q;
+    // S/VR:1608-1612: P = perspective(radians(45), aspect, 0.1, 5000); invV = inverse(V); invP = inverse(P) -- pixel independent, on the host
+    const rtmath::mat4 P = rtmath::perspective(rtmath::radians(45.0f), aspect, 0.1f, 5000.0f);
+    const rtmath::mat4 invP = rtmath::inverse(P), invV = rtmath::inverse(rtmath::mat4::from(view));
+    std::memcpy(Q.invP, invP.data(), sizeof Q.invP);
+    std::memcpy(Q.invV, invV.data(), sizeof Q.invV);
+    std::memcpy(Q.eye, cam_pos, sizeof Q.eye);
+    Q.gx = c->gridMin[0]; Q.gy = c->gridMin[1]; Q.gz = c->gridMin[2]; Q.vs = c->voxelSize;
+    Q.rootSize = c->rootSize; Q.depth = c->depth > 0 ? c->depth : 1;
+    const size_t lds = (size_t)Q.depth * kWave * sizeof(uint4);
+    if (lds > 64 * 1024) return fail(c, RTO_E_UNSUPPORTED, "rto_probe_skip: octree too deep for the LDS frames");
+    const uint8_t* vis = (use_visibility && c->culling) ? c->d_vis : nullptr;
+    hipLaunchKernelGGL(k_probe_skip, dim3(1), dim3(kWave), lds, s, Q, c->d_desc, vis, vis ? 1 : 0, d_skip, d_probeT);
+    RTO_HIP(c, hipGetLastError());
+    return RTO_OK;
+}
+
+int rto_probe_skip_device(rto_context* c, const float view[16], const float cam_pos[3], float aspect, int use_visibility, void* d_skip, void* hip_stream) {
+    if (!c) return RTO_E_INVALID;
+    RTO_HIP(c, hipSetDevice(c->device));
+    return launch_probe_skip(c, view, cam_pos, aspect, use_visibility, (float*)d_skip, nullptr, (hipStream_t)hip_stream);
+}
+
+int rto_probe_skip_host(rto_context* c, const float view[16], const float cam_pos[3], float aspect, int use_visibility, float* io_skip, float* probe_t) {
+    if (!c) return RTO_E_INVALID;
+    if (!io_skip) return fail(c, RTO_E_INVALID, "rto_probe_skip_host: io_skip is NULL");
+    RTO_HIP(c, hipSetDevice(c->device));
+    BuildScratch scratch(c->stream);
+    float* d = nullptr;
+    RTO_HIP(c, scratch.alloc(&d, 64));
+    RTO_HIP(c, hipMemcpyAsync(d, io_skip, sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const int rc = launch_probe_skip(c, view, cam_pos, aspect, use_visibility, d, probe_t ? d + 8 : nullptr, c->stream);
+    if (rc != RTO_OK) return rc;
+    RTO_HIP(c, hipMemcpyAsync(io_skip, d, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (probe_t) RTO_HIP(c, hipMemcpyAsync(probe_t, d + 8, 49 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    return RTO_OK;
+}
+
 int rto_last_kernel_ms(rto_context* c, float* ms) {
     if (!c || !ms) return RTO_E_INVALID;
     if (!c->timed) return fail(c, RTO_E_INVALID, "rto_last_kernel_ms: no kernel launched yet");

@@ -2344,6 +2344,183 @@ __global__ __launch_bounds__(kBlock) void k_octree_ray_skip_packed(const uint2* 
     out[i] = result;
 }
 
+// ---------------------------------------------------------------- N1 as a render mode, and N1's consumer
+// skip_traverse: the search of k_octree_ray_skip_packed with the per-ray frames in LDS ([level][lane], 16 bytes each) instead
+// of a private array, and an O(1) return to the deepest level that still has untried children (`pend`), so that a whole
+// frame of rays (rto_render_skip_device: "nearest hit" as SURVEY.md section 8f asks for it) runs at a useful rate.  Same float
+// operations per child, same child order (Hamming distance from the octant of the positive direction bits, ties by octant
+// index, S/VR:122-152), same visibility rule; pinned per pixel by the reference's compiled function (ref_ray_skip.npz).
+// Entry of the node at depth L (children of edge rootSize >> (L + 1)):
+//   .x = untried candidates in TRAVERSAL order (8) | solid mask << 8 | internal mask << 16    .y = first internal child
+//   .z / .w = the node's clipped interval [enterT, exitT]
+struct SkipRay { float ox, oy, oz, ix, iy, iz; unsigned order; };
+
+__device__ __forceinline__ SkipRay skip_ray(float ox, float oy, float oz, float dx, float dy, float dz) {
+    SkipRay r;
+    r.ox = ox; r.oy = oy; r.oz = oz;
+    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;                  // S/VR:81-87
+    const float smallValue = 1e-10f;
+    if (__builtin_fabsf(dx) < smallValue) r.ix = dx >= 0 ? 1e10f : -1e10f;
+    if (__builtin_fabsf(dy) < smallValue) r.iy = dy >= 0 ? 1e10f : -1e10f;
+    if (__builtin_fabsf(dz) < smallValue) r.iz = dz >= 0 ? 1e10f : -1e10f;
+    const int dirMask = ((dx > 0) ? 1 : 0) | ((dy > 0) ? 2 : 0) | ((dz > 0) ? 4 : 0);   // S/VR:114-116
+    unsigned order = 0;                                                    // the 8 octants by (Hamming distance from dirMask, octant index), 3 bits each
+    int p = 0;
+#pragma unroll
+    for (int dist = 0; dist <= 3; dist++)
+#pragma unroll
+        for (int o = 0; o < 8; o++)
+            if (__builtin_popcount(o ^ dirMask) == dist) { order |= (unsigned)o << (3 * p); p++; }
+    r.order = order;
+    return r;
+}
+
+// returns the distance (1e30: nothing); on a hit lx, ly, lz, ls = the solid leaf's position and edge
+__device__ __forceinline__ float skip_traverse(const uint2* __restrict__ desc, const uint8_t* __restrict__ vis, bool useVis, int rootSize,
+                                               float gx, float gy, float gz, float vs, const SkipRay& r, float tMin0, float tMax0,
+                                               uint4* stk /* this lane's column: entry(L) = stk[L * 64] */, int& lx, int& ly, int& lz, int& ls) {
+    // interval of the box (bx, by, bz) of edge `size`, clipped by [pe, px]: the operations of S/VR:70-100
+    auto interval = [&](int bx, int by, int bz, int size, float pe, float px, float& enterT, float& exitT) {
+        float tNx, tFx, tNy, tFy, tNz, tFz;
+        skip_interval(gx, vs, r.ox, r.ix, bx, size, tNx, tFx);
+        skip_interval(gy, vs, r.oy, r.iy, by, size, tNy, tFy);
+        skip_interval(gz, vs, r.oz, r.iz, bz, size, tNz, tFz);
+        enterT = gmax(gmax(tNx, tNy), gmax(tNz, pe));
+        exitT = gmin(gmin(tFx, tFy), gmin(tFz, px));
+    };
+    float e, x;
+    interval(0, 0, 0, rootSize, tMin0, tMax0, e, x);
+    if ((useVis && vis[0] == 0) || e > x) return 1e30f;
+    unsigned pend = 0;                       // bit L: the entry of depth L still has untried candidates
+    int level = 0, cx = 0, cy = 0, cz = 0;   // the node being entered
+    unsigned cur = 0;
+    for (;;) {
+        {   // enter the internal node `cur` at (cx, cy, cz), depth `level`, interval [e, x]
+            const uint2 d = desc[cur];
+            const int half = rootSize >> (level + 1);
+            const unsigned sm = d.x & 0xffu, im = (d.x >> 8) & 0xffu, vm = useVis ? ((d.x >> 16) & 0xffu) : 0xffu;
+            float tN[3][2], tF[3][2];
+            skip_interval(gx, vs, r.ox, r.ix, cx, half, tN[0][0], tF[0][0]); skip_interval(gx, vs, r.ox, r.ix, cx + half, half, tN[0][1], tF[0][1]);
+            skip_interval(gy, vs, r.oy, r.iy, cy, half, tN[1][0], tF[1][0]); skip_interval(gy, vs, r.oy, r.iy, cy + half, half, tN[1][1], tF[1][1]);
+            skip_interval(gz, vs, r.oz, r.iz, cz, half, tN[2][0], tF[2][0]); skip_interval(gz, vs, r.oz, r.iz, cz + half, half, tN[2][1], tF[2][1]);
+            unsigned pass = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float ce = gmax(gmax(tN[0][k & 1], tN[1][(k >> 1) & 1]), gmax(tN[2][k >> 2], e));
+                const float cxit = gmin(gmin(tF[0][k & 1], tF[1][(k >> 1) & 1]), gmin(tF[2][k >> 2], x));
+                pass |= (ce > cxit) ? 0u : (1u << k);
+            }
+            const unsigned cand = pass & vm & (sm | im);
+            unsigned om = 0;
+#pragma unroll
+            for (int p = 0; p < 8; p++) om |= ((cand >> ((r.order >> (3 * p)) & 7u)) & 1u) << p;
+            stk[level * kWave] = make_uint4(om | (sm << 8) | (im << 16), d.y, __float_as_uint(e), __float_as_uint(x));
+            pend = (pend & ~(1u << level)) | (om ? (1u << level) : 0u);
+        }
+        if (pend == 0) return 1e30f;                                     // every branch returned 1e30
+        const int L = 31 - __builtin_clz(pend);                          // the deepest node with an untried child: where the recursion continues
+        uint4 en = stk[L * kWave];
+        const int p = __builtin_ctz(en.x & 0xffu);
+        const int k = (int)((r.order >> (3 * p)) & 7u);
+        en.x &= ~(1u << p);
+        stk[L * kWave].x = en.x;
+        if ((en.x & 0xffu) == 0) pend &= ~(1u << L);
+        const int edge = rootSize >> L, half = edge >> 1;                // the node at depth L and its children
+        const int nx = cx & ~(edge - 1), ny = cy & ~(edge - 1), nz = cz & ~(edge - 1);
+        const int bx = nx + ((k & 1) ? half : 0), by = ny + ((k & 2) ? half : 0), bz = nz + ((k & 4) ? half : 0);
+        interval(bx, by, bz, half, __uint_as_float(en.z), __uint_as_float(en.w), e, x);
+        if ((en.x >> (8 + k)) & 1u) { lx = bx; ly = by; lz = bz; ls = half; return e; }      // solid leaf: finite, every ancestor returns it (S/VR:146-149)
+        cur = en.y + (unsigned)__builtin_popcount((en.x >> 16) & 0xffu & ((1u << k) - 1u));
+        cx = bx; cy = by; cz = bz; level = L + 1;
+    }
+}
+
+// One thread per pixel (a wave = an 8x8 tile): distance of the ray of generateRay through octreeRaySkip(root, ro, rd, 0, 1e30)
+// and, optionally, the reference's shade (S/RT:283-285, 331-336) of the leaf that distance belongs to, at tHit = that distance.
+__global__ __launch_bounds__(kBlock) void k_skip_render(RenderParams P, const uint2* __restrict__ desc, const uint8_t* __restrict__ vis, int useVis,
+                                                         float4* __restrict__ outRGBA, float* __restrict__ outT) {
+    extern __shared__ uint4 lds_skip[];    // [wave][level][lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* stk = lds_skip + (size_t)wave * P.depth * kWave + lane;
+    const int tile = blockIdx.x * (kBlock / kWave) + wave;
+    const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+    const int px = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    if (!(valid && py < P.H)) return;
+    const Geo G = geo_of(P);
+    const Ray g = generate_ray_tab(P, px, py);
+    const SkipRay r = skip_ray(g.ox, g.oy, g.oz, g.dx, g.dy, g.dz);
+    int lx = 0, lyy = 0, lz = 0, ls = 0;
+    const float t = skip_traverse(desc, vis, useVis != 0, P.rootSize, G.gx, G.gy, G.gz, G.vs, r, 0.0f, 1e30f, stk, lx, lyy, lz, ls);
+    const size_t pix = (size_t)ly * P.W + px;
+    if (outT) outT[pix] = t;
+    if (outRGBA) {
+        float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+        if (t < 1e30f) {
+            const float mnx = G.gx + (float)lx * G.vs, mny = G.gy + (float)lyy * G.vs, mnz = G.gz + (float)lz * G.vs;
+            const float ext = (float)ls * G.vs;
+            const float cx = 0.5f * (mnx + (mnx + ext)), cy = 0.5f * (mny + (mny + ext)), cz = 0.5f * (mnz + (mnz + ext));
+            const float qx = (g.ox + g.dx * t) - cx, qy = (g.oy + g.dy * t) - cy, qz = (g.oz + g.dz * t) - cz;
+            const float inv = inversesqrt(qx * qx + qy * qy + qz * qz);
+            color = shade_color(gmax(0.0f, (qx * inv) * P.lightNeg[0] + (qy * inv) * P.lightNeg[1] + (qz * inv) * P.lightNeg[2]));
+        }
+        store_pixel(outRGBA + pix, color);
+    }
+}
+
+// octreeRaySkip's consumer in drawRaycast (S/VR:1602-1663) in ONE launch of one wave, nothing copied: lane i < 49 makes the
+// i-th probe direction (the reference's glm operations on inverse(P), inverse(V): both pixel independent, from the host),
+// walks the tree, the wave picks the value std::sort would leave at index int(n * 0.15f) among the valid distances by
+// ranking (no sort needed for one order statistic), x 0.75, blended 0.4 old + 0.6 new into *skip (device memory).
+struct ProbeParams { float invP[16], invV[16]; float eye[3]; float gx, gy, gz, vs; int rootSize, depth; };
+
+__global__ __launch_bounds__(kWave) void k_probe_skip(ProbeParams Q, const uint2* __restrict__ desc, const uint8_t* __restrict__ vis, int useVis,
+                                                       float* __restrict__ skip, float* __restrict__ probeT /* optional: the 49 distances */) {
+    extern __shared__ uint4 lds_skip[];
+    const int lane = threadIdx.x;
+    uint4* stk = lds_skip + lane;
+    float t = 1e30f;
+    if (lane < 49) {
+        const int gridSize = 7;
+        const float sampleOffset = 0.2f;
+        const int x = lane % gridSize, y = lane / gridSize;
+        const float ndcX = ((float)x / (float)(gridSize - 1) - 0.5f) * 2.0f * sampleOffset;
+        const float ndcY = ((float)y / (float)(gridSize - 1) - 0.5f) * 2.0f * sampleOffset;
+        const float c[4] = { ndcX, ndcY, 1.f, 1.f };
+        float vp[4], wp[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) vp[rr] = (Q.invP[rr] * c[0] + Q.invP[4 + rr] * c[1]) + (Q.invP[8 + rr] * c[2] + Q.invP[12 + rr] * c[3]);
+        const float w = vp[3];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) vp[rr] = vp[rr] / w;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) wp[rr] = (Q.invV[rr] * vp[0] + Q.invV[4 + rr] * vp[1]) + (Q.invV[8 + rr] * vp[2] + Q.invV[12 + rr] * vp[3]);
+        const float qx = wp[0] - Q.eye[0], qy = wp[1] - Q.eye[1], qz = wp[2] - Q.eye[2];
+        const float inv = inversesqrt(qx * qx + qy * qy + qz * qz);
+        const SkipRay r = skip_ray(Q.eye[0], Q.eye[1], Q.eye[2], qx * inv, qy * inv, qz * inv);
+        int a, b, cc, dd;
+        t = skip_traverse(desc, vis, useVis != 0, Q.rootSize, Q.gx, Q.gy, Q.gz, Q.vs, r, 0.0f, 1e30f, stk, a, b, cc, dd);
+        if (probeT) probeT[lane] = t;
+    }
+    const bool ok = lane < 49 && t < 1e30f && t > 0.0f;                  // S/VR:1640-1642
+    const unsigned long long okMask = __builtin_amdgcn_ballot_w64(ok);
+    const int nv = __builtin_popcountll(okMask);
+    int rank = 0;
+    for (int j = 0; j < 49; j++) {
+        const float tj = __shfl(t, j);
+        const bool okj = (okMask >> j) & 1ull;
+        rank += (okj && (tj < t || (tj == t && j < lane))) ? 1 : 0;
+    }
+    int safeIndex = (int)((float)nv * 0.15f);                            // S/VR:1650
+    if (safeIndex < 0) safeIndex = 0;
+    const unsigned long long pick = __builtin_amdgcn_ballot_w64(ok && rank == safeIndex);
+    float skipDistance = 0.0f;
+    if (nv > 0) skipDistance = __shfl(t, __builtin_ctzll(pick)) * 0.75f; // :1651-1654
+    const float blendFactor = 0.4f;                                      // :1659-1661
+    if (lane == 0) *skip = *skip * blendFactor + skipDistance * (1.0f - blendFactor);
+}
+
 // ================================================================ N4: octree construction on the GPU
 // createOctreeFromVoxelGrid + setOctree (453-skeleton/OctreeVoxel.cpp:704-778, RayTracerBVH.cpp:443-490) without
 // a pointer tree: (1) bottom-up occupancy pyramid over the voxel grid (state 0 = all EMPTY incl. the

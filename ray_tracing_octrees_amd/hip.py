@@ -33,7 +33,7 @@ SYMBOLS = (
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_debug_sort_violations", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
     "rto_comm_unique_id", "rto_comm_create", "rto_comm_create_all", "rto_comm_destroy", "rto_comm_last_error", "rto_comm_submit",
     "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_comm_debug_last_payload", "rto_render_triangles_batch_device",
-    "rto_debug_set_tile_mask", "rto_debug_tile_mask_info",
+    "rto_debug_set_tile_mask", "rto_debug_tile_mask_info", "rto_render_skip_device", "rto_render_skip_host", "rto_probe_skip_device", "rto_probe_skip_host",
     "rto_scene_bounds_get", "rto_scene_bounds_of_nodes", "rto_split_plan_make", "rto_split_part_of_rank", "rto_split_rows_of_part", "rto_split_row_source",
 )
 SPLIT_MAX_FRAMES = 32
@@ -147,6 +147,10 @@ def load():
     L.rto_render_triangles_host.argtypes = [vp, C.POINTER(Frame), C.c_int, vp, C.POINTER(Stats)]
     L.rto_octree_ray_skip.argtypes = [vp, C.POINTER(C.c_float), vp, C.c_int64, C.c_float, C.c_float, C.c_int, vp]
     L.rto_render_steps_host.argtypes = [vp, C.POINTER(Frame), vp]
+    L.rto_render_skip_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), C.c_int, vp, vp, vp]
+    L.rto_render_skip_host.argtypes = [vp, C.POINTER(Frame), C.c_int, vp, vp]
+    L.rto_probe_skip_device.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, vp, vp]
+    L.rto_probe_skip_host.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.POINTER(C.c_float), vp]
     L.rto_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.rto_debug_tile_cost.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.rto_debug_set_tile_order.argtypes = [vp, vp, C.c_int64]
@@ -430,6 +434,35 @@ class Context:
         self._check(self._L.rto_octree_ray_skip(self._h, o, rd.ctypes.data, len(rd), _f(t_min), _f(t_max),
                                                 1 if use_visibility else 0, out.ctypes.data))
         return out
+
+    def render_skip_host(self, frame: Frame, use_visibility=False, rgba=True, dist=True):
+        """Nearest-hit render mode (octreeRaySkip per pixel): (rgba (H, W, 4) or None, dist (H, W) or None)."""
+        o_rgba = np.empty((frame.height, frame.width, 4), np.float32) if rgba else None
+        o_dist = np.empty((frame.height, frame.width), np.float32) if dist else None
+        self._check(self._L.rto_render_skip_host(self._h, C.byref(frame), 1 if use_visibility else 0,
+                                                 o_rgba.ctypes.data if rgba else None, o_dist.ctypes.data if dist else None))
+        return o_rgba, o_dist
+
+    def render_skip_device(self, frame: Frame, d_rgba: int, d_dist: int, use_visibility=False, part: Partition | None = None, stream: int = 0):
+        self._check(self._L.rto_render_skip_device(self._h, C.byref(frame), C.byref(part) if part else None, 1 if use_visibility else 0,
+                                                   C.c_void_p(d_rgba) if d_rgba else None, C.c_void_p(d_dist) if d_dist else None,
+                                                   C.c_void_p(stream) if stream else None))
+
+    def probe_skip_host(self, view, cam_pos, aspect, last=0.0, use_visibility=False, with_probes=False):
+        """octreeSkipT as drawRaycast computes it, one launch: returns the new value (and the 49 probe distances)."""
+        v = np.ascontiguousarray(np.asarray(view, dtype=np.float32).reshape(16))
+        p = np.ascontiguousarray(np.asarray(cam_pos, dtype=np.float32).reshape(3))
+        io = C.c_float(_f(last))
+        probes = np.zeros(49, np.float32) if with_probes else None
+        self._check(self._L.rto_probe_skip_host(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), p.ctypes.data_as(C.POINTER(C.c_float)), _f(aspect),
+                                                1 if use_visibility else 0, C.byref(io), probes.ctypes.data if with_probes else None))
+        return (np.float32(io.value), probes) if with_probes else np.float32(io.value)
+
+    def probe_skip_device(self, view, cam_pos, aspect, d_skip: int, use_visibility=False, stream: int = 0):
+        v = np.ascontiguousarray(np.asarray(view, dtype=np.float32).reshape(16))
+        p = np.ascontiguousarray(np.asarray(cam_pos, dtype=np.float32).reshape(3))
+        self._check(self._L.rto_probe_skip_device(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), p.ctypes.data_as(C.POINTER(C.c_float)), _f(aspect),
+                                                  1 if use_visibility else 0, C.c_void_p(d_skip), C.c_void_p(stream) if stream else None))
 
     def frame_stats(self, frame: Frame) -> dict:
         s = Stats()

@@ -95,6 +95,33 @@ def main():
             out[key + "_rd"] = rds
             out[key + "_t"] = np.array([0.0, 1e30], np.float32)
             out[key + "_out"] = orc.ref_octree_ray_skip(g, eye, rds, 0.0, 1e30, visible=flags)
+        # (7) the nearest-hit RENDER MODE: every pixel of a 96 x 64 frame.  Directions: generateRay (the GLSL of
+        #     S/RayTracerBVH.cpp:338-355 cannot run here: the oracle's restatement makes them); distances: the reference's compiled
+        #     octreeRaySkip for exactly those directions, without and with a visibility map.
+        PW, PH = 96, 64
+        cams = [(theta, phi, radius)] + ([(1.3, 0.2, 0.55)] if name == "sphere32" else [])        # sphere32: also an eye inside the shell's hollow
+        for ci, (t_, p_, r_) in enumerate(cams):
+            v_, e_, _ = orc.ref_camera(t_, p_, r_)
+            rd_px = orc.generate_rays(v_, e_, PW / PH, 45.0, PW, PH).reshape(-1, 3)
+            key = f"{name}_pixels{ci}"
+            out[key + "_cam"] = np.array([t_, p_, r_], np.float32)
+            out[key + "_out"] = orc.ref_octree_ray_skip(g, e_, rd_px, 0.0, 1e30)
+            flags = np.unpackbits(out[f"{name}_vis1_flags"])[: len(nodes)]
+            out[key + "_vis_out"] = orc.ref_octree_ray_skip(g, e_, rd_px, 0.0, 1e30, visible=flags)
+        # (8) octreeRaySkip's consumer (S/VR:1640-1663) on the probe distances of (1): valid = (t < 1e30 && t > 0), sorted,
+        #     index int(n * 0.15f), x 0.75f, blended 0.4 old + 0.6 new -- three consecutive frames starting from 0
+        F = np.float32
+        seq, last = [], F(0.0)
+        for flags_key in (None, f"{name}_vis0_flags"):
+            t_probe = out[f"{name}_probe_out"] if flags_key is None else out[f"{name}_vis0_out"][:49]
+            for _ in range(3):
+                valid = np.sort(t_probe[(t_probe < F(1e30)) & (t_probe > F(0.0))])
+                skip = F(0.0)
+                if len(valid):
+                    skip = F(valid[max(0, int(F(len(valid)) * F(0.15)))] * F(0.75))
+                last = F(F(last * F(0.4)) + F(skip * F(F(1.0) - F(0.4))))
+                seq.append(last)
+        out[f"{name}_probe_skip_seq"] = np.array(seq, np.float32)      # 3 updates without, then 3 with the visibility map vis0
         hits = {k: int((v < 1e30).sum()) for k, v in out.items() if k.startswith(name) and k.endswith("_out")}
         print(name, len(nodes), "nodes; finite results:", hits)
     np.savez_compressed(os.path.join(HERE, "ref_ray_skip.npz"), **out)

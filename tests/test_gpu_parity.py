@@ -1193,6 +1193,102 @@ def test_octree_ray_skip_matches_oracle(ctx, orc, scenes, camera):
     ctx.update_frustum(view, 45.0, 16 / 9, enable=False)
 
 
+@pytest.mark.parametrize("scene", ["sphere32", "odd", "calgary"])
+def test_nearest_hit_render_mode_equals_the_reference_vectors(ctx, orc, scenes, golden, scene):
+    """N1 as a render mode (rto_render_skip_*): every pixel's distance is the one the reference's COMPILED octreeRaySkip returned
+    for that pixel's ray (tests/golden/ref_ray_skip.npz "pixels": 96 x 64, from outside and -- sphere32 -- from inside the shell's
+    hollow); colours and the visibility-map variant (flags of a real frustum update) equal the oracle's, which the same vectors pin
+    with random flags; a partition renders its rows; the outputs may stay on the device."""
+    torch = pytest.importorskip("torch")
+    z = golden("ref_ray_skip.npz")
+    s = scenes(scene)
+    upload(ctx, s)
+    W, H = 96, 64
+    ncam = 2 if scene == "sphere32" else 1
+    for ci in range(ncam):
+        t, p, r = [float(x) for x in z[f"{scene}_pixels{ci}_cam"]]
+        cam = orc.Camera(t, p, r)
+        view, pos = cam.get_view(), cam.get_pos()
+        f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+        rgba, dist = ctx.render_skip_host(f)
+        want = z[f"{scene}_pixels{ci}_out"].reshape(H, W)
+        assert dist.tobytes() == want.tobytes(), f"{scene} camera {ci}: {int((dist.view(np.uint32) != want.view(np.uint32)).sum())} distances differ from the reference's"
+        orgba, odist = orc.render_skip(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H)
+        assert_bit_exact(rgba, orgba, f"{scene} camera {ci}: nearest-hit colours")
+        # device-resident outputs, one part of three
+        part = hip.Partition(3, 2, 8)
+        rows = partition_row_map(H, 3, 2, 8)
+        d_rgba = torch.full((len(rows), W, 4), 7.0, dtype=torch.float32, device="cuda")
+        d_dist = torch.full((len(rows), W), 7.0, dtype=torch.float32, device="cuda")
+        ctx.render_skip_device(f, d_rgba.data_ptr(), d_dist.data_ptr(), False, part)
+        ctx.synchronize()
+        assert d_dist.cpu().numpy().tobytes() == want[rows].tobytes() and d_rgba.cpu().numpy().tobytes() == orgba[rows].tobytes()
+        # a frustum update's flags as the visibility map (S/VR:64-67)
+        aspect = float(np.float32(16 / 9))
+        ctx.update_frustum(view, 45.0, aspect, enable=True)
+        _, vis = orc.cull_compact(s.nodes, s.min, s.voxel, view, 45.0, aspect)
+        vrgba, vdist = ctx.render_skip_host(f, use_visibility=True)
+        worgba, wodist = orc.render_skip(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H, visible=vis)
+        assert vdist.tobytes() == wodist.tobytes() and vrgba.tobytes() == worgba.tobytes(), f"{scene} camera {ci}: with the visibility map"
+        ctx.update_frustum(view, 45.0, aspect, enable=False)
+
+
+def test_nearest_hit_render_mode_at_config2_size(ctx, orc, scenes, camera):
+    """The same at BASELINE config 2's size (256^3 sphere, 1920x1080) against the oracle; where both modes hit, the nearest-hit
+    distance never exceeds the distance of the reference's first-in-DFS-order hit (the reason SURVEY.md section 8f wants the mode)."""
+    s = scenes("sphere256")
+    view, pos = camera("sphere")
+    upload(ctx, s)
+    W, H = 1920, 1080
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    rgba, dist = ctx.render_skip_host(f)
+    orgba, odist = orc.render_skip(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H, nthreads=min(16, orc.max_threads()))
+    assert dist.tobytes() == odist.tobytes()
+    assert_bit_exact(rgba, orgba, "nearest-hit frame, config 2 size")
+    dfs, _ = oracle_frame(orc, s, view, pos, W, H)
+    hit_dfs, hit_near = dfs[..., 0] != 0, dist < 1e30
+    assert hit_near.sum() >= hit_dfs.sum() > 100000                # the DFS mode loses rays to its 512-pop cap; this mode has none
+
+
+@pytest.mark.parametrize("scene,cam", [("sphere32", (0.5, 0.7, 1.8)), ("odd", (0.4, 0.9, 9.0)), ("calgary", (0.6, 0.5, 3500.0))])
+def test_probe_consumer_in_one_launch_equals_the_reference(ctx, orc, scenes, golden, scene, cam):
+    """octreeRaySkip's consumer (S/VolumeRaycastRenderer.cpp:1602-1663) in ONE launch: the 49 probe distances are the compiled
+    reference's, and three consecutive updates give the sequence computed from them (15th percentile x 0.75, blend 0.4 / 0.6);
+    with a frustum update's flags as the visibility map the value follows the oracle; the device form keeps the float on the GPU."""
+    torch = pytest.importorskip("torch")
+    z = golden("ref_ray_skip.npz")
+    s = scenes(scene)
+    upload(ctx, s)
+    c = orc.Camera(*cam)
+    view, eye = c.get_view(), c.get_pos()
+    aspect = float(np.float32(1920 / 1080))
+    want = z[f"{scene}_probe_skip_seq"][:3]
+    last, got = np.float32(0.0), []
+    for k in range(3):
+        last, probes = ctx.probe_skip_host(view, eye, aspect, last, with_probes=True)
+        got.append(last)
+        assert probes.tobytes() == z[f"{scene}_probe_out"].tobytes(), "the 49 probe distances"
+    assert np.array(got, np.float32).tobytes() == want.tobytes(), (got, want)
+    d_skip = torch.zeros(1, dtype=torch.float32, device="cuda")     # the caller's lastSkipDistance lives on the device
+    for k in range(3):
+        ctx.probe_skip_device(view, eye, aspect, d_skip.data_ptr())
+    ctx.synchronize()
+    assert d_skip.cpu().numpy().tobytes() == want[2:3].tobytes()
+    ctx.update_frustum(view, 45.0, aspect, enable=True)
+    _, vis = orc.cull_compact(s.nodes, s.min, s.voxel, view, 45.0, aspect)
+    a = ctx.probe_skip_host(view, eye, aspect, float(want[2]), use_visibility=True)
+    b = orc.probe_skip_distance(s.nodes, s.min, s.voxel, view, eye, aspect, float(want[2]), visible=vis)
+    assert np.float32(a).tobytes() == np.float32(b).tobytes()
+    ctx.update_frustum(view, 45.0, aspect, enable=False)
+    import time
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        ctx.probe_skip_device(view, eye, aspect, d_skip.data_ptr())
+    ctx.synchronize()
+    print(f"probe update, {scene}: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per call (200 back-to-back device calls, no copies)")
+
+
 @pytest.fixture(params=["morton", "level_by_level"])
 def build_path(request, ctx):
     """rto_build_octree's two forms (seven launches with Morton-ordered pyramid levels / level by level): same arrays."""

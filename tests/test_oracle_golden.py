@@ -210,6 +210,60 @@ def test_octree_ray_skip_equals_the_reference(orc, scenes, golden, scene):
     assert finite > 100
 
 
+PIXEL_CAMS = {"sphere32": 2, "odd": 1, "calgary": 1}
+
+
+@pytest.mark.parametrize("scene", ["sphere32", "odd", "calgary"])
+def test_nearest_hit_render_mode_equals_the_reference_distances(orc, scenes, golden, scene):
+    """N1 as a render mode: for every pixel of a 96 x 64 frame, the reference's compiled octreeRaySkip was run on the ray of
+    generateRay (tests/golden/ref_ray_skip.npz "pixels": make_golden_ray_skip.py); the oracle's render_skip must return those
+    distances bit for bit -- without and with a visibility map, from outside and (sphere32) from inside the shell's hollow --
+    and its colours are the reference's shade applied at exactly those hits."""
+    z = golden("ref_ray_skip.npz")
+    s = scenes(scene)
+    W, H = 96, 64
+    flags = np.unpackbits(z[f"{scene}_vis1_flags"])[: len(s.nodes)]
+    for ci in range(PIXEL_CAMS[scene]):
+        t, p, r = [float(x) for x in z[f"{scene}_pixels{ci}_cam"]]
+        cam = orc.Camera(t, p, r)
+        view, pos = cam.get_view(), cam.get_pos()
+        for vis, key in ((None, "_out"), (flags, "_vis_out")):
+            rgba, dist = orc.render_skip(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H, visible=vis)
+            want = z[f"{scene}_pixels{ci}{key}"].reshape(H, W)
+            assert dist.tobytes() == want.tobytes(), f"{scene} camera {ci} {key}: {int((dist.view(np.uint32) != want.view(np.uint32)).sum())} distances differ"
+            hit = want < 1e30
+            assert ((rgba[..., :3] == 0).all(axis=-1) == ~hit).all() and (rgba[..., 3] == 1).all()
+            assert (rgba[hit][:, 0] >= np.float32(0.1)).all() and (rgba[hit][:, 0] <= np.float32(1.1)).all()
+        # the same rays one by one: the render mode is octreeRaySkip on generateRay's directions, nothing else
+        rd = orc.generate_rays(view, pos, W / H, 45.0, W, H).reshape(-1, 3)
+        some = np.arange(0, W * H, 97)
+        one = orc.octree_ray_skip_many(s.nodes, s.min, s.voxel, pos, rd[some])
+        assert one.tobytes() == z[f"{scene}_pixels{ci}_out"][some].tobytes()
+
+
+@pytest.mark.parametrize("scene,cam", [("sphere32", (0.5, 0.7, 1.8)), ("odd", (0.4, 0.9, 9.0)), ("calgary", (0.6, 0.5, 3500.0))])
+def test_probe_consumer_equals_the_reference(orc, scenes, golden, scene, cam):
+    """octreeRaySkip's consumer in drawRaycast (S/VolumeRaycastRenderer.cpp:1602-1663): the oracle's 7 x 7 probe directions are
+    the ones the reference's own glm calls produce (compiled: refvr_probe_rays), and its skip distance -- 15th percentile of the
+    valid distances x 0.75, blended 0.4 old + 0.6 new -- follows, over three consecutive frames without and three with a
+    visibility map, the sequence computed from the compiled function's distances."""
+    z = golden("ref_ray_skip.npz")
+    s = scenes(scene)
+    c = orc.Camera(*cam)
+    view, eye = c.get_view(), c.get_pos()
+    aspect = float(np.float32(1920 / 1080))
+    assert orc.probe_rays(view, eye, aspect).tobytes() == z[f"{scene}_probe_rd"].tobytes(), "probe directions"
+    want = z[f"{scene}_probe_skip_seq"]
+    flags = np.unpackbits(z[f"{scene}_vis0_flags"])[: len(s.nodes)]
+    last, got = np.float32(0.0), []
+    for k in range(6):
+        last = orc.probe_skip_distance(s.nodes, s.min, s.voxel, view, eye, aspect, last, visible=None if k < 3 else flags)
+        got.append(last)
+    assert np.array(got, np.float32).tobytes() == want.tobytes(), (got, want)
+    if scene != "odd":
+        assert want[2] > 0 and abs(want[2] - want[1]) < abs(want[1] - want[0])        # converging towards 0.75 x the percentile
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/453-skeleton"), reason="reference checkout not present")
 def test_octree_ray_skip_against_live_reference_random_grids(orc):
     """Where the reference sources exist: the oracle against the compiled octreeRaySkip itself, on random grids and rays."""
