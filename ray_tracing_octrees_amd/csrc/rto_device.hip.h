@@ -977,13 +977,17 @@ __device__ __forceinline__ void child_axis_terms(float g, float o, float inv, un
     n1 = __uint_as_float(bop3<kSelC>(a1y, a2y, sgn)); f1 = __uint_as_float(bop3<kSelC>(a2y, a1y, sgn));
 }
 
+// clampLo / clampHi (FOLD only): what the entry / exit parameters are clipped with before they are compared.  Defaults: the
+// smallest positive float and the largest float below 1e30 (S/RT:235, :273); the octreeRaySkip traversal passes its parent
+// interval [enterT, exitT] instead (S/VR:97-100: a child passes when max(tNear, enterT) <= min(tFar, exitT)).
 template <bool FOLD = true, bool BIASED = false>
 __device__ __forceinline__ unsigned child_fail_mask_fast(float gx, float gy, float gz, float vs, float ox, float oy, float oz,
                                                          float ix, float iy, float iz, unsigned sx, unsigned sy, unsigned sz,
-                                                         int cx, int cy, int cz, float fh) {
+                                                         int cx, int cy, int cz, float fh,
+                                                         float clampLo = __uint_as_float(1u), float clampHi = __uint_as_float(0x7149f2c9u)) {
     const float sv = fh * vs;                                  // vec3(node.size) * voxelSize
-    const float kEps = __uint_as_float(1u);                   // smallest positive float: tFar > 0  <=>  tFar >= kEps
-    const float kBelow1e30 = __uint_as_float(0x7149f2c9u);    // largest float < 1e30f:  tNear < 1e30 <=> tNear <= this
+    const float kEps = clampLo;                               // default: smallest positive float: tFar > 0  <=>  tFar >= kEps
+    const float kBelow1e30 = clampHi;                         // default: largest float < 1e30f:  tNear < 1e30 <=> tNear <= this
     float nx0, nx1, fx0, fx1, ny0, ny1, fy0, fy1, nz0, nz1, fz0, fz1;
     child_axis_terms<BIASED>(gx, ox, ix, sx, cx, fh, vs, sv, nx0, nx1, fx0, fx1);
     child_axis_terms<BIASED>(gy, oy, iy, sy, cy, fh, vs, sv, ny0, ny1, fy0, fy1);
@@ -2353,7 +2357,7 @@ __global__ __launch_bounds__(kBlock) void k_octree_ray_skip_packed(const uint2* 
 // Entry of the node at depth L (children of edge rootSize >> (L + 1)):
 //   .x = untried candidates in TRAVERSAL order (8) | solid mask << 8 | internal mask << 16    .y = first internal child
 //   .z / .w = the node's clipped interval [enterT, exitT]
-struct SkipRay { float ox, oy, oz, ix, iy, iz; unsigned order; };
+struct SkipRay { float ox, oy, oz, ix, iy, iz; unsigned order; unsigned sx, sy, sz; bool finite; };
 
 __device__ __forceinline__ SkipRay skip_ray(float ox, float oy, float oz, float dx, float dy, float dz) {
     SkipRay r;
@@ -2372,6 +2376,8 @@ __device__ __forceinline__ SkipRay skip_ray(float ox, float oy, float oz, float 
         for (int o = 0; o < 8; o++)
             if (__builtin_popcount(o ^ dirMask) == dist) { order |= (unsigned)o << (3 * p); p++; }
     r.order = order;
+    r.sx = (unsigned)((int)__float_as_uint(r.ix) >> 31); r.sy = (unsigned)((int)__float_as_uint(r.iy) >> 31); r.sz = (unsigned)((int)__float_as_uint(r.iz) >> 31);
+    r.finite = __builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) && __builtin_isfinite(ox) && __builtin_isfinite(oy) && __builtin_isfinite(oz);
     return r;
 }
 
@@ -2390,6 +2396,8 @@ __device__ __forceinline__ float skip_traverse(const uint2* __restrict__ desc, c
     };
     float e, x;
     interval(0, 0, 0, rootSize, tMin0, tMax0, e, x);
+    // wave-uniform: every ray of the wave is finite (then no NaN / inf - inf can arise in the children's verdicts)
+    const bool allFinite = __builtin_amdgcn_ballot_w64(!(r.finite && __builtin_isfinite(e) && __builtin_isfinite(x) && __builtin_fabsf(e) < 1e30f)) == 0ull;
     if ((useVis && vis[0] == 0) || e > x) return 1e30f;
     unsigned pend = 0;                       // bit L: the entry of depth L still has untried candidates
     int level = 0, cx = 0, cy = 0, cz = 0;   // the node being entered
@@ -2399,16 +2407,24 @@ __device__ __forceinline__ float skip_traverse(const uint2* __restrict__ desc, c
             const uint2 d = desc[cur];
             const int half = rootSize >> (level + 1);
             const unsigned sm = d.x & 0xffu, im = (d.x >> 8) & 0xffu, vm = useVis ? ((d.x >> 16) & 0xffu) : 0xffu;
-            float tN[3][2], tF[3][2];
-            skip_interval(gx, vs, r.ox, r.ix, cx, half, tN[0][0], tF[0][0]); skip_interval(gx, vs, r.ox, r.ix, cx + half, half, tN[0][1], tF[0][1]);
-            skip_interval(gy, vs, r.oy, r.iy, cy, half, tN[1][0], tF[1][0]); skip_interval(gy, vs, r.oy, r.iy, cy + half, half, tN[1][1], tF[1][1]);
-            skip_interval(gz, vs, r.oz, r.iz, cz, half, tN[2][0], tF[2][0]); skip_interval(gz, vs, r.oz, r.iz, cz + half, half, tN[2][1], tF[2][1]);
             unsigned pass = 0;
+            if (allFinite) {
+                // which children have a non-empty interval: the arithmetic of the lean kernel's child test (same box expressions as
+                // S/VR:70-97; min / max per axis selected by the sign of the reciprocal; v_min3 / v_max3), the parent's interval
+                // folded in.  Only the VERDICTS are taken from here -- they do not depend on the sign of a zero; the distance that
+                // is returned is recomputed for the one child that is entered with the reference's own min / max below.
+                pass = ~child_fail_mask_fast<true, false>(gx, gy, gz, vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.sx, r.sy, r.sz, cx, cy, cz, (float)half, e, x) & 0xffu;
+            } else {
+                float tN[3][2], tF[3][2];
+                skip_interval(gx, vs, r.ox, r.ix, cx, half, tN[0][0], tF[0][0]); skip_interval(gx, vs, r.ox, r.ix, cx + half, half, tN[0][1], tF[0][1]);
+                skip_interval(gy, vs, r.oy, r.iy, cy, half, tN[1][0], tF[1][0]); skip_interval(gy, vs, r.oy, r.iy, cy + half, half, tN[1][1], tF[1][1]);
+                skip_interval(gz, vs, r.oz, r.iz, cz, half, tN[2][0], tF[2][0]); skip_interval(gz, vs, r.oz, r.iz, cz + half, half, tN[2][1], tF[2][1]);
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const float ce = gmax(gmax(tN[0][k & 1], tN[1][(k >> 1) & 1]), gmax(tN[2][k >> 2], e));
-                const float cxit = gmin(gmin(tF[0][k & 1], tF[1][(k >> 1) & 1]), gmin(tF[2][k >> 2], x));
-                pass |= (ce > cxit) ? 0u : (1u << k);
+                for (int k = 0; k < 8; k++) {
+                    const float ce = gmax(gmax(tN[0][k & 1], tN[1][(k >> 1) & 1]), gmax(tN[2][k >> 2], e));
+                    const float cxit = gmin(gmin(tF[0][k & 1], tF[1][(k >> 1) & 1]), gmin(tF[2][k >> 2], x));
+                    pass |= (ce > cxit) ? 0u : (1u << k);
+                }
             }
             const unsigned cand = pass & vm & (sm | im);
             unsigned om = 0;
