@@ -515,6 +515,8 @@ def main(argv=None):
                 "kernel_ms_avg": round(k_avg, 5), "kernel_ms_median": round(k_med, 5), "kernel_ms_min": round(k_min, 5), "kernel_launches_timed": n_k,
                 "kernel_ms_how": f"HIP event pair around each of {n_k} launches of the timed workload (plain launches, right after the timed region), on the launch stream",
                 "timed_region_gpu_ms_per_frame": round(region_ms, 5),
+                "median_frame": {"ms": round(k_med, 5), "Mrays_per_s": round(rays / k_med / 1e3, 1),
+                                 "what": "median of the per-launch kernel times (SURVEY 8d asks for a median; `value` is the mean over the timed region)"},
                 "event_pair_overhead_ms": round(pair_overhead, 5),
                 "hbm_algorithmic": {
                     "achieved": round(hbm_alg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "ratio": round(hbm_alg / HBM_PEAK_GBS, 4),

@@ -5,7 +5,8 @@
 set -eu
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 W=$(mktemp -d)
-cp -r "$ROOT" "$W/repo"
+mkdir "$W/repo"
+tar -C "$ROOT" --exclude=./gpurun_out --exclude=./.git --exclude=./build -cf - . | tar -C "$W/repo" -xf -
 cd "$W/repo"
 SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -fPIC -shared"
 g++ $SAN -std=c++17 -I include ray_tracing_octrees_amd/host/*.cpp -o ray_tracing_octrees_amd/librto_host.so -ldl
@@ -15,4 +16,9 @@ LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.s
   python -m pytest tests/test_oracle_golden.py tests/test_abi_and_host.py -q -p no:cacheprovider > "$W/log" 2>&1 || true
 tail -3 "$W/log"
 echo "UBSan reports: $(grep -c 'runtime error' "$W/log" || true)"
+echo "ASan reports: $(grep -c 'ERROR: AddressSanitizer' "$W/log" || true)"
+if [ -n "${1:-}" ]; then                      # keep the log (e.g. profiles/r03_sanitize_cpu.log)
+  { echo "# tools/sanitize_cpu.sh: C++ host layer + C oracle under -fsanitize=address,undefined; $(date -u +%F) commit $(git -C "$ROOT" rev-parse --short HEAD)"; tail -5 "$W/log";
+    echo "UBSan reports: $(grep -c 'runtime error' "$W/log" || true)"; echo "ASan reports: $(grep -c 'ERROR: AddressSanitizer' "$W/log" || true)"; } > "$ROOT/$1"
+fi
 rm -rf "$W"
