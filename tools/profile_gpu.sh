@@ -7,9 +7,9 @@
 # (tools/summarize_profile.py) and the bench line of pass 1 (bench.json).  Copy what should be judged into
 # profiles/ and merge the counters with tools/pmc_entry.py.
 set -u
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 CONFIG=${1:-2}; shift || true
-ARGS="--config $CONFIG --cpu-frames 0 --no-verify --orbit-frames 0 $*"
+ARGS="--config $CONFIG --cpu-frames 0 --no-verify --orbit-frames 0 --dropin-frames 0 $*"
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
