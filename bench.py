@@ -11,8 +11,8 @@ Workload : --config 2 (default) BASELINE config 2 -- 256^3 shell-sphere voxel gr
            --config 5           512^3 sphere, 3840x2160, Marching-Cubes leaf triangles + 1 shadow ray per hit.
 Step     : one frame = one pass of the hot path over W x H primary rays, octree and framebuffer resident in HBM.
 N = 1    : `value` is ONE KERNEL LAUNCH PER FRAME (rto_render_device: what the reference's renderSceneCompute does per
-           call), one frame strictly after the other on one stream; the K timed launches are replayed from a HIP graph
-           captured before the timed region (--graph-frames 0: plain stream launches).  Secondary figures in the same
+           call), one frame strictly after the other on one stream, K plain stream launches without per-launch events
+           (--graph-frames n: replayed from a HIP graph of n frames captured before the timed region).  Secondary figures in the same
            line, all outside the timed region: `frames_per_launch` (several frames per kernel launch, identical and
            distinct cameras -- the throughput form for callers that know the next cameras), `dropin_call` (the C++ class
            exactly as main.cpp:1357-1363 calls it: renderSceneComputeWithCulling with a frustum update every frame),
@@ -83,7 +83,7 @@ def parse_args(argv=None):
                     help="N>1: consecutive frames whose parts travel in ONE gather (fewer, larger collectives); 1 = one gather per frame")
     ap.add_argument("--graph-frames", type=int, default=None,
                     help="N=1: capture this many consecutive single-frame launches in a HIP graph (before the timed region) and replay it; "
-                         "0 = plain stream launches.  Default: min(steps, 48)")
+                         "0 (default) = plain stream launches without per-launch events")
     ap.add_argument("--ramp-ms", type=float, default=300.0,
                     help="N=1: untimed frames of the same workload rendered for this long before the W warm-up frames, so that a cold "
                          "GPU has reached its working clock (disclosed in the line as `clock_ramp`); 0 = none")
@@ -265,7 +265,7 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
     if args.graph_frames is None:
-        args.graph_frames = min(args.steps, 48)
+        args.graph_frames = 0          # plain launches without per-launch events beat the graph replay at every K (tools/steps_sweep.sh: K = 20: 0.0405 vs 0.0435 ms)
     if args.rehearse_world > 1:
         args.no_verify, args.cpu_frames, args.force_comm = True, 0, True     # the assembled frames hold one rank's bands only
     world_env = os.environ.get("WORLD_SIZE")
