@@ -765,6 +765,17 @@ int rto_debug_tile_mask_info(const rto_context* c, int* level, int* num_cells) {
     return RTO_OK;
 }
 
+// Developer aid (not in rto_hip.h): the three 64-bit frame counters as they stand; zero != 0 clears them first.  Used by
+// tools/tri_profile.py with an A/B build (-DRTO_TRI_PROFILE) whose colour frames count their loop trips there.
+int rto_debug_counters(rto_context* c, unsigned long long out[3], int zero) {
+    if (!c || !out) return RTO_E_INVALID;
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipDeviceSynchronize());
+    if (zero) RTO_HIP(c, hipMemset(c->d_counters, 0, sizeof(Counters)));
+    RTO_HIP(c, hipMemcpy(out, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost));
+    return RTO_OK;
+}
+
 int rto_debug_sort_violations(rto_context* c, int* count) {
     if (!c || !count) return RTO_E_INVALID;
     RTO_HIP(c, hipSetDevice(c->device));

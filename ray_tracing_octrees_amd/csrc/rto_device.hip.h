@@ -1982,6 +1982,9 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     float ndotl = 0.0f;
     const char* recBytes = reinterpret_cast<const char*>(Sc.rec);
     int trips = 0, rounds = 0;
+#if defined(RTO_TRI_PROFILE)       // A/B build (tools/tri_profile.py): where a frame's instructions go
+    unsigned long long profLaneTrips = 0, profChunks = 0, profPairs = 0, profWaveTrips = 0;
+#endif
 
     for (;;) {
         // node loop: until nobody walks, or RTO_TRI_BATCH lanes wait with a leaf (the tests cost by the pair, so a round
@@ -1990,6 +1993,10 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
         while (__builtin_amdgcn_ballot_w64(alive) != 0ull && __builtin_popcountll(__builtin_amdgcn_ballot_w64(haveLeaf)) < RTO_TRI_BATCH)
         if (alive) {
             trips++;
+#if defined(RTO_TRI_PROFILE)
+            { const unsigned long long act = (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));     // lanes walking in this trip
+              profLaneTrips += __builtin_amdgcn_readfirstlane((int)act); profWaveTrips += 1; }
+#endif
             const uint2 d = *reinterpret_cast<const uint2*>(recBytes + (cur << 3));
             const int Lb = __builtin_ctz(lvlPending | sentinel);
             const uint2 e = stk[Lb * kWave];
@@ -2059,6 +2066,9 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
             keys[lane] = ~0ull;
             __builtin_amdgcn_wave_barrier();
             for (int w0 = 0; w0 < total; w0 += kWave) {
+#if defined(RTO_TRI_PROFILE)
+                profChunks++; profPairs += (unsigned long long)min(kWave, total - w0);
+#endif
                 const int w = w0 + lane;
                 int owner = 0;                                      // lanes whose inclusive prefix is <= w
 #pragma unroll
@@ -2135,6 +2145,18 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
         }
         if (__builtin_amdgcn_ballot_w64(alive || haveLeaf) == 0ull) break;
     }
+#if defined(RTO_TRI_PROFILE)
+    if (counters && MODE == kModeColor) {
+        // profLaneTrips / profWaveTrips live in the lanes that walked; take the wave maximum (every walking lane saw the same counts while it walked)
+        unsigned long long lt = profLaneTrips, wt = profWaveTrips;
+        for (int off = 32; off > 0; off >>= 1) { lt = max(lt, (unsigned long long)__shfl_xor((long long)lt, off)); wt = max(wt, (unsigned long long)__shfl_xor((long long)wt, off)); }
+        if (lane == 0) {
+            atomicAdd(&counters->pops, (wt << 32) | (unsigned long long)rounds);                           // (longest lane's) trips | rounds
+            atomicAdd(&counters->hits, lt);                                                                // lanes walking beside the longest lane, summed over its trips
+            atomicAdd(&counters->capped, (profChunks << 32) | profPairs);                                  // triangle chunks | pairs
+        }
+    }
+#endif
     if (P.tileCost) {
         int cost = trips + 4 * rounds;                                    // of the lane that walked longest
         for (int off = 32; off > 0; off >>= 1) cost = max(cost, __shfl_xor(cost, off));
