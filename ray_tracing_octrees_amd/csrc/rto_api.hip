@@ -1310,13 +1310,14 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     return RTO_OK;
 }
 
-// Resident waves per SIMD of a lean octree launch, set through its dynamic LDS request (160 KB of LDS per CU, 4-wave workgroups:
-// workgroups per CU == waves per SIMD).  With the occupancy mask a frame has fewer waves with work than the machine has wave
-// slots at 6 per SIMD (config 2: ~5,800 against 6,144): all of them would be resident from the first microsecond, statically
-// spread, and the frame would end when the unluckiest SIMD ends (timeline: SIMD totals of 91 +- 30 loop trips).  At 5 per SIMD
-// the last sixth of the waves is handed out as slots free up -- to whichever SIMD is done first: config 2, one frame per
-// launch: 44.9 -> 38.9 us (4 and 5 per SIMD alike; 2-3: 46.7).  Launches of several frames have waves to spare and keep 6.
-// RTO_WAVES_PER_SIMD=<n> overrides (A/B runs); 0 = never pad.
+// Resident waves per SIMD of a lean octree launch, set through its dynamic LDS request (4-wave workgroups: workgroups per CU ==
+// waves per SIMD).  With the occupancy mask a frame has fewer waves with work than the machine has wave slots at 6 per SIMD
+// (config 2: ~5,800 against 6,144): all of them would be resident from the first microsecond, statically spread, and the
+// frame would end when the unluckiest SIMD ends (timeline: SIMD totals of 91 +- 30 loop trips, last SIMD at 42 us, mean 29).
+// At 4 per SIMD the last third of the waves is handed out as slots free up -- to whichever SIMD is done first: config 2, one
+// frame per launch: 44.9 -> 38.9 us.  (Measured: a request of 32 KB and one of 40 KB give the same occupancy and time -- the
+// CU hands its LDS out in two halves --, 53 KB gives 2 per SIMD: 46.7 us.)  Launches of several frames have waves to spare and
+// keep 6.  RTO_WAVES_PER_SIMD=<n> overrides (A/B runs); 0 = never pad.
 static size_t lds_for_occupancy(size_t lds, int wavesDefault) {
     static const int forced = []() { const char* e = std::getenv("RTO_WAVES_PER_SIMD"); return e ? std::atoi(e) : -1; }();
     const int waves = forced >= 0 ? forced : wavesDefault;
@@ -1369,7 +1370,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 if (rc != RTO_OK) return rc;
             }
             const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
-            const size_t lds = Q.tileMask ? lds_for_occupancy(ldsStacks, 5) : lds_for_occupancy(ldsStacks, 0);
+            const size_t lds = Q.tileMask ? lds_for_occupancy(ldsStacks, 4) : lds_for_occupancy(ldsStacks, 0);
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
             startRecorded = true;
             const bool persistent = c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT && st && frameMode;
