@@ -256,6 +256,11 @@ def pmc_entry(config: str, kernel_name: str, order: str, fpl: int):
     return None
 
 
+def _trace(msg):
+    if os.environ.get('RTO_BENCH_TRACE'):
+        print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+
 def median(xs):
     xs = sorted(xs)
     return xs[len(xs) // 2] if xs else None
@@ -323,7 +328,18 @@ def main(argv=None):
         ids = [_hip.comm_unique_id() if rank == 0 else None]
         if dist is not None:
             dist.broadcast_object_list(ids, src=0)
-        comm = _hip.Comm(ctx, world, rank, ids[0], band_rows=args.band_rows)
+        # RCCL prints a version banner to STDOUT when its first communicator is made: this process's stdout carries ONE JSON line, so
+        # file descriptor 1 points at stderr while the communicator is created (C stdio flushed before it is restored)
+        import ctypes
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            comm = _hip.Comm(ctx, world, rank, ids[0], band_rows=args.band_rows)
+        finally:
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         if args.rehearse_world > 1:
             if world != 1:
                 raise SystemExit("--rehearse-world needs --gpus 1 --force-comm")
@@ -448,6 +464,7 @@ def main(argv=None):
         elapsed = max_over_ranks(elapsed)
 
     # ---- everything below is outside the timed region ---------------------------------------------
+    _trace(f'timed region done: {elapsed:.6f} s')
     if img is not None:
         img = img.clone()                                # the legs below reuse the frame buffers
     latency = None
@@ -470,6 +487,7 @@ def main(argv=None):
         latency = {"payload_bytes_per_frame_and_rank": sent * 4, "payload_bytes_whole_rows": whole * 4,
                    "ms_per_frame": round(lat * 1e3, 5), "frames": n_lat,
                    "what": "rto_comm_submit of ONE frame + rto_comm_flush per frame: render part -> grouped send/recv -> assemble, host waits for each frame"}
+    _trace(f'latency leg done, rank {rank}')
     if rank == 0:
         kernel_name = KERNEL_NAMES[args.kernel] if info.canonical else "k_trace_generic"
         if triangles:
@@ -739,6 +757,7 @@ def main(argv=None):
         if cpu is not None:
             result["cpu_baseline"] = cpu
             result["speedup_vs_cpu_all_cores"] = round(result["value"] / cpu["value"], 1)
+        _trace('printing the line')
         print(json.dumps(result), flush=True)
 
     if comm is not None:

@@ -399,7 +399,7 @@ struct BuildScratch {
 // descPos (position + size of every internal node: the frustum update and the cells read it) and the coarse cells of the
 // occupancy mask -- the deepest level whose cells (internal nodes at that depth + solid leaves at or above it) number at most
 // kMaskMaxCells.
-constexpr int kMaskMaxCells = 32768;
+constexpr int kMaskMaxCells = 8192;      // config 2: 5,624 cells (depth 5) serve as well as 20,504 (depth 6): 38.7 us either way; projecting them costs a quarter
 static int build_cells(rto_context* c) {
     (void)hipFree(c->d_descPos); c->d_descPos = nullptr;
     (void)hipFree(c->d_cells); c->d_cells = nullptr; c->numCells = 0; c->cellLevel = 0;
@@ -423,7 +423,8 @@ static int build_cells(rto_context* c) {
     for (int L = 1; L <= c->depth && L <= kMaxDepth; L++) {
         solidAbove += counts[kMaxDepth + 1 + L];
         const long long n = counts[L] + solidAbove;
-        if (n > kMaskMaxCells) break;
+        static const long long cellsEnv = []() { const char* e = std::getenv("RTO_MASK_CELLS"); return e ? std::atoll(e) : 0LL; }();      // A/B knob
+        if (n > (cellsEnv > 0 ? cellsEnv : (long long)kMaskMaxCells)) break;
         level = L; best = n;
     }
     if (level == 0 || best <= 0) return RTO_OK;                              // nothing solid, or already too many cells at depth 1
@@ -1230,7 +1231,10 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     *stOut = st;
     // occupancy mask (maskRegion >= 0: the caller launches a lean kernel; its first maskBlocks workgroups build the mask: mask_block)
     Q.tileMask = nullptr; Q.maskBlocks = 0;
-    if (st && maskRegion >= 0 && (frameMode || timelineMode) && c->maskMode != 0 && c->numCells > 0 && P.aspect > 0.0f && P.tanHalfFov > 0.0f) {
+    // (whole frames only: a rank of the multi-GPU split would project every cell for a seventh of the rows -- rehearsed at 8 GPUs the
+    //  mask cost a rendering rank 16.1 us per frame against 13.2 without)
+    if (st && maskRegion >= 0 && (frameMode || timelineMode) && c->maskMode != 0 && c->numCells > 0 && P.aspect > 0.0f && P.tanHalfFov > 0.0f &&
+        (P.numParts == 1 || c->maskMode == 2)) {
         const int strips = (P.H + 7) / 8;
         const size_t words = (size_t)strips * P.tilesX + 3;              // tiles, "whole frame", "complete", ticket
         if (st->maskWords != words) {
@@ -1247,7 +1251,8 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
         Q.maskStamp = c->maskStamp;
         Q.maskAllIndex = (int)(words - 3);
         Q.maskBlocks = (c->numCells + kBlock - 1) / kBlock;
-        Q.maskTrustSlots = c->maskMode == 2 ? 0 : kMaskTrustSlots;
+        static const int trustEnv = []() { const char* e = std::getenv("RTO_MASK_TRUST"); return e ? std::atoi(e) : -1; }();     // A/B knob
+        Q.maskTrustSlots = c->maskMode == 2 ? 0 : (trustEnv >= 0 ? trustEnv : kMaskTrustSlots);
         Q.maskCells = c->d_cells; Q.maskNumCells = c->numCells;
         Q.maskInvAspTan = 1.0f / (P.aspect * P.tanHalfFov); Q.maskInvTanH = 1.0f / P.tanHalfFov;
     }

@@ -531,7 +531,7 @@ def test_occupancy_mask_never_changes_pixels_and_removes_work(ctx, orc, scenes):
         s = scenes(scene)
         upload(ctx, s)
         level, ncells = ctx.debug_tile_mask_info()
-        assert level >= 1 and 0 < ncells <= 32768, (scene, level, ncells)
+        assert level >= 1 and 0 < ncells <= 8192, (scene, level, ncells)
         W, H = 640, 360
         for (t, p, r, tgt, fov) in cams:
             cam = orc.Camera(t, p, r)

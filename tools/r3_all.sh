@@ -17,7 +17,7 @@ python3 - <<'PY'
 import glob, json, os
 for f in sorted(glob.glob("gpurun_out/r3_final/*.json")):
     try:
-        d = json.load(open(f))
+        d = json.loads([ln for ln in open(f) if ln.startswith("{")][-1])
     except Exception as e:
         print(os.path.basename(f), "FAILED", e); continue
     extra = ""
