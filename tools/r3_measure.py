@@ -34,9 +34,10 @@ ctx.timing_begin(-1)
 for name in ("sphere256", "sphere512", "calgary"):
     g, cam = scene(name)
     ws = []
+    data = g.data                                     # (the Python wrapper copies the grid out of the C++ object: not part of the call)
     for _ in range(4):
         t = time.perf_counter()
-        ctx.build_octree(g.data, g.min, g.voxelSize)
+        ctx.build_octree(data, g.min, g.voxelSize)
         ws.append(time.perf_counter() - t)
     k, u = ctx.last_build_ms()
     lv, nc = ctx.debug_tile_mask_info()
@@ -47,8 +48,8 @@ for name in ("sphere256", "sphere512", "calgary"):
     print(f"{name}: {ctx.info().num_nodes} nodes; rto_build_octree wall {min(ws[1:]) * 1e3:.3f} ms (pyramid + emission kernels {k:.3f} ms, H2D {u:.3f} ms; the rest: "
           f"descPos + occupancy cells [level {lv}, {nc} cells] and their two read-backs)")
     ctx.update_frustum(view, 45.0, aspect, True)
-    us = per_call_us(lambda: ctx.update_frustum(view, 45.0, aspect, True), ctx.synchronize)
-    print(f"  rto_update_frustum: {us:.1f} us per call (400 back-to-back, nothing read back; one kernel)")
+    us = per_call_us(lambda: ctx.update_frustum(view, 45.0, aspect, True), ctx.synchronize, 100)
+    print(f"  rto_update_frustum: {us:.1f} us per call (100 back-to-back, nothing read back; one kernel)")
     ctx.update_frustum(view, 45.0, aspect, False)
     d_skip = torch.zeros(1, dtype=torch.float32, device="cuda")
     us = per_call_us(lambda: ctx.probe_skip_device(view, pos, float(np.float32(aspect)), d_skip.data_ptr()), ctx.synchronize, 200)
