@@ -52,7 +52,7 @@ for name in ("sphere256", "sphere512", "calgary"):
     print(f"  rto_update_frustum: {us:.1f} us per call (100 back-to-back, nothing read back; one kernel)")
     ctx.update_frustum(view, 45.0, aspect, False)
     d_skip = torch.zeros(1, dtype=torch.float32, device="cuda")
-    us = per_call_us(lambda: ctx.probe_skip_device(view, pos, float(np.float32(aspect)), d_skip.data_ptr()), ctx.synchronize, 200)
+    us = per_call_us(lambda: ctx.probe_skip_device(view, pos, float(np.float32(aspect)), d_skip.data_ptr()), ctx.synchronize, 100)
     print(f"  rto_probe_skip_device (49 probes -> percentile -> blend): {us:.1f} us per call, value {float(d_skip.cpu()[0]):.6g}")
     d_rgba = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
     d_dist = torch.empty((H, W), dtype=torch.float32, device="cuda")
