@@ -121,8 +121,9 @@ int  rto_set_kernel(rto_context* ctx, int kernel /* RTO_KERNEL_* */);
  * waves that will run longest should start first.
  * CENTRE_OUT: outwards from the projection of the solid geometry's centre.  TEMPORAL (default): by the per-tile
  * trip counts earlier frames of the same size recorded (CENTRE_OUT until one exists); the table is rebuilt by one
- * small kernel in front of a frame whenever the rectangle's tile box moved and at least every refresh_period-th frame
- * (default 8; 0 keeps the current period). */
+ * small kernel in front of a frame whenever the rectangle's tile box changed its size, and otherwise after refresh_period
+ * frames (default 8; 0 keeps the current period) -- an interval that doubles, up to 8 x refresh_period, for as long as the
+ * box keeps its size (a camera that stands still or pans). */
 #define RTO_ORDER_CENTRE_OUT 0
 #define RTO_ORDER_TEMPORAL   1
 int  rto_set_launch_order(rto_context* ctx, int policy, int refresh_period);

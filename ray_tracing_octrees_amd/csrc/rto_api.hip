@@ -74,7 +74,7 @@ struct rto_context {
         // being stream-captured.  A graph replay re-runs its k_order_build nodes and rewrites its table behind the host's back, so
         // plain launches never read table [1]; and every capture starts with a rebuild node of its own (capId), so a replay never
         // depends on what plain launches, another graph or its own tail left in the table.
-        struct Table { int* d = nullptr; bool valid = false; int box[4] = { 0, 0, 0, 0 }; int age = 0; };
+        struct Table { int* d = nullptr; bool valid = false; int box[4] = { 0, 0, 0, 0 }; int age = 0; int stretch = 1; };   // stretch: see prepare_schedule
         Table tab[2];
         int active = 0;                 // the table the launch being prepared uses
         unsigned long long capId = 0;   // id of the capture table [1] was last (re)built in
@@ -736,7 +736,7 @@ int rto_set_launch_order(rto_context* c, int policy, int refresh_period) {
     if (refresh_period < 0) return fail(c, RTO_E_INVALID, "rto_set_launch_order: refresh_period must be >= 0 (0 keeps the current one)");
     c->orderPolicy = policy;
     if (refresh_period > 0) c->orderPeriod = refresh_period;
-    for (auto& kv : c->orders) { if (!kv.second.fixed) kv.second.tab[0].valid = false; kv.second.tab[1].valid = false; kv.second.tab[0].age = kv.second.tab[1].age = 0; }
+    for (auto& kv : c->orders) { if (!kv.second.fixed) kv.second.tab[0].valid = false; kv.second.tab[1].valid = false; kv.second.tab[0].age = kv.second.tab[1].age = 0; kv.second.tab[0].stretch = kv.second.tab[1].stretch = 1; }
     return RTO_OK;
 }
 
@@ -1299,7 +1299,11 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
         // SIZE (the entries are relative to the box's corner: a box that only moved -- a camera in motion -- keeps using
         // it) or every orderPeriod-th frame.  k_order_build emits a permutation of the box's tiles whatever the
         // cost array holds and keeps no state between calls: inside a capture it becomes a node of the graph.
-        if (!fixedOrder && Q.traceWaves > 0 && (!T.valid || box[2] != T.box[2] || box[3] != T.box[3] || T.age >= c->orderPeriod)) {
+        // A rebuild for age alone (same box size: a camera that stands still or only pans) doubles the next interval, up to 8
+        // periods: the costs of such frames change slowly, and a build (13 us at config 2) every 8th frame was 4 % of a frame.
+        const bool resized = !T.valid || box[2] != T.box[2] || box[3] != T.box[3];
+        if (!fixedOrder && Q.traceWaves > 0 && (resized || T.age >= c->orderPeriod * T.stretch)) {
+            T.stretch = resized ? 1 : std::min(T.stretch * 2, 8);
             if (o->costValid) {
                 const int staged = Q.traceWaves <= kOrderLdsTiles ? 1 : 0;
                 hipLaunchKernelGGL(k_order_build, dim3(1), dim3(kOrderBlock), staged ? (size_t)((Q.traceWaves + 15) & ~15) : 0, s, o->d_tileCost, Q.tilesX,

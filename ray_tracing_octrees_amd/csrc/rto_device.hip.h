@@ -1305,8 +1305,17 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_build(const int* __restri
                 for (int q = 0; q < 4; q++) if (rx0 + q * kWave < boxW) stagedBucket[ry * boxW + rx0 + q * kWave] = (unsigned char)v[q];
             }
     __syncthreads();
+    // Bucket 0 -- tiles whose wave did not walk: with the occupancy mask more than half of a box -- is counted and placed by
+    // ballot (one LDS atomic per wave and row chunk): 64 lanes adding to ONE counter serialise.
     for (int ry = wave; ry < boxH; ry += kWaves)
-        for (int rx = lane; rx < boxW; rx += kWave) atomicAdd(&cnt[wave][staged ? (int)stagedBucket[ry * boxW + rx] : bucket_at(rx, ry)], 1);
+        for (int rx0 = 0; rx0 < boxW; rx0 += kWave) {                   // wave-uniform trip count: ballots inside
+            const int rx = rx0 + lane;
+            const bool in = rx < boxW;
+            const int b = in ? (staged ? (int)stagedBucket[ry * boxW + rx] : bucket_at(rx, ry)) : -1;
+            const unsigned long long zeros = __builtin_amdgcn_ballot_w64(b == 0);
+            if (b > 0) atomicAdd(&cnt[wave][b], 1);
+            if (zeros && lane == (int)__builtin_ctzll(zeros)) atomicAdd(&cnt[wave][0], (int)__builtin_popcountll(zeros));
+        }
     __syncthreads();
     // write cursors: costlier buckets first, within a bucket wave 0 first.  Wave 0 does it: lane b owns bucket 63 - b.
     if (wave == 0) {
@@ -1320,8 +1329,21 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_build(const int* __restri
     }
     __syncthreads();
     for (int ry = wave; ry < boxH; ry += kWaves)
-        for (int rx = lane; rx < boxW; rx += kWave) {
-            const int pos = atomicAdd(&cnt[wave][staged ? (int)stagedBucket[ry * boxW + rx] : bucket_at(rx, ry)], 1);
+        for (int rx0 = 0; rx0 < boxW; rx0 += kWave) {
+            const int rx = rx0 + lane;
+            const bool in = rx < boxW;
+            const int b = in ? (staged ? (int)stagedBucket[ry * boxW + rx] : bucket_at(rx, ry)) : -1;
+            const unsigned long long zeros = __builtin_amdgcn_ballot_w64(b == 0);
+            int pos = -1;
+            if (b > 0) pos = atomicAdd(&cnt[wave][b], 1);
+            if (zeros) {
+                const int leader = (int)__builtin_ctzll(zeros);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&cnt[wave][0], (int)__builtin_popcountll(zeros));
+                base = __shfl(base, leader);
+                if (b == 0) pos = base + (int)__builtin_popcountll(zeros & ((1ull << lane) - 1ull));
+            }
+            if (!in) continue;
             // cannot fall outside by construction (both passes see the same buckets: the kernel that writes the costs runs
             // before or after this one on the stream, never beside it); refused writes are counted and tests assert 0
             if (pos >= 0 && pos < n) order[pos] = rx | (ry << 16);           // relative to the box: a box of the same size elsewhere can use the table
