@@ -48,6 +48,8 @@ NODE_BYTES = 60                # struct GPUNodes, the reference's node record (S
 PIXEL_BYTES = 16               # RGBA32F
 SIMDS, CLOCK_GHZ, VALU_CYCLES_PER_WAVE_INST = 1024, 2.4, 2   # 256 CUs x 4 SIMD-32: a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
 VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INST   # 1228.8 G wave-instructions/s
+MEASURED_CYCLES_PER_WAVE_INST = 3.35   # the traversal loop's mix at the issue costs measured on a saturated SIMD (profiles/r02_valu_issue_rates.txt): 401.5 cycles / 120 instructions
+R02_VALU_INSTS = {"2": 24.12e6, "4": 55.13e6, "5": 328.1e6}   # SQ_INSTS_VALU per single-frame launch of round 2's kernels (profiles/r02_config*_summary.json)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_counters.json")
 
 CONFIGS = {
@@ -550,6 +552,14 @@ def main(argv=None):
                 roofline["achieved"] = round(achieved, 1)
                 roofline["frac"] = round(achieved / VALU_PEAK_GINST, 4)
                 roofline["valu_insts_per_launch"] = int(insts)
+                # The same duration priced two other ways ("Reading frac"): at the issue cost measured for
+                # this loop's instruction mix (tools/ubench/valu_rate*.hip: 2.3-2.6 cycles for the full-rate third, 4.1-4.4 for
+                # the rest), and with round 2's instruction count for the same frame -- frac falls when a change removes
+                # instructions faster than time (the occupancy mask), this one does not.
+                roofline["issue_weighted"] = round(achieved * MEASURED_CYCLES_PER_WAVE_INST / VALU_CYCLES_PER_WAVE_INST / VALU_PEAK_GINST, 4)
+                r02 = R02_VALU_INSTS.get(str(args.config))
+                if r02 and order_key == "temporal":
+                    roofline["frac_r02_work"] = round(r02 / (k_avg * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)
                 if pmc.get("SQ_THREAD_CYCLES_VALU"):
                     roofline["lane_utilisation"] = round(float(pmc["SQ_THREAD_CYCLES_VALU"]) / (64.0 * insts), 3)
                 roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
