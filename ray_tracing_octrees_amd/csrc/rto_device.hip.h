@@ -1943,6 +1943,22 @@ __global__ __launch_bounds__(kBlock) void k_unified_fill(const uint2* __restrict
     }
 }
 
+// Wave64 inclusive scans in registers (gfx9 DPP: shifts inside the rows of 16 lanes, then the two row broadcasts), no LDS
+// round trips: lanes without a source, and rows outside the row mask, take the identity 0.
+template <int CTRL, int ROWS> __device__ __forceinline__ int dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, false); }
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);      // row_shr:1, 2, 4, 8
+    v += dpp0<0x142, 0xa>(v);                                                                                    // row_bcast:15 into rows 1, 3
+    v += dpp0<0x143, 0xc>(v);                                                                                    // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ int wave_scan_max_nonneg(int v) {       // values >= 0
+    v = max(v, dpp0<0x111, 0xf>(v)); v = max(v, dpp0<0x112, 0xf>(v)); v = max(v, dpp0<0x114, 0xf>(v)); v = max(v, dpp0<0x118, 0xf>(v));
+    v = max(v, dpp0<0x142, 0xa>(v));
+    v = max(v, dpp0<0x143, 0xc>(v));
+    return v;
+}
+
 #ifndef RTO_TRI_WAVES
 #define RTO_TRI_WAVES 5
 #endif
@@ -1990,7 +2006,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     const bool anyRisky = __builtin_amdgcn_ballot_w64(risky) != 0ull;   // wave-uniform; shadow rays are never risky themselves
                                                                          // (finite light direction), the exact form serves them too
     unsigned cur = 0;
-    int cx = 0, cy = 0, cz = 0;
+    int cx = (int)kCoordBias, cy = (int)kCoordBias, cz = (int)kCoordBias;      // node position, biased (child_axis_terms): the bit operations below never touch the bias
     int bpos = P.depth - 1;
     unsigned lvlPending = 0;
     const unsigned sentinel = 1u << P.depth;
@@ -2003,6 +2019,9 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     bool shadowRay = false;        // the ray in flight is the pixel's shadow ray
     float ndotl = 0.0f;
     const char* recBytes = reinterpret_cast<const char*>(Sc.rec);
+    // scratch of the triangle rounds: this wave's row of the dummy stack entry `depth` (nothing valid is ever read from it,
+    // and no node trip runs while a round uses it)
+    unsigned* marks = reinterpret_cast<unsigned*>(stk - lane + P.depth * kWave);
     int trips = 0, rounds = 0;
 #if defined(RTO_TRI_PROFILE)       // A/B build (tools/tri_profile.py): where a frame's instructions go
     unsigned long long profLaneTrips = 0, profChunks = 0, profPairs = 0, profWaveTrips = 0;
@@ -2012,8 +2031,13 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
         // node loop: until nobody walks, or RTO_TRI_BATCH lanes wait with a leaf (the tests cost by the pair, so a round
         // for 16 leaves -- ~70 pairs -- fills the wave; measured at config 5: 2 / 4 / 8 / 12 / 16 / 20 / 32 / 48 / 64 lanes ->
         // 632 / 599 / 554 / 535 / 533 / 534 / 560 / 614 / 641 us)
-        while (__builtin_amdgcn_ballot_w64(alive) != 0ull && __builtin_popcountll(__builtin_amdgcn_ballot_w64(haveLeaf)) < RTO_TRI_BATCH)
-        if (alive) {
+        // Shape of the loop: a plain divergent `while (alive)` (lanes drop out as they pop a leaf or end) with a wave-uniform
+        // break -- `waiting` lives in a scalar register: the lanes waiting at the start of the round plus, per trip, the lanes
+        // that have just popped a leaf (the ballot sees exactly the lanes walking in this trip).  The earlier form, a loop on
+        // the two ballots around `if (alive)`, cost ~20 VALU instructions per trip in register copies at the loop's edges.
+        int waiting = __builtin_popcountll(__builtin_amdgcn_ballot_w64(haveLeaf));
+        if (waiting < RTO_TRI_BATCH)
+        while (alive) {
             trips++;
 #if defined(RTO_TRI_PROFILE)
             { const unsigned long long act = (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));     // lanes walking in this trip
@@ -2025,9 +2049,9 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
             const float fh = __uint_as_float((unsigned)(bpos + 127) << 23);        // (float)(1 << bpos), exact (bpos = -1 after a finest leaf: unused)
             unsigned fail8;
             if (anyRisky) fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz,
-                                                        r.ix, r.iy, r.iz, cx, cy, cz, 1 << (bpos & 31));
-            else fail8 = child_fail_mask_fast(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                              sgnX, sgnY, sgnZ, cx, cy, cz, fh);
+                                                        r.ix, r.iy, r.iz, cx & 0x7fffff, cy & 0x7fffff, cz & 0x7fffff, 1 << (bpos & 31));
+            else fail8 = child_fail_mask_fast<true, true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                          sgnX, sgnY, sgnZ, cx, cy, cz, fh);
             const unsigned vm0 = (d.x >> 16) & 0xffu;
             S += __builtin_popcount(vm0);
             // children that do more than count a pop: visible internal ones and visible triangle leaves that pass the slab test
@@ -2055,6 +2079,8 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
             haveLeaf = !dead && leaf;
             ended = dead;
             alive = !dead && !leaf;
+            waiting += __builtin_popcountll(__builtin_amdgcn_ballot_w64(haveLeaf));
+            if (waiting >= RTO_TRI_BATCH) break;
         }
         rounds++;
         // ---- the waiting lanes' triangles, tested by ALL 64 lanes (S/RT semantics of the pop: it happens only below the
@@ -2082,9 +2108,9 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
             uint2 tr = make_uint2(0u, 0u);                          // first triangle, triangles of this lane's leaf
             if (haveLeaf) tr = *reinterpret_cast<const uint2*>(recBytes + (cur << 3));
             const int cnt = (int)tr.y;
-            int incl = cnt;
-            for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            const int incl = wave_scan_add(cnt);
             const int total = __builtin_amdgcn_readlane(incl, kWave - 1);
+            const int first = (int)tr.x - (incl - cnt);             // pair w of this lane's leaf is triangle first + w
             keys[lane] = ~0ull;
             __builtin_amdgcn_wave_barrier();
             for (int w0 = 0; w0 < total; w0 += kWave) {
@@ -2092,16 +2118,22 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
                 profChunks++; profPairs += (unsigned long long)min(kWave, total - w0);
 #endif
                 const int w = w0 + lane;
-                int owner = 0;                                      // lanes whose inclusive prefix is <= w
-#pragma unroll
-                for (int step = 32; step >= 1; step >>= 1) {
-                    const int v = __shfl(incl, owner + step - 1);
-                    if (v <= w) owner += step;
-                }
-                const int inclO = __shfl(incl, owner), cntO = __shfl(cnt, owner);
-                const int k = (int)__shfl((int)tr.x, owner) + (w - (inclO - cntO));
-                const float oox = __shfl(r.ox, owner), ooy = __shfl(r.oy, owner), ooz = __shfl(r.oz, owner);
-                const float odx = __shfl(r.dx, owner), ody = __shfl(r.dy, owner), odz = __shfl(r.dz, owner);
+                // owner of pair w = the lane whose range [incl - cnt, incl) holds it.  Every lane whose range meets this chunk
+                // writes its number at the chunk position where the range begins (ranges are disjoint and in lane order, so are
+                // the marks); the owner of a position is then the last mark at or before it: a running maximum in registers.
+                // (A wave's LDS operations execute in order: the zeroes land before the marks, the marks before the read.)
+                marks[lane] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const int p = incl - cnt - w0;
+                if (cnt > 0 && p < kWave && incl > w0) marks[max(p, 0)] = (unsigned)lane;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const int owner = wave_scan_max_nonneg((int)marks[lane]);
+                const int oa = owner << 2;                          // ds_bpermute address of the owner's lane
+                const int k = __builtin_amdgcn_ds_bpermute(oa, first) + w;
+#define RTO_FROM(x) __int_as_float(__builtin_amdgcn_ds_bpermute(oa, __float_as_int(x)))
+                const float oox = RTO_FROM(r.ox), ooy = RTO_FROM(r.oy), ooz = RTO_FROM(r.oz);
+                const float odx = RTO_FROM(r.dx), ody = RTO_FROM(r.dy), odz = RTO_FROM(r.dz);
+#undef RTO_FROM
                 if (w < total) {
                     float t;
                     if (ray_triangle(oox, ooy, ooz, odx, ody, odz, Sc.tris + (size_t)k * 12, t) && t < 1e30f)
@@ -2160,7 +2192,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
                         float tNear, tFar, a0, a1, a2, a3, a4, a5;
                         alive = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
                         if (!alive) stepsTotal += 1;                  // the shadow ray pops the root and misses it
-                        cur = 0; cx = cy = cz = 0; bpos = P.depth - 1; lvlPending = 0; S = 0;
+                        cur = 0; cx = cy = cz = (int)kCoordBias; bpos = P.depth - 1; lvlPending = 0; S = 0;
                     }
                 }
             } else if (endedHit) shade = 0.0f;                         // something between the hit and the light
