@@ -3,6 +3,7 @@
 // (inverse(view), tan(fov/2), frustum planes) and kernel launches.  No torch, no
 // oracle, no CPU fallback: every entry point needs a gfx950 device.
 #include "rto_device.hip.h"
+static int lean_block(int path);
 
 #include "../host/rtmath.h"
 
@@ -777,6 +778,17 @@ int rto_debug_counters(rto_context* c, unsigned long long out[3], int zero) {
     return RTO_OK;
 }
 
+// Developer aid (not in rto_hip.h): the first n ints of the instrumentation buffer -- the per-wave timeline records a
+// -DRTO_TRI_PROFILE build's colour frames of the triangle path leave there (tools/tri_timeline.py).
+int rto_debug_steps_buffer(rto_context* c, int32_t* out, int64_t n) {
+    if (!c || !out || n <= 0) return RTO_E_INVALID;
+    RTO_HIP(c, hipSetDevice(c->device));
+    RTO_HIP(c, hipDeviceSynchronize());
+    if (!c->d_steps || (size_t)n > c->stepsCap) return fail(c, RTO_E_INVALID, "rto_debug_steps_buffer: no such buffer");
+    RTO_HIP(c, hipMemcpy(out, c->d_steps, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    return RTO_OK;
+}
+
 int rto_debug_sort_violations(rto_context* c, int* count) {
     if (!c || !count) return RTO_E_INVALID;
     RTO_HIP(c, hipSetDevice(c->device));
@@ -1250,7 +1262,7 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
         Q.tileMask = st->d_tileMask + (size_t)maskRegion * words;
         Q.maskStamp = c->maskStamp;
         Q.maskAllIndex = (int)(words - 3);
-        Q.maskBlocks = (c->numCells + kBlock - 1) / kBlock;
+        Q.maskBlocks = (c->numCells + lean_block(path) - 1) / lean_block(path);
         static const int trustEnv = []() { const char* e = std::getenv("RTO_MASK_TRUST"); return e ? std::atoi(e) : -1; }();     // A/B knob
         Q.maskTrustSlots = c->maskMode == 2 ? 0 : (trustEnv >= 0 ? trustEnv : kMaskTrustSlots);
         Q.maskCells = c->d_cells; Q.maskNumCells = c->numCells;
@@ -1327,11 +1339,27 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
 // frame per launch: 44.9 -> 38.9 us.  (Measured: a request of 32 KB and one of 40 KB give the same occupancy and time -- the
 // CU hands its LDS out in two halves --, 53 KB gives 2 per SIMD: 46.7 us.)  Launches of several frames have waves to spare and
 // keep 6.  RTO_WAVES_PER_SIMD=<n> overrides (A/B runs); 0 = never pad.
+// Threads per workgroup of the lean kernels (path 0: octree frames, 1: triangle frames; single and batch forms).  Their waves
+// share nothing but the launch, so a workgroup is only a unit of dispatch: the dispatcher places a workgroup when ALL its waves
+// fit, and with 4-wave workgroups a CU's wave slots stand empty until four are free at once (config 5's timeline: ~4,300 of
+// 5,120 slots taken in mid-frame).  Measured (us per frame, 256 / 128 / 64 threads): config 5 453 / 445 / 439; config 2 36.5 /
+// 43.2 / 43.3, config 4 75.1 / 81.2 / 78.5 -- the octree frames, whose launch geometry was tuned around 4-wave workgroups (four
+// consecutive launch slots per CU, 4 resident waves per SIMD through the LDS request), keep 256.
+// RTO_LEAN_BLOCK / RTO_TRI_BLOCK = <64|128|256> override (A/B runs).
+static int lean_block(int path) {
+    static const int b[2] = {
+        []() { const char* e = std::getenv("RTO_LEAN_BLOCK"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 256; }(),
+        []() { const char* e = std::getenv("RTO_TRI_BLOCK"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 64; }() };
+    return b[path ? 1 : 0];
+}
+static int lean_wpb(int path) { return lean_block(path) / kWave; }
+
 static size_t lds_for_occupancy(size_t lds, int wavesDefault) {
     static const int forced = []() { const char* e = std::getenv("RTO_WAVES_PER_SIMD"); return e ? std::atoi(e) : -1; }();
     const int waves = forced >= 0 ? forced : wavesDefault;
     if (waves <= 0) return lds;
-    const size_t perGroup = (size_t)(160 * 1024) / (size_t)waves;          // workgroups per CU == waves per SIMD (4 waves -> 4 SIMDs)
+    const size_t groupsPerCU = (size_t)waves * 4 / (size_t)lean_wpb(0);     // 4 SIMDs per CU
+    const size_t perGroup = (size_t)(160 * 1024) / groupsPerCU;
     return std::max(lds, std::min<size_t>(perGroup, 64 * 1024) & ~(size_t)255);
 }
 
@@ -1379,7 +1407,9 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 if (rc != RTO_OK) return rc;
             }
             const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
-            const size_t lds = Q.tileMask ? lds_for_occupancy(ldsStacks, 4) : lds_for_occupancy(ldsStacks, 0);
+            const int lblocksLean = (Q.launchWaves + lean_wpb(0) - 1) / lean_wpb(0);
+            const size_t ldsLean = (size_t)lean_wpb(0) * (P.depth + 1) * kWave * sizeof(uint2);
+            const size_t lds = Q.tileMask ? lds_for_occupancy(ldsLean, 4) : (leanKernel && !(c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT) ? lds_for_occupancy(ldsLean, 0) : ldsStacks);
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
             startRecorded = true;
             const bool persistent = c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT && st && frameMode;
@@ -1402,8 +1432,8 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             } else {
                 // maskMode 2 (tests): a launch of the mask workgroups alone first, so that every wave of the frame finds the mask complete
                 if (c->maskMode == 2 && Q.maskBlocks > 0)
-                    hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(Q.maskBlocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
-                hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(lblocks + Q.maskBlocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+                    hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(Q.maskBlocks), dim3(lean_block(0)), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+                hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(lblocksLean + Q.maskBlocks), dim3(lean_block(0)), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             }
         }
     } else {
@@ -1525,11 +1555,11 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
     hipEvent_t evA = c->ev0, evB = c->ev1;
     if (!noEvents && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
     if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
-    const size_t lds = lds_for_occupancy((size_t)(kBlock / kWave) * (Ps[0].depth + 1) * kWave * sizeof(uint2), 0);
+    const size_t lds = lds_for_occupancy((size_t)lean_wpb(0) * (Ps[0].depth + 1) * kWave * sizeof(uint2), 0);
     const long long waves = (long long)maxWaves * n;
     if (c->maskMode == 2 && B.P[0].maskBlocks > 0)
-        hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)(B.P[0].maskBlocks * n)), dim3(kBlock), lds, s, B, c->d_desc);
-    hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)((waves + (kBlock / kWave) - 1) / (kBlock / kWave)) + (unsigned)(B.P[0].maskBlocks * n)), dim3(kBlock), lds, s, B, c->d_desc);
+        hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)(B.P[0].maskBlocks * n)), dim3(lean_block(0)), lds, s, B, c->d_desc);
+    hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)((waves + lean_wpb(0) - 1) / lean_wpb(0)) + (unsigned)(B.P[0].maskBlocks * n)), dim3(lean_block(0)), lds, s, B, c->d_desc);
     RTO_HIP(c, hipGetLastError());
     if (!noEvents) RTO_HIP(c, hipEventRecord(evB, s));
     c->lastA = evA; c->lastB = evB;                       // what rto_last_kernel_ms reads
@@ -1886,12 +1916,16 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
         if (c->d_triRec && c->kernelMode != RTO_KERNEL_PACKED_V3) {
             // default: the lean loop on the unified records (8-byte stack entries, shadow rays start inside the loop)
             LeanTriScene S{ c->d_triRec, c->d_tris };
-            const size_t lds = (size_t)(kBlock / kWave) * ((P.depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));   // stacks + the keys of the triangle rounds
+#if defined(RTO_TRI_TIMELINE)
+            S.timeline = (!count && !shadeOut && !capturing && ensure_steps(c, (size_t)tiles * 8) == RTO_OK) ? c->d_steps : nullptr;
+#endif
+            const size_t lds = (size_t)lean_wpb(1) * ((P.depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));   // stacks + the keys of the triangle rounds
+            const dim3 lb(lean_block(1)), lgrid((P.launchWaves + lean_wpb(1) - 1) / lean_wpb(1) + P.maskBlocks);
             if (c->maskMode == 2 && P.maskBlocks > 0 && !count)
-                hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, false>), dim3(P.maskBlocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
-            if (shadeOut) hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, true>), dim3(lblocks + P.maskBlocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
-            else if (count) hipLaunchKernelGGL((k_trace_lean_triangles<kModeSteps, false>), dim3(lblocks + P.maskBlocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
-            else hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, false>), dim3(lblocks + P.maskBlocks), dim3(kBlock), lds, s, P, S, shadow, d_out, c->d_counters);
+                hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, false>), dim3(P.maskBlocks), lb, lds, s, P, S, shadow, d_out, c->d_counters);
+            if (shadeOut) hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, true>), lgrid, lb, lds, s, P, S, shadow, d_out, c->d_counters);
+            else if (count) hipLaunchKernelGGL((k_trace_lean_triangles<kModeSteps, false>), lgrid, lb, lds, s, P, S, shadow, d_out, c->d_counters);
+            else hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, false>), lgrid, lb, lds, s, P, S, shadow, d_out, c->d_counters);
         } else {
             // RTO_KERNEL_PACKED_V3: round 1's form on the descriptors + triOffset (kept in the test matrix)
             PackedTriScene S{ c->d_desc, c->d_descFirstChild, c->d_tris, c->d_triOffset };
@@ -1955,13 +1989,16 @@ static int launch_triangles_batch(rto_context* c, const rto_frame* frames, int n
     if (!noEvents && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
     if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
     LeanTriScene S{ c->d_triRec, c->d_tris };
-    const size_t lds = (size_t)(kBlock / kWave) * ((B.P[0].depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));
+#if defined(RTO_TRI_TIMELINE)
+    S.timeline = nullptr;
+#endif
+    const size_t lds = (size_t)lean_wpb(1) * ((B.P[0].depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));
     const long long waves = (long long)maxWaves * n;
-    const dim3 grid((unsigned)((waves + (kBlock / kWave) - 1) / (kBlock / kWave)) + (unsigned)(B.P[0].maskBlocks * n));
+    const dim3 grid((unsigned)((waves + lean_wpb(1) - 1) / lean_wpb(1)) + (unsigned)(B.P[0].maskBlocks * n));
     if (c->maskMode == 2 && B.P[0].maskBlocks > 0)
-        hipLaunchKernelGGL(k_trace_lean_triangles_batch<false>, dim3((unsigned)(B.P[0].maskBlocks * n)), dim3(kBlock), lds, s, B, S, shadow);
-    if (shadeOut) hipLaunchKernelGGL(k_trace_lean_triangles_batch<true>, grid, dim3(kBlock), lds, s, B, S, shadow);
-    else hipLaunchKernelGGL(k_trace_lean_triangles_batch<false>, grid, dim3(kBlock), lds, s, B, S, shadow);
+        hipLaunchKernelGGL(k_trace_lean_triangles_batch<false>, dim3((unsigned)(B.P[0].maskBlocks * n)), dim3(lean_block(1)), lds, s, B, S, shadow);
+    if (shadeOut) hipLaunchKernelGGL(k_trace_lean_triangles_batch<true>, grid, dim3(lean_block(1)), lds, s, B, S, shadow);
+    else hipLaunchKernelGGL(k_trace_lean_triangles_batch<false>, grid, dim3(lean_block(1)), lds, s, B, S, shadow);
     RTO_HIP(c, hipGetLastError());
     if (!noEvents) RTO_HIP(c, hipEventRecord(evB, s));
     c->lastA = evA; c->lastB = evB;

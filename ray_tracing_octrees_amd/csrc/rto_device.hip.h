@@ -603,7 +603,7 @@ __device__ __forceinline__ void mask_block(const RenderParams& P, int blockInFra
     unsigned* mask = P.tileMask;
     const unsigned stamp = P.maskStamp;
     const int all = P.maskAllIndex;
-    const int i = blockInFrame * kBlock + (int)threadIdx.x;
+    const int i = blockInFrame * (int)blockDim.x + (int)threadIdx.x;
     if (i < P.maskNumCells) {
         const int4 c = P.maskCells[i];
         const float vs = P.voxelSize;
@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean(RenderPar
     const int wave = threadIdx.x >> 6;
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64], b in [0, depth]
     if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x); return; }        // the first workgroups build the occupancy mask
-    const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (kBlock / kWave) + wave);
+    const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (int)(blockDim.x >> 6) + wave);
     if (slot >= P.launchWaves) return;
     trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
 }
@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_batch(Ren
     const int wave = threadIdx.x >> 6;
     const int mb = B.P[0].maskBlocks;                          // mask workgroups per frame (every frame of a batch: the same octree)
     if ((int)blockIdx.x < mb * B.n) { const int fm = (int)blockIdx.x / mb; mask_block(B.P[fm], (int)blockIdx.x - fm * mb); return; }
-    const int g = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - mb * B.n) * (kBlock / kWave) + wave);
+    const int g = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - mb * B.n) * (int)(blockDim.x >> 6) + wave);
     const int slot = g / B.n, f = g - slot * B.n;
     const RenderParams& P = B.P[f];
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;
@@ -1909,6 +1909,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_packed_triangles(RenderParams 
 struct LeanTriScene {
     const uint2* rec;           // [0] the root's descriptor; see above
     const float* tris;          // 12 floats per triangle: v0, v1, v2, face normal
+#if defined(RTO_TRI_TIMELINE)
+    int* timeline;              // A/B build: 8 ints per tile {start lo, hi, end lo, hi (100 MHz), trips, rounds, HW_ID, XCC_ID | slot << 4}
+#endif
 };
 
 // interesting children per descriptor (after k_desc_trimask)
@@ -1969,6 +1972,9 @@ template <int MODE, bool SHADE>
 __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P, const LeanTriScene& Sc, int shadow, float4* __restrict__ out,
                                                           Counters* __restrict__ counters, uint2* stk, unsigned long long* keys,
                                                           const int lane, const int slot) {
+#if defined(RTO_TRI_TIMELINE)
+    const unsigned long long profT0 = wall_clock64();
+#endif
     int tile, tx, ty;
     resolve_slot(P, slot, tx, ty, tile);
     const int px = tx * 8 + (lane & 7);
@@ -2199,6 +2205,20 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
         }
         if (__builtin_amdgcn_ballot_w64(alive || haveLeaf) == 0ull) break;
     }
+#if defined(RTO_TRI_TIMELINE)
+    if (Sc.timeline && MODE == kModeColor) {
+        int tmax = trips;
+        for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
+        if (lane == 0 && ty < P.tilesY) {
+            const unsigned long long tl1 = wall_clock64();
+            const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+            int* rec = Sc.timeline + (size_t)tile * 8;
+            rec[0] = (int)(profT0 & 0xffffffffu); rec[1] = (int)(profT0 >> 32); rec[2] = (int)(tl1 & 0xffffffffu); rec[3] = (int)(tl1 >> 32);
+            rec[4] = tmax; rec[5] = rounds; rec[6] = (int)hwid; rec[7] = (int)(xcc & 15u) | (slot << 4);
+        }
+    }
+#endif
 #if defined(RTO_TRI_PROFILE)
     if (counters && MODE == kModeColor) {
         // profLaneTrips / profWaveTrips live in the lanes that walked; take the wave maximum (every walking lane saw the same counts while it walked)
@@ -2235,9 +2255,9 @@ __global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles(
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64], b in [0, depth]
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds_stack + (size_t)(kBlock / kWave) * (P.depth + 1) * kWave) + wave * kWave;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds_stack + (size_t)(blockDim.x >> 6) * (P.depth + 1) * kWave) + wave * kWave;
     if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x); return; }
-    const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (kBlock / kWave) + wave);
+    const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (int)(blockDim.x >> 6) + wave);
     if (slot >= P.launchWaves) return;
     trace_tile_lean_triangles<MODE, SHADE>(P, Sc, shadow, out, counters, stk, keys, lane, slot);
 }
@@ -2251,11 +2271,11 @@ __global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles_
     const int wave = threadIdx.x >> 6;
     const int mb = B.P[0].maskBlocks;
     if ((int)blockIdx.x < mb * B.n) { const int fm = (int)blockIdx.x / mb; mask_block(B.P[fm], (int)blockIdx.x - fm * mb); return; }
-    const int g = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - mb * B.n) * (kBlock / kWave) + wave);
+    const int g = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - mb * B.n) * (int)(blockDim.x >> 6) + wave);
     const int slot = g / B.n, f = g - slot * B.n;
     const RenderParams& P = B.P[f];
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds_stack + (size_t)(kBlock / kWave) * (P.depth + 1) * kWave) + wave * kWave;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds_stack + (size_t)(blockDim.x >> 6) * (P.depth + 1) * kWave) + wave * kWave;
     if (slot >= P.launchWaves) return;
     trace_tile_lean_triangles<kModeColor, SHADE>(P, Sc, shadow, B.out[f], nullptr, stk, keys, lane, slot);
 }
