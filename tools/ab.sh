@@ -7,6 +7,7 @@ run() {
   local name=$1; shift
   local out
   out=$(RTO_HIP_LIB=$LIB python3 bench.py --cpu-frames 0 --orbit-frames 0 "$@" 2>&1 | tail -1)
+  case "$out" in *"GPU core dump"*|*"Memory access fault"*) echo "$name: GPU FAULT -- stopping: $out"; exit 1;; esac
   python3 - "$name" "$out" <<'PY'
 import json, sys
 try:
