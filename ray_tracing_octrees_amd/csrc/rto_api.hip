@@ -1331,14 +1331,6 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     return RTO_OK;
 }
 
-// Resident waves per SIMD of a lean octree launch, set through its dynamic LDS request (4-wave workgroups: workgroups per CU ==
-// waves per SIMD).  With the occupancy mask a frame has fewer waves with work than the machine has wave slots at 6 per SIMD
-// (config 2: ~5,800 against 6,144): all of them would be resident from the first microsecond, statically spread, and the
-// frame would end when the unluckiest SIMD ends (timeline: SIMD totals of 91 +- 30 loop trips, last SIMD at 42 us, mean 29).
-// At 4 per SIMD the last third of the waves is handed out as slots free up -- to whichever SIMD is done first: config 2, one
-// frame per launch: 44.9 -> 38.9 us.  (Measured: a request of 32 KB and one of 40 KB give the same occupancy and time -- the
-// CU hands its LDS out in two halves --, 53 KB gives 2 per SIMD: 46.7 us.)  Launches of several frames have waves to spare and
-// keep 6.  RTO_WAVES_PER_SIMD=<n> overrides (A/B runs); 0 = never pad.
 // Threads per workgroup of the lean kernels (path 0: octree frames, 1: triangle frames; single and batch forms).  Their waves
 // share nothing but the launch, so a workgroup is only a unit of dispatch: the dispatcher places a workgroup when ALL its waves
 // fit, and with 4-wave workgroups a CU's wave slots stand empty until four are free at once (config 5's timeline: ~4,300 of
@@ -1350,10 +1342,18 @@ static int lean_block(int path) {
     static const int b[2] = {
         []() { const char* e = std::getenv("RTO_LEAN_BLOCK"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 256; }(),
         []() { const char* e = std::getenv("RTO_TRI_BLOCK"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 64; }() };
-    return b[path ? 1 : 0];
+    return b[path == 1 ? 1 : 0];
 }
 static int lean_wpb(int path) { return lean_block(path) / kWave; }
 
+// Resident waves per SIMD of a lean octree launch, set through its dynamic LDS request (4-wave workgroups: workgroups per CU ==
+// waves per SIMD).  With the occupancy mask a frame has fewer waves with work than the machine has wave slots at 6 per SIMD
+// (config 2: ~5,800 against 6,144): all of them would be resident from the first microsecond, statically spread, and the
+// frame would end when the unluckiest SIMD ends (timeline: SIMD totals of 91 +- 30 loop trips, last SIMD at 42 us, mean 29).
+// At 4 per SIMD the last third of the waves is handed out as slots free up -- to whichever SIMD is done first: config 2, one
+// frame per launch: 44.9 -> 38.9 us.  (Measured: a request of 32 KB and one of 40 KB give the same occupancy and time -- the
+// CU hands its LDS out in two halves --, 53 KB gives 2 per SIMD: 46.7 us.)  Launches of several frames have waves to spare and
+// keep 6.  RTO_WAVES_PER_SIMD=<n> overrides (A/B runs); 0 = never pad.
 static size_t lds_for_occupancy(size_t lds, int wavesDefault) {
     static const int forced = []() { const char* e = std::getenv("RTO_WAVES_PER_SIMD"); return e ? std::atoi(e) : -1; }();
     const int waves = forced >= 0 ? forced : wavesDefault;
@@ -2138,7 +2138,13 @@ static int launch_skip_render(rto_context* c, const rto_frame* f, const rto_part
     const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint4);
     if (lds > 64 * 1024) return fail(c, RTO_E_UNSUPPORTED, "rto_render_skip: octree too deep for the LDS frames");
     const uint8_t* vis = (use_visibility && c->culling) ? c->d_vis : nullptr;
-    const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
+    // launch geometry, launch order and occupancy mask of the first-hit frames (path 2: tables of its own kind on the stream)
+    rto_context::OrderState* st = nullptr;
+    const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
+    if ((rc = prepare_schedule(c, s, stream_is_capturing(s), true, false, 2, solidRect, P, &st, 0)) != RTO_OK) return rc;
+    const int blocks = (P.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave) + P.maskBlocks;
+    if (c->maskMode == 2 && P.maskBlocks > 0)
+        hipLaunchKernelGGL(k_skip_render, dim3(P.maskBlocks), dim3(kBlock), lds, s, P, c->d_desc, vis, vis ? 1 : 0, d_rgba, d_dist);
     hipLaunchKernelGGL(k_skip_render, dim3(blocks), dim3(kBlock), lds, s, P, c->d_desc, vis, vis ? 1 : 0, d_rgba, d_dist);
     RTO_HIP(c, hipGetLastError());
     return RTO_OK;

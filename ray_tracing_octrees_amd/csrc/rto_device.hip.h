@@ -651,9 +651,8 @@ __device__ __forceinline__ void mask_block(const RenderParams& P, int blockInFra
 
 // The fill duty of launch slot `slot`: chunks slot, slot + launchWaves, ... of the region outside the root rectangle.
 // Every pixel there is black after the root's pop (S/RT:254-270, :363): (0,0,0,1), or kShadeMiss in the shade buffer.
-template <int MODE>
-__device__ __forceinline__ void fill_outside(const RenderParams& P, float4* __restrict__ out, int lane, int slot) {
-    if (!(MODE == kModeColor || MODE == kModeShade || MODE == kModeTimeline) || !P.skipOutside) return;
+template <class F>
+__device__ __forceinline__ void for_each_outside_pixel(const RenderParams& P, int lane, int slot, F&& body) {
     const int per = P.fillLeftPer + P.fillRightPer;
     for (int c = slot; c < P.fillChunks; c += P.launchWaves) {            // wave-uniform
         size_t pix;
@@ -672,11 +671,16 @@ __device__ __forceinline__ void fill_outside(const RenderParams& P, float4* __re
             else { x = P.fillRightX0 + (k - P.fillLeftPer) * kWave + lane; ok = x < P.W; }
             pix = (size_t)(P.fillTopRows + row) * P.W + x;
         }
-        if (ok) {
-            if (MODE == kModeShade) __builtin_nontemporal_store(kShadeMiss, reinterpret_cast<float*>(out) + pix);
-            else store_pixel(out + pix, make_float4(0.f, 0.f, 0.f, 1.f));
-        }
+        if (ok) body(pix);
     }
+}
+template <int MODE>
+__device__ __forceinline__ void fill_outside(const RenderParams& P, float4* __restrict__ out, int lane, int slot) {
+    if (!(MODE == kModeColor || MODE == kModeShade || MODE == kModeTimeline) || !P.skipOutside) return;
+    for_each_outside_pixel(P, lane, slot, [&](size_t pix) {
+        if (MODE == kModeShade) __builtin_nontemporal_store(kShadeMiss, reinterpret_cast<float*>(out) + pix);
+        else store_pixel(out + pix, make_float4(0.f, 0.f, 0.f, 1.f));
+    });
 }
 
 // hipcc does not fold fmax(fmax(a,b),c) into v_max3_f32 when a, b, c are themselves min/max results (it cannot
@@ -2480,7 +2484,8 @@ __device__ __forceinline__ SkipRay skip_ray(float ox, float oy, float oz, float 
 // returns the distance (1e30: nothing); on a hit lx, ly, lz, ls = the solid leaf's position and edge
 __device__ __forceinline__ float skip_traverse(const uint2* __restrict__ desc, const uint8_t* __restrict__ vis, bool useVis, int rootSize,
                                                float gx, float gy, float gz, float vs, const SkipRay& r, float tMin0, float tMax0,
-                                               uint4* stk /* this lane's column: entry(L) = stk[L * 64] */, int& lx, int& ly, int& lz, int& ls) {
+                                               uint4* stk /* this lane's column: entry(L) = stk[L * 64] */, int& lx, int& ly, int& lz, int& ls,
+                                               int* visits = nullptr /* internal nodes entered (the render mode's tile cost) */) {
     // interval of the box (bx, by, bz) of edge `size`, clipped by [pe, px]: the operations of S/VR:70-100
     auto interval = [&](int bx, int by, int bz, int size, float pe, float px, float& enterT, float& exitT) {
         float tNx, tFx, tNy, tFy, tNz, tFz;
@@ -2500,6 +2505,7 @@ __device__ __forceinline__ float skip_traverse(const uint2* __restrict__ desc, c
     unsigned cur = 0;
     for (;;) {
         {   // enter the internal node `cur` at (cx, cy, cz), depth `level`, interval [e, x]
+            if (visits) ++*visits;
             const uint2 d = desc[cur];
             const int half = rootSize >> (level + 1);
             const unsigned sm = d.x & 0xffu, im = (d.x >> 8) & 0xffu, vm = useVis ? ((d.x >> 16) & 0xffu) : 0xffu;
@@ -2554,31 +2560,55 @@ __global__ __launch_bounds__(kBlock) void k_skip_render(RenderParams P, const ui
     extern __shared__ uint4 lds_skip[];    // [wave][level][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint4* stk = lds_skip + (size_t)wave * P.depth * kWave + lane;
-    const int tile = blockIdx.x * (kBlock / kWave) + wave;
-    const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+    // launch geometry of the lean kernels: the first workgroups build the occupancy mask, waves only for the tiles of the solid
+    // geometry's screen rectangle in the stream's launch order (costliest tiles of earlier frames first), wide stores for the rest
+    if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x); return; }
+    const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (kBlock / kWave) + wave);
+    if (slot >= P.launchWaves) return;
+    int tile, tx, ty;
+    resolve_slot(P, slot, tx, ty, tile);
     const int px = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
     const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
     const int py = global_row(P, ly);
-    if (!(valid && py < P.H)) return;
+    const bool inImage = valid && py < P.H;
+    // outside the solid leaves' screen rectangle (widened by a voxel) no ray meets a solid leaf: the search returns 1e30
+    const bool outside = px < P.rootX0 || px > P.rootX1 || py < P.rootY0 || py > P.rootY1;
     const Geo G = geo_of(P);
-    const Ray g = generate_ray_tab(P, px, py);
-    const SkipRay r = skip_ray(g.ox, g.oy, g.oz, g.dx, g.dy, g.dz);
-    int lx = 0, lyy = 0, lz = 0, ls = 0;
-    const float t = skip_traverse(desc, vis, useVis != 0, P.rootSize, G.gx, G.gy, G.gz, G.vs, r, 0.0f, 1e30f, stk, lx, lyy, lz, ls);
-    const size_t pix = (size_t)ly * P.W + px;
-    if (outT) outT[pix] = t;
-    if (outRGBA) {
-        float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
-        if (t < 1e30f) {
-            const float mnx = G.gx + (float)lx * G.vs, mny = G.gy + (float)lyy * G.vs, mnz = G.gz + (float)lz * G.vs;
-            const float ext = (float)ls * G.vs;
-            const float cx = 0.5f * (mnx + (mnx + ext)), cy = 0.5f * (mny + (mny + ext)), cz = 0.5f * (mnz + (mnz + ext));
-            const float qx = (g.ox + g.dx * t) - cx, qy = (g.oy + g.dy * t) - cy, qz = (g.oz + g.dz * t) - cz;
-            const float inv = inversesqrt(qx * qx + qy * qy + qz * qz);
-            color = shade_color(gmax(0.0f, (qx * inv) * P.lightNeg[0] + (qy * inv) * P.lightNeg[1] + (qz * inv) * P.lightNeg[2]));
-        }
-        store_pixel(outRGBA + pix, color);
+    float t = 1e30f;
+    int lx = 0, lyy = 0, lz = 0, ls = 0, visits = 0;
+    Ray g;
+    g.ox = g.oy = g.oz = g.dx = g.dy = g.dz = 0.0f;
+    if (inImage && !outside && tile_may_hit(P, tx, ty, slot)) {
+        g = generate_ray_tab(P, px, py);
+        const SkipRay r = skip_ray(g.ox, g.oy, g.oz, g.dx, g.dy, g.dz);
+        t = skip_traverse(desc, vis, useVis != 0, P.rootSize, G.gx, G.gy, G.gz, G.vs, r, 0.0f, 1e30f, stk, lx, lyy, lz, ls, &visits);
     }
+    if (P.tileCost) {                                                    // this tile's cost for the launch order: the visits of its busiest ray
+        int cst = visits;
+        for (int off = 32; off > 0; off >>= 1) cst = max(cst, __shfl_xor(cst, off));
+        if (lane == 0 && ty < P.tilesY) P.tileCost[tile] = cst;
+    }
+    if (inImage && !(P.skipOutside && outside)) {
+        const size_t pix = (size_t)ly * P.W + px;
+        if (outT) __builtin_nontemporal_store(t, outT + pix);
+        if (outRGBA) {
+            float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
+            if (t < 1e30f) {
+                const float mnx = G.gx + (float)lx * G.vs, mny = G.gy + (float)lyy * G.vs, mnz = G.gz + (float)lz * G.vs;
+                const float ext = (float)ls * G.vs;
+                const float cx = 0.5f * (mnx + (mnx + ext)), cy = 0.5f * (mny + (mny + ext)), cz = 0.5f * (mnz + (mnz + ext));
+                const float qx = (g.ox + g.dx * t) - cx, qy = (g.oy + g.dy * t) - cy, qz = (g.oz + g.dz * t) - cz;
+                const float inv = inversesqrt(qx * qx + qy * qy + qz * qz);
+                color = shade_color(gmax(0.0f, (qx * inv) * P.lightNeg[0] + (qy * inv) * P.lightNeg[1] + (qz * inv) * P.lightNeg[2]));
+            }
+            store_pixel(outRGBA + pix, color);
+        }
+    }
+    if (P.skipOutside)
+        for_each_outside_pixel(P, lane, slot, [&](size_t pix) {
+            if (outT) __builtin_nontemporal_store(1e30f, outT + pix);
+            if (outRGBA) store_pixel(outRGBA + pix, make_float4(0.f, 0.f, 0.f, 1.f));
+        });
 }
 
 // octreeRaySkip's consumer in drawRaycast (S/VR:1602-1663) in ONE launch of one wave, nothing copied: lane i < 49 makes the
