@@ -9,7 +9,7 @@ for c in 2 4 5; do
   [ -f $D/summary.json ] || { echo "no $D/summary.json"; continue; }
   cp $D/summary.json profiles/${TAG}_config${c}_summary.json
   cp $D/bench.json profiles/${TAG}_config${c}_bench.json
-  cp $(ls $D/trace/*/*_kernel_stats.csv | head -1) profiles/${TAG}_config${c}_kernel_stats.csv
+  cp $(ls -t $D/trace/*/*_kernel_stats.csv | head -1) profiles/${TAG}_config${c}_kernel_stats.csv
   if [ $c = 5 ]; then K1=k_trace_lean_triangles; K4=k_trace_lean_triangles_batch; else K1=k_trace_lean; K4=k_trace_lean_batch; fi
   python3 tools/pmc_entry.py profiles/${TAG}_config${c}_summary.json $c $K1 temporal profiles/${TAG}_config${c}_summary.json 1
   python3 tools/pmc_entry.py profiles/${TAG}_config${c}_summary.json $c $K4 temporal profiles/${TAG}_config${c}_summary.json 4
