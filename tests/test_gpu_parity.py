@@ -540,11 +540,16 @@ def test_occupancy_mask_never_changes_pixels_and_removes_work(ctx, orc, scenes):
             view, pos = cam.get_view(), cam.get_pos()
             f = rto.make_frame(view, pos, W / H, fov, W, H)
             want, st = oracle_frame(orc, s, view, pos, W, H, fov=fov)
+            near_rgba, near_t = orc.render_skip(s.nodes, s.min, s.voxel, view, pos, W / H, fov, W, H, nthreads=min(8, orc.max_threads()))
             for on in (2, 1, 0):
                 ctx.debug_set_tile_mask(on)
                 for _ in range(2):
                     got = ctx.render_host(f)
                 assert_bit_exact(got, want, f"{scene} cam {(t, p, r, tgt, fov)} mask mode {on}")
+                for _ in range(3):                               # the nearest-hit mode shares the launch geometry, the mask and the order tables
+                    nrgba, nt = ctx.render_skip_host(f)
+                assert nt.tobytes() == near_t.tobytes(), f"{scene} cam {(t, p, r, tgt, fov)} nearest-hit distances, mask mode {on}"
+                assert_bit_exact(nrgba, near_rgba, f"{scene} cam {(t, p, r, tgt, fov)} nearest-hit colours, mask mode {on}")
                 out = torch.full((2, H, W, 4), 7.0, dtype=torch.float32, device="cuda")          # the batch kernel and a 3-way partition too
                 ctx.render_batch_device(hip.Context.frame_array([f, f]), out.data_ptr(), out.stride(0) * 4, None, False, 0)
                 torch.cuda.synchronize()
