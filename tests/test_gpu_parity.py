@@ -107,6 +107,13 @@ def test_fuzz_random_scenes_and_cameras(ctx, orc, seed):
             np.testing.assert_array_equal(ctx.render_steps(f), steps, err_msg=what)
             gs = ctx.frame_stats(f)
             assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"]), what
+        # the nearest-hit render mode (octreeRaySkip per pixel) on the same frame
+        ctx.set_kernel(rto.KERNEL_AUTO)
+        nrgba, nt = orc.render_skip(s.nodes, s.min, s.voxel, view, pos, aspect, fov, W, H)
+        for _ in range(2):
+            grgba, gt_ = ctx.render_skip_host(f)
+        assert gt_.tobytes() == nt.tobytes(), f"seed {seed} {kind} {g.dims} {W}x{H} fov {fov}: nearest-hit distances"
+        assert_bit_exact(grgba, nrgba, f"seed {seed} {kind} nearest-hit colours")
         if shot == 0:
             tris, off = orc.build_leaf_triangles(s.grid, s.nodes)
             ctx.build_leaf_triangles(g.data)                            # GPU builder == oracle's buffer, then render from it
