@@ -2457,7 +2457,40 @@ __global__ __launch_bounds__(kBlock) void k_octree_ray_skip_packed(const uint2* 
 // Entry of the node at depth L (children of edge rootSize >> (L + 1)):
 //   .x = untried candidates in TRAVERSAL order (8) | solid mask << 8 | internal mask << 16    .y = first internal child
 //   .z / .w = the node's clipped interval [enterT, exitT]
-struct SkipRay { float ox, oy, oz, ix, iy, iz; unsigned order; unsigned sx, sy, sz; bool finite; };
+struct SkipRay { float ox, oy, oz, ix, iy, iz; unsigned order; unsigned sx, sy, sz; bool finite; int dirMask; };
+
+// Child order of octreeRaySkip as a table: for the octant of the ray's positive direction bits (dirMask) and a mask of
+// candidate children, the same candidates with bit p = the p-th child in the reference's order (Hamming distance from dirMask,
+// ties by octant index: S/VR:122-131).  8 x 256 bytes, copied into LDS by the kernels that walk (one ds_read_u8 per visited
+// node instead of 27 VALU instructions of shifts and masks).
+struct SkipPermTable { unsigned char v[8 * 256]; };
+constexpr SkipPermTable make_skip_perm_table() {
+    SkipPermTable t{};
+    for (int m = 0; m < 8; m++) {
+        int order[8] = {};
+        int p = 0;
+        for (int dist = 0; dist <= 3; dist++)
+            for (int o = 0; o < 8; o++) {
+                int diff = o ^ m, bits = 0;
+                while (diff) { bits += diff & 1; diff >>= 1; }
+                if (bits == dist) order[p++] = o;
+            }
+        for (int cand = 0; cand < 256; cand++) {
+            unsigned om = 0;
+            for (int q = 0; q < 8; q++) om |= (unsigned)((cand >> order[q]) & 1) << q;
+            t.v[m * 256 + cand] = (unsigned char)om;
+        }
+    }
+    return t;
+}
+__device__ const SkipPermTable kSkipPerm = make_skip_perm_table();
+
+// copies the table into `lut` (2 KB of LDS); every thread of the workgroup calls it, then the workgroup synchronises
+__device__ __forceinline__ void load_skip_perm(unsigned char* lut) {
+    const uint2* src = reinterpret_cast<const uint2*>(kSkipPerm.v);
+    uint2* dst = reinterpret_cast<uint2*>(lut);
+    for (int i = (int)threadIdx.x; i < 8 * 256 / 8; i += (int)blockDim.x) dst[i] = src[i];
+}
 
 __device__ __forceinline__ SkipRay skip_ray(float ox, float oy, float oz, float dx, float dy, float dz) {
     SkipRay r;
@@ -2476,6 +2509,7 @@ __device__ __forceinline__ SkipRay skip_ray(float ox, float oy, float oz, float 
         for (int o = 0; o < 8; o++)
             if (__builtin_popcount(o ^ dirMask) == dist) { order |= (unsigned)o << (3 * p); p++; }
     r.order = order;
+    r.dirMask = dirMask;
     r.sx = (unsigned)((int)__float_as_uint(r.ix) >> 31); r.sy = (unsigned)((int)__float_as_uint(r.iy) >> 31); r.sz = (unsigned)((int)__float_as_uint(r.iz) >> 31);
     r.finite = __builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) && __builtin_isfinite(ox) && __builtin_isfinite(oy) && __builtin_isfinite(oz);
     return r;
@@ -2485,7 +2519,8 @@ __device__ __forceinline__ SkipRay skip_ray(float ox, float oy, float oz, float 
 __device__ __forceinline__ float skip_traverse(const uint2* __restrict__ desc, const uint8_t* __restrict__ vis, bool useVis, int rootSize,
                                                float gx, float gy, float gz, float vs, const SkipRay& r, float tMin0, float tMax0,
                                                uint4* stk /* this lane's column: entry(L) = stk[L * 64] */, int& lx, int& ly, int& lz, int& ls,
-                                               int* visits = nullptr /* internal nodes entered (the render mode's tile cost) */) {
+                                               int* visits = nullptr /* internal nodes entered (the render mode's tile cost) */,
+                                               const unsigned char* perm = nullptr /* kSkipPerm in LDS, or NULL */) {
     // interval of the box (bx, by, bz) of edge `size`, clipped by [pe, px]: the operations of S/VR:70-100
     auto interval = [&](int bx, int by, int bz, int size, float pe, float px, float& enterT, float& exitT) {
         float tNx, tFx, tNy, tFy, tNz, tFz;
@@ -2494,6 +2529,28 @@ __device__ __forceinline__ float skip_traverse(const uint2* __restrict__ desc, c
         skip_interval(gz, vs, r.oz, r.iz, bz, size, tNz, tFz);
         enterT = gmax(gmax(tNx, tNy), gmax(tNz, pe));
         exitT = gmin(gmin(tFx, tFy), gmin(tFz, px));
+    };
+    // The same interval for finite rays in a third of the instructions: per axis the smaller / larger of (t1, t2) SELECTED by the
+    // sign of the reciprocal (hi >= lo and the operations are monotonic: the same float, see child_axis_terms), the 4-way
+    // max / min as v_max3 + v_max.  The hardware's max / min differ from the reference's (a < b) ? b : a only in the sign of
+    // a zero result, and only enterT is ever handed out: a zero enterT is recomputed with the reference's form.
+    auto interval_fast = [&](int bx, int by, int bz, int size, float pe, float px, float& enterT, float& exitT) {
+        const float wSize = (float)size * vs;
+        float n[3], f[3];
+        const float g3[3] = { gx, gy, gz }, o3[3] = { r.ox, r.oy, r.oz }, i3[3] = { r.ix, r.iy, r.iz };
+        const unsigned s3[3] = { r.sx, r.sy, r.sz };
+        const int b3[3] = { bx, by, bz };
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float w0 = g3[a] + (float)b3[a] * vs;
+            const unsigned t1 = __float_as_uint((w0 - o3[a]) * i3[a]), t2 = __float_as_uint(((w0 + wSize) - o3[a]) * i3[a]);
+            n[a] = __uint_as_float(bop3<kSelC>(t1, t2, s3[a])); f[a] = __uint_as_float(bop3<kSelC>(t2, t1, s3[a]));
+        }
+        float en, ex;
+        asm("v_max_f32 %0, %1, %2" : "=v"(en) : "v"(max3f(n[0], n[1], n[2])), "v"(pe));
+        asm("v_min_f32 %0, %1, %2" : "=v"(ex) : "v"(min3f(f[0], f[1], f[2])), "v"(px));
+        enterT = en; exitT = ex;
+        if (en == 0.0f) interval(bx, by, bz, size, pe, px, enterT, exitT);      // rare: the sign of the zero is the reference's
     };
     float e, x;
     interval(0, 0, 0, rootSize, tMin0, tMax0, e, x);
@@ -2530,8 +2587,11 @@ __device__ __forceinline__ float skip_traverse(const uint2* __restrict__ desc, c
             }
             const unsigned cand = pass & vm & (sm | im);
             unsigned om = 0;
+            if (perm) om = perm[r.dirMask * 256 + (int)cand];
+            else {
 #pragma unroll
-            for (int p = 0; p < 8; p++) om |= ((cand >> ((r.order >> (3 * p)) & 7u)) & 1u) << p;
+                for (int p = 0; p < 8; p++) om |= ((cand >> ((r.order >> (3 * p)) & 7u)) & 1u) << p;
+            }
             stk[level * kWave] = make_uint4(om | (sm << 8) | (im << 16), d.y, __float_as_uint(e), __float_as_uint(x));
             pend = (pend & ~(1u << level)) | (om ? (1u << level) : 0u);
         }
@@ -2546,7 +2606,8 @@ __device__ __forceinline__ float skip_traverse(const uint2* __restrict__ desc, c
         const int edge = rootSize >> L, half = edge >> 1;                // the node at depth L and its children
         const int nx = cx & ~(edge - 1), ny = cy & ~(edge - 1), nz = cz & ~(edge - 1);
         const int bx = nx + ((k & 1) ? half : 0), by = ny + ((k & 2) ? half : 0), bz = nz + ((k & 4) ? half : 0);
-        interval(bx, by, bz, half, __uint_as_float(en.z), __uint_as_float(en.w), e, x);
+        if (allFinite) interval_fast(bx, by, bz, half, __uint_as_float(en.z), __uint_as_float(en.w), e, x);
+        else interval(bx, by, bz, half, __uint_as_float(en.z), __uint_as_float(en.w), e, x);
         if ((en.x >> (8 + k)) & 1u) { lx = bx; ly = by; lz = bz; ls = half; return e; }      // solid leaf: finite, every ancestor returns it (S/VR:146-149)
         cur = en.y + (unsigned)__builtin_popcount((en.x >> 16) & 0xffu & ((1u << k) - 1u));
         cx = bx; cy = by; cz = bz; level = L + 1;
@@ -2560,6 +2621,9 @@ __global__ __launch_bounds__(kBlock) void k_skip_render(RenderParams P, const ui
     extern __shared__ uint4 lds_skip[];    // [wave][level][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint4* stk = lds_skip + (size_t)wave * P.depth * kWave + lane;
+    __shared__ unsigned char permLut[8 * 256];
+    load_skip_perm(permLut);
+    __syncthreads();                                                     // before any wave leaves
     // launch geometry of the lean kernels: the first workgroups build the occupancy mask, waves only for the tiles of the solid
     // geometry's screen rectangle in the stream's launch order (costliest tiles of earlier frames first), wide stores for the rest
     if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x); return; }
@@ -2581,7 +2645,7 @@ __global__ __launch_bounds__(kBlock) void k_skip_render(RenderParams P, const ui
     if (inImage && !outside && tile_may_hit(P, tx, ty, slot)) {
         g = generate_ray_tab(P, px, py);
         const SkipRay r = skip_ray(g.ox, g.oy, g.oz, g.dx, g.dy, g.dz);
-        t = skip_traverse(desc, vis, useVis != 0, P.rootSize, G.gx, G.gy, G.gz, G.vs, r, 0.0f, 1e30f, stk, lx, lyy, lz, ls, &visits);
+        t = skip_traverse(desc, vis, useVis != 0, P.rootSize, G.gx, G.gy, G.gz, G.vs, r, 0.0f, 1e30f, stk, lx, lyy, lz, ls, &visits, permLut);
     }
     if (P.tileCost) {                                                    // this tile's cost for the launch order: the visits of its busiest ray
         int cst = visits;
@@ -2622,7 +2686,12 @@ __global__ __launch_bounds__(kWave) void k_probe_skip(ProbeParams Q, const uint2
     extern __shared__ uint4 lds_skip[];
     const int lane = threadIdx.x;
     uint4* stk = lds_skip + lane;
+    __shared__ unsigned char permLut[8 * 256];
+    // the table's 2 KB: 32 bytes per lane, fetched first and stored after the ray set-up (a launch's first loads are its slowest)
+    const uint4 lutA = reinterpret_cast<const uint4*>(kSkipPerm.v)[lane * 2], lutB = reinterpret_cast<const uint4*>(kSkipPerm.v)[lane * 2 + 1];
+    const uint2 rootDesc = desc[0];                                       // warms the root's line while the rays are set up
     float t = 1e30f;
+    SkipRay r = skip_ray(0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
     if (lane < 49) {
         const int gridSize = 7;
         const float sampleOffset = 0.2f;
@@ -2640,9 +2709,14 @@ __global__ __launch_bounds__(kWave) void k_probe_skip(ProbeParams Q, const uint2
         for (int rr = 0; rr < 4; rr++) wp[rr] = (Q.invV[rr] * vp[0] + Q.invV[4 + rr] * vp[1]) + (Q.invV[8 + rr] * vp[2] + Q.invV[12 + rr] * vp[3]);
         const float qx = wp[0] - Q.eye[0], qy = wp[1] - Q.eye[1], qz = wp[2] - Q.eye[2];
         const float inv = inversesqrt(qx * qx + qy * qy + qz * qz);
-        const SkipRay r = skip_ray(Q.eye[0], Q.eye[1], Q.eye[2], qx * inv, qy * inv, qz * inv);
+        r = skip_ray(Q.eye[0], Q.eye[1], Q.eye[2], qx * inv, qy * inv, qz * inv);
+    }
+    reinterpret_cast<uint4*>(permLut)[lane * 2] = lutA; reinterpret_cast<uint4*>(permLut)[lane * 2 + 1] = lutB;
+    asm volatile("" :: "v"(rootDesc.x), "v"(rootDesc.y));
+    __syncthreads();
+    if (lane < 49) {
         int a, b, cc, dd;
-        t = skip_traverse(desc, vis, useVis != 0, Q.rootSize, Q.gx, Q.gy, Q.gz, Q.vs, r, 0.0f, 1e30f, stk, a, b, cc, dd);
+        t = skip_traverse(desc, vis, useVis != 0, Q.rootSize, Q.gx, Q.gy, Q.gz, Q.vs, r, 0.0f, 1e30f, stk, a, b, cc, dd, nullptr, permLut);
         if (probeT) probeT[lane] = t;
     }
     const bool ok = lane < 49 && t < 1e30f && t > 0.0f;                  // S/VR:1640-1642
