@@ -84,7 +84,7 @@ struct rto_context {
         bool costValid = false;         // a frame of this geometry has recorded its costs
         bool fixed = false;             // debug: the caller supplied the table (over ALL tiles), do not rebuild it
         int* d_queue = nullptr;         // persistent-threads variant: the slot counter (zeroed in front of every launch)
-        unsigned* d_tileMask = nullptr; // occupancy masks of the frames of one launch: kMaxBatch regions of maskWords words (k_tile_mask)
+        unsigned* d_tileMask = nullptr; // occupancy masks of the frames of one launch: kMaxBatch regions of maskWords words (mask_block)
         size_t maskWords = 0;           // strips * tilesX + 1 of the frame size the buffer was made for
         unsigned long lastUse = 0;      // orderClock value of the last launch on this stream (eviction order)
     };
@@ -94,7 +94,7 @@ struct rto_context {
     unsigned long orderClock = 0;
     int* d_sortViolations = nullptr;            // k_sort_scatter: out-of-range writes refused (must stay 0; rto_debug_sort_violations)
 
-    // occupancy mask: the coarse cells of the tree at level cellLevel, projected per frame by k_tile_mask
+    // occupancy mask: the coarse cells of the tree at level cellLevel, projected per frame by the launch's first workgroups (mask_block)
     int4* d_cells = nullptr;
     int numCells = 0, cellLevel = 0;
     unsigned maskStamp = 0;                     // one fresh value per frame launched

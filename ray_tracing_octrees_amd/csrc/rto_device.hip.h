@@ -105,7 +105,7 @@ struct RenderParams {
     const float* rayX;              // [W]  ((px+.5)/W*2-1)*aspect*tanHalfFov, the separable part of S/RT:341-346 (host-computed)
     const float* rayY;              // [H]  (1-(py+.5)/H*2)*tanHalfFov
     const StartState* start;        // non-null while a frustum update is active on a canonical tree: replaces rootVisible / the root as start node (lean kernels)
-    // Screen-space occupancy mask (k_tile_mask, launched in front of a colour / shade frame of the lean kernels): one word per
+    // Screen-space occupancy mask (mask_block, run by the first workgroups of a colour / shade launch of the lean kernels): one word per
     // 8x8 tile in GLOBAL image rows ([strip = row / 8][tx]); a tile whose word differs from maskStamp -- and with the "whole frame"
     // word at maskAllIndex also different -- cannot contain a ray that meets a solid leaf: its wave stores black and does nothing else.
     unsigned* tileMask;             // null: no mask (instrumented frames, A/B kernels, non-canonical arrays)

@@ -525,7 +525,7 @@ def test_frustum_update_reads_nothing_back_and_can_be_captured(ctx, orc, scenes,
 
 
 def test_occupancy_mask_never_changes_pixels_and_removes_work(ctx, orc, scenes):
-    """The occupancy mask (k_tile_mask in front of every colour / shade frame of the default kernels) is a scheduling device:
+    """The occupancy mask (mask_block: built by the first workgroups of every colour / shade launch of the default kernels) is a scheduling device:
     frames with it, without it and the oracle's are bit-identical -- cameras outside, grazing, far away, with the scene partly
     or wholly off the screen, and inside the geometry (cells around the eye: the "whole frame" word) -- while the number of
     tiles whose wave walks the tree drops to little more than the tiles that contain a hit."""
