@@ -2,6 +2,7 @@
 // Host side: argument checks, the canonical-octree repack, uniform hoisting
 // (inverse(view), tan(fov/2), frustum planes) and kernel launches.  No torch, no
 // oracle, no CPU fallback: every entry point needs a gfx950 device.
+#include <chrono>
 #include "rto_device.hip.h"
 static int lean_block(int path);
 
@@ -401,7 +402,17 @@ struct BuildScratch {
 // occupancy mask -- the deepest level whose cells (internal nodes at that depth + solid leaves at or above it) number at most
 // kMaskMaxCells.
 constexpr int kMaskMaxCells = 8192;      // config 2: 5,624 cells (depth 5) serve as well as 20,504 (depth 6): 38.7 us either way; projecting them costs a quarter
+static int build_cells_impl(rto_context* c);
 static int build_cells(rto_context* c) {
+    static const bool trace = std::getenv("RTO_BUILD_TRACE") != nullptr;     // developer aid: host time of this step, on stderr
+    if (!trace) return build_cells_impl(c);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = build_cells_impl(c);
+    std::fprintf(stderr, "[rto] derived data of the octree (descPos, occupancy cells): %.3f ms of host time\n",
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return rc;
+}
+static int build_cells_impl(rto_context* c) {
     (void)hipFree(c->d_descPos); c->d_descPos = nullptr;
     (void)hipFree(c->d_cells); c->d_cells = nullptr; c->numCells = 0; c->cellLevel = 0;
     if (!c->canonical || c->numInternal <= 0) return RTO_OK;

@@ -51,8 +51,9 @@ for name in ("sphere256", "sphere512", "calgary"):
     W, H = 1920, 1080
     aspect = W / H
     f = rto.make_frame(view, pos, aspect, 45.0, W, H)
-    print(f"{name}: {ctx.info().num_nodes} nodes; rto_build_octree wall {min(ws[1:]) * 1e3:.3f} ms (pyramid + emission kernels {k:.3f} ms, H2D {u:.3f} ms; the rest: "
-          f"descPos + occupancy cells [level {lv}, {nc} cells] and their two read-backs)")
+    print(f"{name}: {ctx.info().num_nodes} nodes; rto_build_octree wall {min(ws[1:]) * 1e3:.3f} ms (pyramid + emission kernels {k:.3f} ms, H2D {u:.3f} ms; the rest: freeing the previous "
+          f"octree's buffers and allocating this one's; the derived data -- descPos, occupancy cells [level {lv}, {nc} cells], two small read-backs -- "
+          f"take 0.07-0.09 ms of it: RTO_BUILD_TRACE=1)")
     ctx.update_frustum(view, 45.0, aspect, True)
     us = per_call_us(lambda: ctx.update_frustum(view, 45.0, aspect, True), ctx.synchronize, 100)
     print(f"  rto_update_frustum: {us:.1f} us per call (100 back-to-back, best of 3 bursts; nothing read back; one kernel)")
