@@ -275,6 +275,7 @@ def main(argv=None):
         args.graph_frames = 0          # plain launches without per-launch events beat the graph replay at every K (tools/steps_sweep.sh: K = 20: 0.0405 vs 0.0435 ms)
     if args.rehearse_world > 1:
         args.no_verify, args.cpu_frames, args.force_comm = True, 0, True     # the assembled frames hold one rank's bands only
+        os.environ.setdefault("RTO_REHEARSE_NO_CLEAR", "1")                  # the per-batch clear of the absent ranks' rows is test scaffolding, not a rank's work
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         sys.exit(self_launch(args, argv))

@@ -1244,6 +1244,14 @@ static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, bool 
 // path): waves for the tiles of `rect`'s box only, the outside shared out as fill chunks, the box's tiles in the order of
 // the costs earlier frames recorded.  frameMode: a colour / shade frame (records costs); otherwise (instrumentation) the
 // whole image keeps one wave per tile.  On return Q holds the geometry, the table and the cost pointer.
+// The occupancy mask serves frames cut into at most this many parts: a part's launch projects every cell for its share of the
+// rows, which pays as long as the share is not too small -- a rank of the screen split, per frame: 2 GPUs 28.1 -> 25.6 us, 4 GPUs
+// 21.9 -> 20.2, 8 GPUs (7 rendering parts) 14.4 -> 14.3.  RTO_MASK_PARTS_MAX overrides (A/B runs; 1: whole frames only).
+static int mask_parts_max() {
+    static const int v = []() { const char* e = std::getenv("RTO_MASK_PARTS_MAX"); return e ? std::atoi(e) : 8; }();
+    return v;
+}
+
 static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool frameMode, bool timelineMode, int path, const int rect[4],
                             RenderParams& Q, rto_context::OrderState** stOut, int maskRegion = -1) {
     const RenderParams& P = Q;
@@ -1254,10 +1262,9 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     *stOut = st;
     // occupancy mask (maskRegion >= 0: the caller launches a lean kernel; its first maskBlocks workgroups build the mask: mask_block)
     Q.tileMask = nullptr; Q.maskBlocks = 0;
-    // (whole frames only: a rank of the multi-GPU split would project every cell for a seventh of the rows -- rehearsed at 8 GPUs the
-    //  mask cost a rendering rank 16.1 us per frame against 13.2 without)
+    // (frames in up to mask_parts_max() parts: the ranks of the multi-GPU split included)
     if (st && maskRegion >= 0 && (frameMode || timelineMode) && c->maskMode != 0 && c->numCells > 0 && P.aspect > 0.0f && P.tanHalfFov > 0.0f &&
-        (P.numParts == 1 || c->maskMode == 2)) {
+        (P.numParts <= mask_parts_max() || c->maskMode == 2)) {
         const int strips = (P.H + 7) / 8;
         const size_t words = (size_t)strips * P.tilesX + 3;              // tiles, "whole frame", "complete", ticket
         if (st->maskWords != words) {
