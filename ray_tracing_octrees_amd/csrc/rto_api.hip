@@ -1246,10 +1246,11 @@ static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, bool 
 // whole image keeps one wave per tile.  On return Q holds the geometry, the table and the cost pointer.
 // The occupancy mask serves frames cut into at most this many parts: a part's launch projects every cell for its share of the
 // rows, which pays as long as the share is not too small -- a rank of the screen split, per frame: 2 GPUs 28.1 -> 25.6 us, 4 GPUs
-// 21.9 -> 20.2, 8 GPUs (7 rendering parts) 14.4 -> 14.3.  RTO_MASK_PARTS_MAX overrides (A/B runs; 1: whole frames only).
-static int mask_parts_max() {
-    static const int v = []() { const char* e = std::getenv("RTO_MASK_PARTS_MAX"); return e ? std::atoi(e) : 8; }();
-    return v;
+// 21.9 -> 20.2, 8 GPUs (7 rendering parts) 14.4 -> 14.3.  The triangle frames (path 1) keep it for whole frames: a rank of 8 at
+// config 5 measured 93.5 us with it against 91.5 without.  RTO_MASK_PARTS_MAX overrides both (A/B runs; 1: whole frames only).
+static int mask_parts_max(int path) {
+    static const int v = []() { const char* e = std::getenv("RTO_MASK_PARTS_MAX"); return e ? std::atoi(e) : 0; }();
+    return v > 0 ? v : (path == 1 ? 1 : 8);
 }
 
 static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool frameMode, bool timelineMode, int path, const int rect[4],
@@ -1262,9 +1263,9 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     *stOut = st;
     // occupancy mask (maskRegion >= 0: the caller launches a lean kernel; its first maskBlocks workgroups build the mask: mask_block)
     Q.tileMask = nullptr; Q.maskBlocks = 0;
-    // (frames in up to mask_parts_max() parts: the ranks of the multi-GPU split included)
+    // (frames in up to mask_parts_max(path) parts: the ranks of the multi-GPU split included)
     if (st && maskRegion >= 0 && (frameMode || timelineMode) && c->maskMode != 0 && c->numCells > 0 && P.aspect > 0.0f && P.tanHalfFov > 0.0f &&
-        (P.numParts <= mask_parts_max() || c->maskMode == 2)) {
+        (P.numParts <= mask_parts_max(path) || c->maskMode == 2)) {
         const int strips = (P.H + 7) / 8;
         const size_t words = (size_t)strips * P.tilesX + 3;              // tiles, "whole frame", "complete", ticket
         if (st->maskWords != words) {
