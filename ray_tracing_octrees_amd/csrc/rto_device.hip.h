@@ -585,6 +585,22 @@ __device__ __forceinline__ bool tile_may_hit(const RenderParams& P, int tx, int 
            __hip_atomic_load(P.tileMask + P.maskAllIndex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp;
 }
 
+// Wave64 inclusive scans in registers (gfx9 DPP: shifts inside the rows of 16 lanes, then the two row broadcasts), no LDS
+// round trips: lanes without a source, and rows outside the row mask, take the identity 0.
+template <int CTRL, int ROWS> __device__ __forceinline__ int dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, false); }
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);      // row_shr:1, 2, 4, 8
+    v += dpp0<0x142, 0xa>(v);                                                                                    // row_bcast:15 into rows 1, 3
+    v += dpp0<0x143, 0xc>(v);                                                                                    // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ int wave_scan_max_nonneg(int v) {       // values >= 0
+    v = max(v, dpp0<0x111, 0xf>(v)); v = max(v, dpp0<0x112, 0xf>(v)); v = max(v, dpp0<0x114, 0xf>(v)); v = max(v, dpp0<0x118, 0xf>(v));
+    v = max(v, dpp0<0x142, 0xa>(v));
+    v = max(v, dpp0<0x143, 0xc>(v));
+    return v;
+}
+
 // ================================================================ screen-space occupancy mask
 // About two thirds of the rays inside the solid geometry's screen rectangle miss everything (config 2: the corners of the
 // sphere's bounding box, the ring around its silhouette) -- and each still costs its wave the ray set-up (two inversesqrt,
@@ -873,6 +889,7 @@ __device__ __forceinline__ void trace_tile_packed3(const RenderParams& P, const 
         RTO_T(3);                                   // [C] pop, stack write, next node
     }
     if (!hit && steps > kMaxTraversalSteps) steps = kMaxTraversalSteps;
+    trips = __builtin_amdgcn_readlane(wave_scan_max_nonneg(trips), kWave - 1);      // of the tile's busiest ray (see trace_tile_lean)
     if (P.tileCost && lane == 0 && ty < P.tilesY) P.tileCost[tile] = trips;
 
     const bool mine = valid && !(P.skipOutside && outsideRoot);     // pixels outside the root rectangle belong to the fill duty
@@ -1157,7 +1174,12 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
         bpos = bpos2 - 1;
         alive = !dead && !solid;
     }
-    if (P.tileCost && lane == 0 && ty < P.tilesY) P.tileCost[tile] = trips;
+    // the tile's cost for the launch order: the trips of its BUSIEST ray (a lane keeps the count of its own last trip: lane 0's
+    // alone -- what was recorded until round 3 -- underrates every tile whose costly rays are not in its top-left corner)
+    if (P.tileCost || MODE == kModeTimeline) {
+        trips = __builtin_amdgcn_readlane(wave_scan_max_nonneg(trips), kWave - 1);
+        if (P.tileCost && lane == 0 && ty < P.tilesY) P.tileCost[tile] = trips;
+    }
     const int leafShift = bpos + 1;                                      // on a hit: log2 of the leaf's edge
     cx &= 0x7fffff; cy &= 0x7fffff; cz &= 0x7fffff;                      // plain coordinates for the epilogue
 
@@ -1948,22 +1970,6 @@ __global__ __launch_bounds__(kBlock) void k_unified_fill(const uint2* __restrict
             rec[idx] = make_uint2((unsigned)t0, (unsigned)(triOffset[c0 + k + 1] - t0));
         }
     }
-}
-
-// Wave64 inclusive scans in registers (gfx9 DPP: shifts inside the rows of 16 lanes, then the two row broadcasts), no LDS
-// round trips: lanes without a source, and rows outside the row mask, take the identity 0.
-template <int CTRL, int ROWS> __device__ __forceinline__ int dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, false); }
-__device__ __forceinline__ int wave_scan_add(int v) {
-    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);      // row_shr:1, 2, 4, 8
-    v += dpp0<0x142, 0xa>(v);                                                                                    // row_bcast:15 into rows 1, 3
-    v += dpp0<0x143, 0xc>(v);                                                                                    // row_bcast:31 into rows 2, 3
-    return v;
-}
-__device__ __forceinline__ int wave_scan_max_nonneg(int v) {       // values >= 0
-    v = max(v, dpp0<0x111, 0xf>(v)); v = max(v, dpp0<0x112, 0xf>(v)); v = max(v, dpp0<0x114, 0xf>(v)); v = max(v, dpp0<0x118, 0xf>(v));
-    v = max(v, dpp0<0x142, 0xa>(v));
-    v = max(v, dpp0<0x143, 0xc>(v));
-    return v;
 }
 
 #ifndef RTO_TRI_WAVES

@@ -10,7 +10,8 @@ dim, W, H = 256, 1920, 1080
 g = rto.VoxelGrid.test_sphere(dim)
 ctx = rto.Context(0)
 ctx.build_octree(g.data, g.min, g.voxelSize)
-cam = rto.Camera(0.5, 0.7, 1.8)
+theta = float(next((a.split("=")[1] for a in sys.argv if a.startswith("theta=")), 0.5))
+cam = rto.Camera(theta, 0.7, 1.8)
 f = rto.make_frame(cam.getView(), cam.getPos(), W / H, 45.0, W, H)
 if "nomask" in sys.argv:
     ctx.debug_set_tile_mask(False)
