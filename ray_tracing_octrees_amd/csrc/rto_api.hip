@@ -1442,7 +1442,11 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
             const int lblocksLean = (Q.launchWaves + lean_wpb(0) - 1) / lean_wpb(0);
             const size_t ldsLean = (size_t)lean_wpb(0) * (P.depth + 1) * kWave * sizeof(uint2);
-            const size_t lds = Q.tileMask ? lds_for_occupancy(ldsLean, 4) : (leanKernel && !(c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT) ? lds_for_occupancy(ldsLean, 0) : ldsStacks);
+            // 4 resident waves per SIMD when the frame's waves with work would all be resident at once at 6 (see lds_for_occupancy): about
+            // 40 % of the box's tiles have work behind the mask, so up to 3 x the machine's slots at 6 per SIMD.  Config 2 (14,280 tiles)
+            // 32.8 us at 4 against 36.5 at 6; config 4 (28,652 tiles) 71.6 at 4 against 69.3 at 6.
+            const bool fewWaves = Q.traceWaves <= 3 * 6 * 4 * c->numCUs;
+            const size_t lds = Q.tileMask ? lds_for_occupancy(ldsLean, fewWaves ? 4 : 0) : (leanKernel && !(c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT) ? lds_for_occupancy(ldsLean, 0) : ldsStacks);
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
             startRecorded = true;
             const bool persistent = c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT && st && frameMode;
