@@ -2042,6 +2042,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
 #if defined(RTO_TRI_PROFILE)       // A/B build (tools/tri_profile.py): where a frame's instructions go
     unsigned long long profLaneTrips = 0, profChunks = 0, profPairs = 0, profWaveTrips = 0;
 #endif
+    int chunks = 0;                // triangle chunks of this wave (wave-uniform): part of the tile's cost
 
     for (;;) {
         // node loop: until nobody walks, or RTO_TRI_BATCH lanes wait with a leaf (the tests cost by the pair, so a round
@@ -2133,6 +2134,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
 #if defined(RTO_TRI_PROFILE)
                 profChunks++; profPairs += (unsigned long long)min(kWave, total - w0);
 #endif
+                chunks++;
                 const int w = w0 + lane;
                 // owner of pair w = the lane whose range [incl - cnt, incl) holds it.  Every lane whose range meets this chunk
                 // writes its number at the chunk position where the range begins (ranges are disjoint and in lane order, so are
@@ -2225,7 +2227,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
             const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
             int* rec = Sc.timeline + (size_t)tile * 8;
             rec[0] = (int)(profT0 & 0xffffffffu); rec[1] = (int)(profT0 >> 32); rec[2] = (int)(tl1 & 0xffffffffu); rec[3] = (int)(tl1 >> 32);
-            rec[4] = tmax; rec[5] = rounds; rec[6] = (int)hwid; rec[7] = (int)(xcc & 15u) | (slot << 4);
+            rec[4] = tmax; rec[5] = rounds | (chunks << 12); rec[6] = (int)hwid; rec[7] = (int)(xcc & 15u) | (slot << 4);
         }
     }
 #endif
@@ -2242,9 +2244,13 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     }
 #endif
     if (P.tileCost) {
-        int cost = trips + 4 * rounds;                                    // of the lane that walked longest
+        // the wave's time on a full machine, fitted over a frame's timeline (tools/tri_timeline.py): 0.67 us per trip of its busiest
+        // lane + 1.88 per round + 0.62 per chunk.  Until round 3 the chunks were left out: the tiles of big leaves (200 chunks in 9
+        // rounds) were rated cheap, started at 300 of 440 us and ended the frame alone
+        int cost = trips;
         for (int off = 32; off > 0; off >>= 1) cost = max(cost, __shfl_xor(cost, off));
-        if (lane == 0 && ty < P.tilesY) P.tileCost[tile] = cost >> 2;
+        cost += 3 * rounds + chunks;
+        if (lane == 0 && ty < P.tilesY) P.tileCost[tile] = cost >> 3;
     }
     if (valid && !(P.skipOutside && outside)) {
         if (SHADE) __builtin_nontemporal_store(shade, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);

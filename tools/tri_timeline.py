@@ -35,7 +35,7 @@ u = lambda a, b: (a.astype(np.uint32).astype(np.uint64) | (b.astype(np.uint32).a
 t0, t1 = u(rec[:, 0], rec[:, 1]), u(rec[:, 2], rec[:, 3])
 base = t0.min()
 s, e = (t0 - base) / 100.0, (t1 - base) / 100.0
-trips, rounds, hw, slot, xcc = rec[:, 4], rec[:, 5], rec[:, 6].astype(np.uint32), rec[:, 7] >> 4, rec[:, 7] & 15
+trips, rounds, chunks, hw, slot, xcc = rec[:, 4], rec[:, 5] & 0xfff, rec[:, 5] >> 12, rec[:, 6].astype(np.uint32), rec[:, 7] >> 4, rec[:, 7] & 15
 simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
 skey = ((((xcc.astype(np.int64) * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd)
 dur = e - s
@@ -61,10 +61,15 @@ print("cost vs slot rank correlation:", np.corrcoef(np.argsort(np.argsort(slot))
 o = np.argsort(-e)[:24]
 print("last waves to end:")
 for i in o:
-    print(f"  slot {slot[i]:6d} start {s[i]:7.1f} end {e[i]:7.1f} dur {dur[i]:6.1f} trips {trips[i]:4d} rounds {rounds[i]:3d} simd {skey[i]}")
+    print(f"  slot {slot[i]:6d} start {s[i]:7.1f} end {e[i]:7.1f} dur {dur[i]:6.1f} trips {trips[i]:4d} rounds {rounds[i]:3d} chunks {chunks[i]:4d} simd {skey[i]}")
 late = s > 350
 print(f"waves that start after 350 us: {late.sum()}, live {(late & (trips > 0)).sum()}; their trips percentiles", np.percentile(trips[late & (trips > 0)], [50, 90, 100]) if (late & (trips > 0)).any() else "-")
 # start time by slot decile
 for q in range(0, 100, 10):
     m = (slot >= np.percentile(slot, q)) & (slot < np.percentile(slot, q + 10))
-    print(f"  slot decile {q:2d}: start {s[m].mean():6.1f} us, live {int((trips[m] > 0).sum()):5d}, mean trips {trips[m].mean():5.1f} rounds {rounds[m].mean():5.1f} dur {dur[m].mean():6.1f}")
+    print(f"  slot decile {q:2d}: start {s[m].mean():6.1f} us, live {int((trips[m] > 0).sum()):5d}, mean trips {trips[m].mean():5.1f} rounds {rounds[m].mean():5.1f} chunks {chunks[m].mean():5.1f} dur {dur[m].mean():6.1f}")
+# which of the three counts explains a wave's duration?  least squares over the live waves that ran on a full machine
+m = (trips > 0) & (s > 30) & (e < 380)
+A = np.stack([trips[m], rounds[m], chunks[m], np.ones(m.sum())], axis=1).astype(np.float64)
+coef, *_ = np.linalg.lstsq(A, dur[m], rcond=None)
+print("duration ~ %.2f us x trips + %.2f x rounds + %.2f x chunks + %.1f   (live waves of the full-machine phase)" % tuple(coef))
