@@ -89,8 +89,10 @@ struct rto_context {
         size_t maskWords = 0;           // strips * tilesX + 1 of the frame size the buffer was made for
         unsigned long lastUse = 0;      // orderClock value of the last launch on this stream (eviction order)
     };
-    std::map<hipStream_t, OrderState> orders;
-    hipStream_t lastOrderStream = nullptr;      // what the rto_debug_* order functions refer to
+    typedef std::pair<hipStream_t, int> OrderKey;       // launch stream, path (0 octree / 1 triangle / 2 nearest-hit frames): an application that
+                                                         // renders two kinds of frame on one stream keeps a history for each
+    std::map<OrderKey, OrderState> orders;
+    OrderKey lastOrderKey = OrderKey(nullptr, -1);       // what the rto_debug_* order functions refer to
     static constexpr size_t kMaxOrderStreams = 16;   // a 17th stream evicts the least recently used entry
     unsigned long orderClock = 0;
     int* d_sortViolations = nullptr;            // k_sort_scatter: out-of-range writes refused (must stay 0; rto_debug_sort_violations)
@@ -708,7 +710,7 @@ int rto_download_nodes(rto_context* c, rto_node* out, int64_t capacity, int64_t*
 
 int rto_debug_tile_cost(rto_context* c, int32_t* host_cost, int64_t capacity, int64_t* count) {
     if (!c || !count) return RTO_E_INVALID;
-    auto it = c->orders.find(c->lastOrderStream);
+    auto it = c->orders.find(c->lastOrderKey);
     *count = it == c->orders.end() ? 0 : it->second.tiles;
     if (!host_cost) return RTO_OK;
     if (it == c->orders.end() || capacity < it->second.tiles || !it->second.d_tileCost)
@@ -720,7 +722,7 @@ int rto_debug_tile_cost(rto_context* c, int32_t* host_cost, int64_t capacity, in
 
 int rto_debug_set_tile_order(rto_context* c, const int32_t* host_order, int64_t n) {
     if (!c) return RTO_E_INVALID;
-    auto it = c->orders.find(c->lastOrderStream);
+    auto it = c->orders.find(c->lastOrderKey);
     if (!host_order) {
         if (it == c->orders.end()) return RTO_OK;
         rto_context::OrderState& o = it->second;
@@ -754,13 +756,18 @@ int rto_set_launch_order(rto_context* c, int policy, int refresh_period) {
 
 int rto_forget_stream(rto_context* c, void* hip_stream) {
     if (!c) return RTO_E_INVALID;
-    auto it = c->orders.find((hipStream_t)hip_stream);
-    if (it == c->orders.end()) return RTO_OK;
-    RTO_HIP(c, hipSetDevice(c->device));
-    RTO_HIP(c, hipDeviceSynchronize());          // no kernel still reads the tables
-    (void)hipFree(it->second.d_tileCost); (void)hipFree(it->second.tab[0].d); (void)hipFree(it->second.tab[1].d); (void)hipFree(it->second.d_queue); (void)hipFree(it->second.d_tileMask);
-    if (c->lastOrderStream == it->first) c->lastOrderStream = nullptr;
-    c->orders.erase(it);
+    bool synced = false;
+    for (auto it = c->orders.begin(); it != c->orders.end();) {                  // every kind of frame that was launched on the stream
+        if (it->first.first != (hipStream_t)hip_stream) { ++it; continue; }
+        if (!synced) {
+            RTO_HIP(c, hipSetDevice(c->device));
+            RTO_HIP(c, hipDeviceSynchronize());  // no kernel still reads the tables
+            synced = true;
+        }
+        (void)hipFree(it->second.d_tileCost); (void)hipFree(it->second.tab[0].d); (void)hipFree(it->second.tab[1].d); (void)hipFree(it->second.d_queue); (void)hipFree(it->second.d_tileMask);
+        if (c->lastOrderKey == it->first) c->lastOrderKey = rto_context::OrderKey(nullptr, -1);
+        it = c->orders.erase(it);
+    }
     return RTO_OK;
 }
 
@@ -1223,8 +1230,9 @@ static bool stream_is_capturing(hipStream_t s) {
 // The scheduling state of launch stream `s` (temporal launch order, persistent-kernel counter).  At most
 // kMaxOrderStreams streams are tracked; when a new stream arrives at the limit, the entry that was used longest ago is
 // dropped (its buffers are freed after a device synchronise, so a capture in progress refuses instead: see callers).
-static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, bool capturing) {
-    auto it = c->orders.find(s);
+static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, int path, bool capturing) {
+    const rto_context::OrderKey key(s, path);
+    auto it = c->orders.find(key);
     if (it != c->orders.end()) { it->second.lastUse = ++c->orderClock; return &it->second; }
     if (c->orders.size() >= rto_context::kMaxOrderStreams) {
         if (capturing) return nullptr;                       // eviction frees memory: not inside a capture
@@ -1234,18 +1242,14 @@ static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, bool 
         (void)hipDeviceSynchronize();
         (void)hipFree(victim->second.d_tileCost); (void)hipFree(victim->second.tab[0].d); (void)hipFree(victim->second.tab[1].d);
         (void)hipFree(victim->second.d_queue); (void)hipFree(victim->second.d_tileMask);
-        if (c->lastOrderStream == victim->first) c->lastOrderStream = nullptr;
+        if (c->lastOrderKey == victim->first) c->lastOrderKey = rto_context::OrderKey(nullptr, -1);
         c->orders.erase(victim);
     }
-    rto_context::OrderState* st = &c->orders[s];
+    rto_context::OrderState* st = &c->orders[key];
     st->lastUse = ++c->orderClock;
     return st;
 }
 
-// Launch geometry + launch order of one frame of the packed kernels on stream `s` (shared by the octree and the triangle
-// path): waves for the tiles of `rect`'s box only, the outside shared out as fill chunks, the box's tiles in the order of
-// the costs earlier frames recorded.  frameMode: a colour / shade frame (records costs); otherwise (instrumentation) the
-// whole image keeps one wave per tile.  On return Q holds the geometry, the table and the cost pointer.
 // The occupancy mask serves frames cut into at most this many parts: a part's launch projects every cell for its share of the
 // rows, which pays as long as the share is not too small -- a rank of the screen split, per frame: 2 GPUs 28.1 -> 25.6 us, 4 GPUs
 // 21.9 -> 20.2, 8 GPUs (7 rendering parts) 14.4 -> 14.3.  The triangle frames (path 1) keep it for whole frames: a rank of 8 at
@@ -1255,13 +1259,17 @@ static int mask_parts_max(int path) {
     return v > 0 ? v : (path == 1 ? 1 : 8);
 }
 
+// Launch geometry + launch order of one frame of the packed kernels on stream `s` (shared by the octree and the triangle
+// path): waves for the tiles of `rect`'s box only, the outside shared out as fill chunks, the box's tiles in the order of
+// the costs earlier frames recorded.  frameMode: a colour / shade frame (records costs); otherwise (instrumentation) the
+// whole image keeps one wave per tile.  On return Q holds the geometry, the table and the cost pointer.
 static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool frameMode, bool timelineMode, int path, const int rect[4],
                             RenderParams& Q, rto_context::OrderState** stOut, int maskRegion = -1) {
     const RenderParams& P = Q;
     const int tiles = P.tilesX * P.tilesY;
     Q.tileOrder = nullptr; Q.tileCost = nullptr;
     const long key[7] = { P.W, P.H, P.numParts, P.part, P.bandRows, tiles, path };
-    rto_context::OrderState* st = order_state(c, s, capturing);      // this stream's scheduling state
+    rto_context::OrderState* st = order_state(c, s, path, capturing);      // the scheduling state of this kind of frame on this stream
     *stOut = st;
     // occupancy mask (maskRegion >= 0: the caller launches a lean kernel; its first maskBlocks workgroups build the mask: mask_block)
     Q.tileMask = nullptr; Q.maskBlocks = 0;
@@ -1292,7 +1300,7 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
     rto_context::OrderState* o = (c->orderPolicy == RTO_ORDER_TEMPORAL && (frameMode || timelineMode) &&
                                   P.tilesX <= 0xffff && P.tilesY <= 0x7fff) ? st : nullptr;      // table entries are x | y << 16 inside the box
     if (o) {
-        c->lastOrderStream = s;
+        c->lastOrderKey = rto_context::OrderKey(s, path);
         if (o->tiles != tiles) {
             if (capturing)
                 return fail(c, RTO_E_UNSUPPORTED, "render: the first frame of a new size on a stream allocates its launch-order "

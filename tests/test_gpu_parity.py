@@ -1260,6 +1260,12 @@ def test_nearest_hit_render_mode_at_config2_size(ctx, orc, scenes, camera):
     dfs, _ = oracle_frame(orc, s, view, pos, W, H)
     hit_dfs, hit_near = dfs[..., 0] != 0, dist < 1e30
     assert hit_near.sum() >= hit_dfs.sum() > 100000                # the DFS mode loses rays to its 512-pop cap; this mode has none
+    # both kinds of frame in turn on one stream: each keeps its own launch-order history (stream, kind), neither disturbs the other
+    for k in range(3):
+        assert_bit_exact(ctx.render_host(f), dfs, f"first-hit frame between nearest-hit frames, round {k}")
+        r2, d2 = ctx.render_skip_host(f)
+        assert d2.tobytes() == odist.tobytes() and r2.tobytes() == orgba.tobytes(), f"nearest-hit frame between first-hit frames, round {k}"
+    assert ctx.debug_sort_violations() == 0
 
 
 @pytest.mark.parametrize("scene,cam", [("sphere32", (0.5, 0.7, 1.8)), ("odd", (0.4, 0.9, 9.0)), ("calgary", (0.6, 0.5, 3500.0))])
