@@ -579,6 +579,13 @@ def test_occupancy_mask_never_changes_pixels_and_removes_work(ctx, orc, scenes):
                 inner = cost[ys.min(): ys.max() + 1, xs.min(): xs.max() + 1]
                 n_walk, n_hit, n_box = int((inner > 0).sum()), int(hit_tiles.sum()), inner.size
                 assert n_hit <= n_walk <= 1.35 * n_hit + 40 and n_walk < n_box, (n_walk, n_hit, n_box)
+                # the cost the launch order sorts by is that of the tile's BUSIEST ray: a loop trip pops at most 8 nodes, so the
+                # tile's trip count bounds every pixel's pop count (lane 0's count alone, recorded until round 3, did not)
+                pops = np.abs(ctx.render_steps(f))[: H // 8 * 8, : W // 8 * 8].reshape(H // 8, 8, W // 8, 8).max(axis=(1, 3))
+                ctx.render_host(f)
+                cost = ctx.debug_tile_cost().reshape((H + 7) // 8, (W + 7) // 8)[: H // 8, : W // 8]
+                walked = hit_tiles & (cost > 0)
+                assert (8 * cost[walked] + 1 >= pops[walked]).all(), "a tile's recorded cost is below what its busiest ray needs"
     ctx.debug_set_tile_mask(1)
 
 
