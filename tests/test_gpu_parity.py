@@ -180,6 +180,42 @@ def test_config2_full_size_256_1080p(ctx, orc, scenes, camera, golden_meta, knam
     assert lit.min() >= np.float32(0.1) and lit.max() <= np.float32(1.1)
 
 
+@pytest.mark.parametrize("scene", ["sphere256", "calgary"])
+def test_random_cameras_at_full_size(ctx, orc, scenes, scene):
+    """The launch geometry (solid rectangle, occupancy mask, cost-sorted order, 4 / 6 resident waves) is chosen per frame from the
+    camera: seeded random cameras at 1920x1080 -- far, near, grazing, inside the volume, looking past it -- give the oracle's
+    pixels in the first-hit mode (three frames each: the table of the previous camera, then its own) and in the nearest-hit mode,
+    and the instrumented frame's counters agree.  RTO_CAMERA_SEEDS widens the sweep (default 4 per scene)."""
+    s = scenes(scene)
+    upload(ctx, s)
+    W, H = 1920, 1080
+    n = int(os.environ.get("RTO_CAMERA_SEEDS", "4"))
+    first = int(os.environ.get("RTO_CAMERA_START", "0"))
+    dims = np.array(s.grid.dims, np.float32)
+    ext = float(dims.max() * s.voxel)
+    centre = np.asarray(s.min, np.float32) + 0.5 * dims * np.float32(s.voxel)
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(77000 + seed)
+        kind = ("far", "near", "inside", "past")[seed % 4]
+        radius = ext * {"far": rng.uniform(1.5, 5.0), "near": rng.uniform(0.55, 1.0), "inside": rng.uniform(0.05, 0.45), "past": rng.uniform(0.8, 2.0)}[kind]
+        cam = orc.Camera(float(rng.uniform(0, 6.28)), float(rng.uniform(-1.4, 1.4)), float(radius))
+        off = rng.uniform(-0.15, 0.15, 3) if kind != "past" else rng.uniform(0.6, 1.2, 3) * rng.choice([-1.0, 1.0], 3)
+        cam.set_target(*[float(x) for x in centre + off.astype(np.float32) * ext])
+        view, pos = cam.get_view(), cam.get_pos()
+        fov = float(rng.choice([30.0, 45.0, 70.0]))
+        f = rto.make_frame(view, pos, W / H, fov, W, H)
+        want, st = oracle_frame(orc, s, view, pos, W, H, fov=fov)
+        for k in range(3):
+            assert_bit_exact(ctx.render_host(f), want, f"{scene} seed {seed} ({kind}) frame {k}")
+        gs = ctx.frame_stats(f)
+        assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"]), (scene, seed, kind)
+        nrgba, nt = orc.render_skip(s.nodes, s.min, s.voxel, view, pos, W / H, fov, W, H, nthreads=min(16, orc.max_threads()))
+        for k in range(2):
+            grgba, gt = ctx.render_skip_host(f)
+        assert gt.tobytes() == nt.tobytes() and grgba.tobytes() == nrgba.tobytes(), f"{scene} seed {seed} ({kind}): nearest-hit mode"
+    assert ctx.debug_sort_violations() == 0
+
+
 @pytest.mark.parametrize("cam_name,W,H", [("calgary_default", 1300, 1300), ("calgary_oblique", 1920, 1080)])
 def test_config4_calgary(ctx, orc, scenes, camera, golden_meta, cam_name, W, H):
     """BASELINE config 4: the shipped sceneCache.bin grid (425x243x29, root 512); default app camera (eye
