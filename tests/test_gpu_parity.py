@@ -188,6 +188,10 @@ def test_random_cameras_at_full_size(ctx, orc, scenes, scene):
     and the instrumented frame's counters agree.  RTO_CAMERA_SEEDS widens the sweep (default 4 per scene)."""
     s = scenes(scene)
     upload(ctx, s)
+    tris = off = None
+    if scene == "sphere256":                                   # the triangle path (config 5's kernels) from the same cameras
+        tris, off = orc.build_leaf_triangles(s.grid, s.nodes)
+        ctx.upload_leaf_triangles(tris, off)
     W, H = 1920, 1080
     n = int(os.environ.get("RTO_CAMERA_SEEDS", "4"))
     first = int(os.environ.get("RTO_CAMERA_START", "0"))
@@ -199,8 +203,8 @@ def test_random_cameras_at_full_size(ctx, orc, scenes, scene):
         kind = ("far", "near", "inside", "past")[seed % 4]
         radius = ext * {"far": rng.uniform(1.5, 5.0), "near": rng.uniform(0.55, 1.0), "inside": rng.uniform(0.05, 0.45), "past": rng.uniform(0.8, 2.0)}[kind]
         cam = orc.Camera(float(rng.uniform(0, 6.28)), float(rng.uniform(-1.4, 1.4)), float(radius))
-        off = rng.uniform(-0.15, 0.15, 3) if kind != "past" else rng.uniform(0.6, 1.2, 3) * rng.choice([-1.0, 1.0], 3)
-        cam.set_target(*[float(x) for x in centre + off.astype(np.float32) * ext])
+        aim = rng.uniform(-0.15, 0.15, 3) if kind != "past" else rng.uniform(0.6, 1.2, 3) * rng.choice([-1.0, 1.0], 3)
+        cam.set_target(*[float(x) for x in centre + aim.astype(np.float32) * ext])
         view, pos = cam.get_view(), cam.get_pos()
         fov = float(rng.choice([30.0, 45.0, 70.0]))
         f = rto.make_frame(view, pos, W / H, fov, W, H)
@@ -213,6 +217,13 @@ def test_random_cameras_at_full_size(ctx, orc, scenes, scene):
         for k in range(2):
             grgba, gt = ctx.render_skip_host(f)
         assert gt.tobytes() == nt.tobytes() and grgba.tobytes() == nrgba.tobytes(), f"{scene} seed {seed} ({kind}): nearest-hit mode"
+        if tris is not None:
+            wt, wst = orc.render_triangles(s.nodes, tris, off, s.min, s.voxel, view, pos, W / H, fov, W, H, shadow=True, nthreads=min(16, orc.max_threads()))
+            for k in range(2):                                  # the colour kernel (mask, launch order), then the instrumented one
+                assert_bit_exact(ctx.render_triangles_host(f, shadow=True), wt, f"{scene} seed {seed} ({kind}) triangles + shadow, frame {k}")
+            got, gs = ctx.render_triangles_host(f, shadow=True, stats=True)
+            assert_bit_exact(got, wt, f"{scene} seed {seed} ({kind}) triangles + shadow, instrumented frame")
+            assert (gs["pops"], gs["hits"]) == (wst["pops"], wst["hits"]), (scene, seed, kind)
     assert ctx.debug_sort_violations() == 0
 
 
