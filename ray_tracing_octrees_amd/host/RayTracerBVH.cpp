@@ -39,7 +39,7 @@ struct HipApi {
     bool load() {
         if (handle) return true;
         std::vector<std::string> candidates;
-        if (const char* env = std::getenv("RTO_HIP_LIB")) candidates.emplace_back(env);
+        if (const char* env = std::getenv("RTO_HIP_LIB")) { if (*env) candidates.emplace_back(env); }      // set but empty: as if unset
         Dl_info info;
         if (dladdr(reinterpret_cast<void*>(&anchor), &info) && info.dli_fname) {   // next to this library
             std::string dir(info.dli_fname);
