@@ -1,10 +1,10 @@
 #!/bin/bash
-# tools/store_profiles.sh [TAG] -- copy what tools/profile_gpu.sh left under gpurun_out/prof_TAG_c{2,4,5}/ into profiles/ (tracked) and
+# tools/store_profiles.sh [TAG] -- copy what tools/profile_gpu.sh left under gpurun_out/prof_TAG_c{2,4,4synthetic,5}/ into profiles/ (tracked) and
 # merge the counters into profiles/pmc_counters.json (entries for one frame per launch and for 4 frames per launch).
 set -e
 TAG=${1:-r03}
 R=$(cd "$(dirname "$0")/.." && pwd); cd "$R"
-for c in 2 4 5; do
+for c in 2 4 4synthetic 5; do
   D=gpurun_out/prof_${TAG}_c$c
   [ -f $D/summary.json ] || { echo "no $D/summary.json"; continue; }
   cp $D/summary.json profiles/${TAG}_config${c}_summary.json
