@@ -180,7 +180,9 @@ def test_config2_full_size_256_1080p(ctx, orc, scenes, camera, golden_meta, knam
     assert lit.min() >= np.float32(0.1) and lit.max() <= np.float32(1.1)
 
 
-@pytest.mark.parametrize("scene", ["sphere256", "calgary"])
+@pytest.mark.parametrize("scene", ["sphere256", "calgary",
+                                   pytest.param("sphere512", marks=pytest.mark.skipif(not os.environ.get("RTO_CAMERA_BIG"),
+                                                                                    reason="config 5's size (512^3, 4K): RTO_CAMERA_BIG=1 sweeps it"))])
 def test_random_cameras_at_full_size(ctx, orc, scenes, scene):
     """The launch geometry (solid rectangle, occupancy mask, cost-sorted order, 4 / 6 resident waves) is chosen per frame from the
     camera: seeded random cameras at 1920x1080 -- far, near, grazing, inside the volume, looking past it -- give the oracle's
@@ -189,10 +191,10 @@ def test_random_cameras_at_full_size(ctx, orc, scenes, scene):
     s = scenes(scene)
     upload(ctx, s)
     tris = off = None
-    if scene == "sphere256":                                   # the triangle path (config 5's kernels) from the same cameras
+    if scene != "calgary":                                     # the triangle path (config 5's kernels) from the same cameras
         tris, off = orc.build_leaf_triangles(s.grid, s.nodes)
         ctx.upload_leaf_triangles(tris, off)
-    W, H = 1920, 1080
+    W, H = (3840, 2160) if scene == "sphere512" else (1920, 1080)
     n = int(os.environ.get("RTO_CAMERA_SEEDS", "4"))
     first = int(os.environ.get("RTO_CAMERA_START", "0"))
     dims = np.array(s.grid.dims, np.float32)
