@@ -61,6 +61,8 @@ struct rto_context {
     bool cullAsync = false;          // the flags in force come from k_cull_desc
     bool cullStateStale = false;     // rootVisible / visibleNodes below are older than d_start
     bool cullCaptured = false;       // an update was stream-captured: replays change d_start behind the host's back
+    hipEvent_t evCull = nullptr;     // recorded on c->stream behind every kernel that rewrites the visibility state (descriptor bits, d_vis,
+    bool evCullPending = false;      // d_start); frames launched on OTHER streams wait for it (order_after_cull).  Pending: recorded, not yet seen complete
 
     // temporal launch order (packed kernel): an earlier frame's per-tile cost -> this frame's slot->tile table.
     // The tables are written and read by kernels in stream order, so every launch stream owns a set of its own:
@@ -231,6 +233,7 @@ int rto_create(int device_ordinal, rto_context** out) {
     }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->evCull, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc(&c->d_counters, sizeof(Counters))) != hipSuccess ||
         (e = hipMalloc(&c->d_visibleCount, 2 * sizeof(int64_t))) != hipSuccess ||     // [0] count of visible nodes, [1] the root's flag
         (e = hipMalloc(&c->d_start, sizeof(StartState))) != hipSuccess || (e = hipMemset(c->d_start, 0, sizeof(StartState))) != hipSuccess ||
@@ -265,6 +268,7 @@ void rto_destroy(rto_context* c) {
     for (hipEvent_t e : c->ringStop) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->evCull) (void)hipEventDestroy(c->evCull);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -844,6 +848,36 @@ int rto_set_kernel(rto_context* c, int kernel) {
 // One frustum update for the given planes (LEFT, RIGHT, TOP, BOTTOM, NEAR, FAR; normalised) and margin.
 static bool stream_is_capturing(hipStream_t s);
 
+// The visibility state (descriptor bits, d_vis, d_start) was just rewritten by a kernel on c->stream: mark the point.  Inside a
+// capture of c->stream nothing is recorded -- the replays are launched by the caller, who orders them like any graph.
+static int cull_state_written(rto_context* c) {
+    if (stream_is_capturing(c->stream)) return RTO_OK;
+    RTO_HIP(c, hipEventRecord(c->evCull, c->stream));
+    c->evCullPending = true;
+    return RTO_OK;
+}
+
+// A launch on stream `s` is about to READ the visibility state.  On the context's own stream the stream orders it; any other
+// stream -- a caller's, or rto_comm's render stream: what RayTracerBVH::renderSceneComputeWithCulling uses on several GPUs --
+// waits for the last rewrite (hipStreamWaitEvent: nothing happens on the host; a stream that is being CAPTURED cannot wait
+// for an event from outside its capture, so there the host waits for the event instead -- once, then the flag is down).
+static int order_after_cull(rto_context* c, hipStream_t s) {
+    if (s == c->stream || !c->evCullPending) return RTO_OK;
+    if (stream_is_capturing(s)) {
+        // the event lives outside the capture: wait for it on the host.  Event queries count as "unsafe" calls under the global
+        // capture mode (what torch.cuda.graph uses), so this thread steps into the relaxed mode for the one call
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        RTO_HIP(c, hipThreadExchangeStreamCaptureMode(&mode));
+        const hipError_t e = hipEventSynchronize(c->evCull);
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (e != hipSuccess) return fail(c, RTO_E_HIP, std::string("order_after_cull: ") + hipGetErrorString(e));
+        c->evCullPending = false;
+        return RTO_OK;
+    }
+    RTO_HIP(c, hipStreamWaitEvent(s, c->evCull, 0));
+    return RTO_OK;
+}
+
 // What the last (asynchronous) frustum update left on the device -> the host's copies (rootVisible, visibleNodes).  Only the
 // paths that need them on the host call this: the A/B kernels, the generic kernel, compaction, info queries.
 static int sync_cull_state(rto_context* c) {
@@ -852,6 +886,7 @@ static int sync_cull_state(rto_context* c) {
         return fail(c, RTO_E_UNSUPPORTED, "the result of a frustum update cannot be read while the context's stream is being captured");
     RTO_HIP(c, hipSetDevice(c->device));
     RTO_HIP(c, hipDeviceSynchronize());
+    c->evCullPending = false;
     StartState st;
     RTO_HIP(c, hipMemcpy(&st, c->d_start, sizeof st, hipMemcpyDeviceToHost));
     c->rootVisible = st.rootVisible ? 1 : 0;
@@ -924,7 +959,7 @@ static int update_frustum_planes(rto_context* c, const float planes[24], float m
         RTO_HIP(c, hipGetLastError());
         c->culling = true; c->cullAsync = true; c->cullStateStale = true;
         if (capturing) c->cullCaptured = true;
-        return RTO_OK;
+        return cull_state_written(c);
     }
     // arbitrary arrays (generic kernel): per-node flags + scan, the count and the root's flag come back in one copy
     if (capturing) return fail(c, RTO_E_UNSUPPORTED, "rto_update_frustum: capturable for canonical BFS octrees only");
@@ -954,6 +989,8 @@ int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, floa
         if (c->culling && c->canonical && nbInt > 0) {
             hipLaunchKernelGGL(k_desc_visall, dim3(nbInt), dim3(kBlock), 0, c->stream, c->numInternal, c->d_desc);
             RTO_HIP(c, hipGetLastError());
+            const int rcEv = cull_state_written(c);
+            if (rcEv != RTO_OK) return rcEv;
         }
         c->culling = false; c->cullAsync = false; c->cullStateStale = false; c->rootVisible = 1; c->visibleNodes = c->numNodes;
         return RTO_OK;
@@ -1189,7 +1226,7 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     P.rayX = c->d_rayX; P.rayY = c->d_rayY;
     P.tileOrder = nullptr; P.tileCost = nullptr;
     P.start = nullptr;                     // the lean kernels' launchers point it at the device-side start state while culling is active
-    P.tileMask = nullptr; P.maskStamp = 0; P.maskAllIndex = 0; P.maskBlocks = 0; P.maskTrustSlots = 0; P.maskCells = nullptr; P.maskNumCells = 0;
+    P.tileMask = nullptr; P.maskStamp = 0; P.maskAllIndex = 0; P.maskBlocks = 0; P.maskTrustSlots = 0; P.maskCells = nullptr; P.maskNumCells = 0; P.maskLdsBytes = 0;
     P.maskInvAspTan = P.maskInvTanH = 0.0f;                                 // prepare_schedule switches the occupancy mask on for lean colour / shade frames
     for (int r = 0; r < 3; r++) for (int k = 0; k < 4; k++) P.viewRows[r * 4 + k] = f->view[k * 4 + r];   // column-major glm matrix -> rows
     {   // rays through pixels outside these rectangles miss the root box / every solid leaf for certain
@@ -1407,6 +1444,7 @@ static size_t lds_for_occupancy(size_t lds, int wavesDefault) {
 template <int MODE>
 static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hipStream_t s) {
     if (s != c->stream) c->otherStreams = true;
+    { const int rcOrder = order_after_cull(c, s); if (rcOrder != RTO_OK) return rcOrder; }
     const int tiles = P.tilesX * P.tilesY;
     if (tiles <= 0) return RTO_OK;
     const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
@@ -1455,6 +1493,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             // 32.8 us at 4 against 36.5 at 6; config 4 (28,652 tiles) 71.6 at 4 against 69.3 at 6.
             const bool fewWaves = Q.traceWaves <= 3 * 6 * 4 * c->numCUs;
             const size_t lds = Q.tileMask ? lds_for_occupancy(ldsLean, fewWaves ? 4 : 0) : (leanKernel && !(c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT) ? lds_for_occupancy(ldsLean, 0) : ldsStacks);
+            Q.maskLdsBytes = (int)lds;
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
             startRecorded = true;
             const bool persistent = c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT && st && frameMode;
@@ -1571,6 +1610,7 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
     }
     const bool capturing = stream_is_capturing(s);
     if (capturing && s != c->stream) c->foreignCaptured = true;
+    { const int rcOrder = order_after_cull(c, s); if (rcOrder != RTO_OK) return rcOrder; }
     const bool noEvents = capturing || c->eventsOff;
     RenderBatch B;
     B.n = n;
@@ -1601,6 +1641,7 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
     if (!noEvents && c->ringUsed < c->ringStart.size()) { evA = c->ringStart[c->ringUsed]; evB = c->ringStop[c->ringUsed]; c->ringUsed++; }
     if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));
     const size_t lds = lds_for_occupancy((size_t)lean_wpb(0) * (Ps[0].depth + 1) * kWave * sizeof(uint2), 0);
+    for (int i = 0; i < n; i++) B.P[i].maskLdsBytes = (int)lds;
     const long long waves = (long long)maxWaves * n;
     if (c->maskMode == 2 && B.P[0].maskBlocks > 0)
         hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)(B.P[0].maskBlocks * n)), dim3(lean_block(0)), lds, s, B, c->d_desc);
@@ -1936,6 +1977,7 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
     if (s != c->stream) c->otherStreams = true;
     if (!c->d_triOffset) return fail(c, RTO_E_NO_OCTREE, "render_triangles: no leaf triangles uploaded");
     if (c->culling) return fail(c, RTO_E_UNSUPPORTED, "render_triangles: not available while frustum culling is active");
+    { const int rcOrder = order_after_cull(c, s); if (rcOrder != RTO_OK) return rcOrder; }      // a culling switch-off rewrites the descriptors too
     RenderParams P;
     int rc = fill_params(c, f, p, P, s);
     if (rc != RTO_OK) return rc;
@@ -1965,6 +2007,7 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
             S.timeline = (!count && !shadeOut && !capturing && ensure_steps(c, (size_t)tiles * 8) == RTO_OK) ? c->d_steps : nullptr;
 #endif
             const size_t lds = (size_t)lean_wpb(1) * ((P.depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));   // stacks + the keys of the triangle rounds
+            P.maskLdsBytes = (int)lds;
             const dim3 lb(lean_block(1)), lgrid((P.launchWaves + lean_wpb(1) - 1) / lean_wpb(1) + P.maskBlocks);
             if (c->maskMode == 2 && P.maskBlocks > 0 && !count)
                 hipLaunchKernelGGL((k_trace_lean_triangles<kModeColor, false>), dim3(P.maskBlocks), lb, lds, s, P, S, shadow, d_out, c->d_counters);
@@ -2008,6 +2051,7 @@ static int launch_triangles_batch(rto_context* c, const rto_frame* frames, int n
     }
     if (!c->d_triOffset) return fail(c, RTO_E_NO_OCTREE, "render_triangles: no leaf triangles uploaded");
     const bool capturing = stream_is_capturing(s);
+    { const int rcOrder = order_after_cull(c, s); if (rcOrder != RTO_OK) return rcOrder; }
     const bool noEvents = capturing || c->eventsOff;
     RenderBatch B;
     B.n = n;
@@ -2038,6 +2082,7 @@ static int launch_triangles_batch(rto_context* c, const rto_frame* frames, int n
     S.timeline = nullptr;
 #endif
     const size_t lds = (size_t)lean_wpb(1) * ((B.P[0].depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));
+    for (int i = 0; i < n; i++) B.P[i].maskLdsBytes = (int)lds;
     const long long waves = (long long)maxWaves * n;
     const dim3 grid((unsigned)((waves + lean_wpb(1) - 1) / lean_wpb(1)) + (unsigned)(B.P[0].maskBlocks * n));
     if (c->maskMode == 2 && B.P[0].maskBlocks > 0)
@@ -2178,6 +2223,7 @@ static int launch_skip_render(rto_context* c, const rto_frame* f, const rto_part
     RenderParams P;
     int rc = fill_params(c, f, p, P, s);
     if (rc != RTO_OK) return rc;
+    if ((rc = order_after_cull(c, s)) != RTO_OK) return rc;
     const int tiles = P.tilesX * P.tilesY;
     if (tiles <= 0) return RTO_OK;
     const size_t lds = (size_t)(kBlock / kWave) * P.depth * kWave * sizeof(uint4);
@@ -2187,6 +2233,7 @@ static int launch_skip_render(rto_context* c, const rto_frame* f, const rto_part
     rto_context::OrderState* st = nullptr;
     const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
     if ((rc = prepare_schedule(c, s, stream_is_capturing(s), true, false, 2, solidRect, P, &st, 0)) != RTO_OK) return rc;
+    P.maskLdsBytes = (int)lds;
     const int blocks = (P.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave) + P.maskBlocks;
     if (c->maskMode == 2 && P.maskBlocks > 0)
         hipLaunchKernelGGL(k_skip_render, dim3(P.maskBlocks), dim3(kBlock), lds, s, P, c->d_desc, vis, vis ? 1 : 0, d_rgba, d_dist);
@@ -2222,6 +2269,7 @@ static int launch_probe_skip(rto_context* c, const float view[16], const float c
     if (c->numNodes <= 0) return fail(c, RTO_E_NO_OCTREE, "rto_probe_skip: no octree uploaded");
     if (!(c->canonical && c->numInternal > 0)) return fail(c, RTO_E_UNSUPPORTED, "rto_probe_skip: needs a canonical BFS octree");
     if (s != c->stream) c->otherStreams = true;
+    { const int rcOrder = order_after_cull(c, s); if (rcOrder != RTO_OK) return rcOrder; }
     ProbeParams Q;
     // S/VR:1608-1612: P = perspective(radians(45), aspect, 0.1, 5000); invV = inverse(V); invP = inverse(P) -- pixel independent, on the host
     const rtmath::mat4 P = rtmath::perspective(rtmath::radians(45.0f), aspect, 0.1f, 5000.0f);

@@ -115,6 +115,7 @@ struct RenderParams {
     int maskTrustSlots;             // launch slots below this never consult the mask (kMaskTrustSlots; 0 in the tests' forced mode)
     const int4* maskCells;          // the coarse cells (x, y, z, edge)
     int maskNumCells;
+    int maskLdsBytes;               // dynamic LDS of the launch: a mask workgroup gathers its stamps there (mask_block)
     float maskInvAspTan, maskInvTanH;   // 1 / (aspect * tan(fov/2)), 1 / tan(fov/2)
     float viewRows[12];             // rows 0..2 of the view matrix
 };
@@ -577,6 +578,7 @@ __device__ __forceinline__ bool resolve_slot(const RenderParams& P, int slot, in
 __device__ __forceinline__ bool tile_may_hit(const RenderParams& P, int tx, int ty, int slot) {
     if (!P.tileMask || ty >= P.tilesY || slot < P.maskTrustSlots) return true;
     if (__hip_atomic_load(P.tileMask + P.maskAllIndex + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.maskStamp) return true;   // not complete (yet)
+    asm volatile("" ::: "memory");                             // the loads below are issued after this poll has matched, never hoisted above it
     // No acquire fence here: it would invalidate the whole CU's L1 (the descriptors!) once per wave.  The loads below are
     // agent-scope loads themselves (they do not read this CU's or this XCD's stale lines) and are issued after the branch on
     // the load above has resolved; the words they read were stored, and released, before the "complete" word.
@@ -613,13 +615,36 @@ __device__ __forceinline__ int wave_scan_max_nonneg(int v) {       // values >= 
 // writers of a frame store the same value (no atomics; safe under graph replay: a replayed launch re-stamps its own tiles).
 constexpr int kMaskMaxRectTiles = 2048;    // a cell that covers more tiles than this stamps the "whole frame" word instead
 
-// One workgroup's share of a frame's mask: cell blockInFrame * kBlock + thread.  The workgroup that finishes last (ticket)
+// A word of the mask leaves as an sc1 (agent-scope) store: it bypasses nothing on the way to memory that a reader on another XCD
+// could miss, and its acknowledgement -- what s_waitcnt vmcnt(0) waits for -- means "visible to every CU of the device".
+__device__ __forceinline__ void mask_put(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// four consecutive words at once (16-byte aligned): one fabric write instead of four
+__device__ __forceinline__ void mask_put4(unsigned* p, unsigned v) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u q = { v, v, v, v };
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(q) : "memory");
+}
+// s_waitcnt vmcnt(0) as inline asm: invisible to the compiler's wait-count insertion, so it is never merged away.
+__device__ __forceinline__ void drain_vector_memory() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// One workgroup's share of a frame's mask: cell blockInFrame * blockDim + thread.  The workgroup that finishes last (ticket)
 // publishes the "complete" word.
-__device__ __forceinline__ void mask_block(const RenderParams& P, int blockInFrame) {
+//
+// Stamps leave the CU as sc1 stores (the hand-off below needs that), and a scalar sc1 store is one fabric write: the ~20 tiles
+// a cell's rectangle covers, written cell by cell (112 k stores per config-2 frame, most of them the same few thousand words
+// over and over), made the mask complete after the frame instead of 2 us into it (69 us per frame instead of 33).  So a
+// workgroup first ORs its cells' rectangles into a bitmap of ITS tile bounding box in LDS -- its cells are neighbours in the
+// tree's level order, the box is small -- and then stores one stamp per set bit, four at a time where four neighbours are set
+// (mask_put4): ~7 k words per frame in ~2.5 k stores.  Measured at config 2, us per frame: plain stores (round 3's invalid
+// form, with this dedupe) 33.2; this form 33.6; without the x4 stores 34.7; sc1 stores cell by cell 69.  `bits` / `capWords`:
+// the launch's dynamic LDS (the traversal stacks of a tracing workgroup; a mask workgroup has no other use for it).  A
+// workgroup whose box does not fit stores per cell as before (correct, slow: scattered cells in a very large frame).
+__device__ __forceinline__ void mask_block(const RenderParams& P, int blockInFrame, unsigned* bits, int capWords) {
     unsigned* mask = P.tileMask;
     const unsigned stamp = P.maskStamp;
     const int all = P.maskAllIndex;
     const int i = blockInFrame * (int)blockDim.x + (int)threadIdx.x;
+    int kind = 0, tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;          // 0: stamps nothing, 1: the tile rectangle, 2: the "whole frame" word
     if (i < P.maskNumCells) {
         const int4 c = P.maskCells[i];
         const float vs = P.voxelSize;
@@ -640,26 +665,77 @@ __device__ __forceinline__ void mask_block(const RenderParams& P, int blockInFra
             const float sx = ((vx * iz) * P.maskInvAspTan * 0.5f + 0.5f) * (float)P.W, sy = (0.5f - (vy * iz) * P.maskInvTanH * 0.5f) * (float)P.H;
             lox = __builtin_fminf(lox, sx); hix = __builtin_fmaxf(hix, sx); loy = __builtin_fminf(loy, sy); hiy = __builtin_fmaxf(hiy, sy);
         }
-        if (!front || !(hix - lox < 1.0e7f) || !(hiy - loy < 1.0e7f)) mask[all] = stamp;        // around / behind the eye, or not finite
+        if (!front || !(hix - lox < 1.0e7f) || !(hiy - loy < 1.0e7f)) kind = 2;                  // around / behind the eye, or not finite
         else {
             // 3 pixels of margin: 2 as the host's rectangles + 1 for this float evaluation (their errors are ~1e-3 pixel)
             const float fx0 = __builtin_floorf(lox) - 3.0f, fx1 = __builtin_ceilf(hix) + 3.0f, fy0 = __builtin_floorf(loy) - 3.0f, fy1 = __builtin_ceilf(hiy) + 3.0f;
             if (!(fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(P.W - 1) || fy0 > (float)(P.H - 1))) {       // else: off the screen
-                const int tx0 = (int)__builtin_fmaxf(fx0, 0.0f) >> 3, tx1 = (int)__builtin_fminf(fx1, (float)(P.W - 1)) >> 3;
-                const int ty0 = (int)__builtin_fmaxf(fy0, 0.0f) >> 3, ty1 = (int)__builtin_fminf(fy1, (float)(P.H - 1)) >> 3;
-                if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kMaskMaxRectTiles) mask[all] = stamp;
-                else
-                    for (int y = ty0; y <= ty1; y++)
-                        for (int x = tx0; x <= tx1; x++) mask[y * P.tilesX + x] = stamp;
+                tx0 = (int)__builtin_fmaxf(fx0, 0.0f) >> 3; tx1 = (int)__builtin_fminf(fx1, (float)(P.W - 1)) >> 3;
+                ty0 = (int)__builtin_fmaxf(fy0, 0.0f) >> 3; ty1 = (int)__builtin_fminf(fy1, (float)(P.H - 1)) >> 3;
+                kind = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kMaskMaxRectTiles ? 2 : 1;
             }
         }
     }
-    __syncthreads();                                             // this workgroup's stores are issued
+    // the workgroup's tile bounding box (the first 8 words of the dynamic LDS: a static __shared__ array would add to every
+    // workgroup's LDS request, which the launchers size to the byte for a residency of 4 or 6 waves per SIMD)
+    int* box = reinterpret_cast<int*>(bits);
+    int& wholeFrame = box[4];
+    bits += 8; capWords -= 8;
+    if (threadIdx.x == 0) { box[0] = box[1] = 0x7fffffff; box[2] = box[3] = -1; wholeFrame = 0; }
+    __syncthreads();
+    if (kind == 1) { atomicMin(&box[0], tx0); atomicMin(&box[1], ty0); atomicMax(&box[2], tx1); atomicMax(&box[3], ty1); }
+    if (kind == 2) wholeFrame = 1;
+    __syncthreads();
+    const bool wide = (P.tilesX & 3) == 0;                                   // every mask row starts 16-byte aligned: runs of 4 set tiles leave as one store
+    const int bx0 = wide ? box[0] & ~3 : box[0], by0 = box[1], bx1 = box[2], by1 = box[3];
+    const int rowWords = (bx1 - bx0 + 32) >> 5, rows = by1 - by0 + 1;        // a bitmap row: whole words
+    const int words = rowWords * rows;
+    if (bx1 >= bx0 && words <= capWords) {                                   // workgroup-uniform
+        for (int w = threadIdx.x; w < words; w += blockDim.x) bits[w] = 0u;
+        __syncthreads();
+        if (kind == 1) {
+            const int a = tx0 - bx0, b = tx1 - bx0;
+            for (int wi = a >> 5; wi <= (b >> 5); wi++) {
+                const int l = max(a - (wi << 5), 0), h = min(b - (wi << 5), 31);
+                const unsigned m = (h == 31 ? ~0u : (1u << (h + 1)) - 1u) & ~((1u << l) - 1u);
+                for (int y = ty0; y <= ty1; y++) atomicOr(&bits[(y - by0) * rowWords + wi], m);
+            }
+        }
+        __syncthreads();
+        for (int w = threadIdx.x; w < words; w += blockDim.x) {
+            unsigned m = bits[w];
+            if (!m) continue;
+            const int row = w / rowWords, col = (w - row * rowWords) << 5;
+            unsigned* base = mask + (size_t)(by0 + row) * P.tilesX + bx0 + col;
+            if (wide) {
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (((m >> (4 * q)) & 0xfu) == 0xfu) { mask_put4(base + 4 * q, stamp); m &= ~(0xfu << (4 * q)); }
+            }
+            while (m) { mask_put(base + __builtin_ctz(m), stamp); m &= m - 1u; }
+        }
+    } else if (kind == 1) {
+        for (int y = ty0; y <= ty1; y++)
+            for (int x = tx0; x <= tx1; x++) mask_put(mask + y * P.tilesX + x, stamp);
+    }
+    if (threadIdx.x == 0 && wholeFrame) mask_put(mask + all, stamp);
+    // The hand-off to the frame's waves on other CUs / XCDs (tile_may_hit), in the gfx950 form whose consumer needs no acquire
+    // (MI355X_MICROARCH.md, "inter-workgroup visibility", valid forms): EVERY stamp is an sc1 store (mask_put), EVERY storing wave
+    // drains its stores before the workgroup's barrier, ONE lane signals for the whole workgroup behind that barrier, and every
+    // signal -- the ticket, the "complete" word -- sits behind an explicit s_waitcnt that the compiler cannot drop (its
+    // scoreboard pass removes the wait after buffer_wbl2 when a waited atomic has just emptied the counter: the flag could
+    // overtake the write-back).
+    drain_vector_memory();
+    __syncthreads();                                             // every wave's stamps have left the CU and are acknowledged
     if (threadIdx.x == 0) {
-        __threadfence();                                         // release them before the ticket
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // belt and braces (0.15 us per frame for both): with it the producer side is ALSO the
+                                                                 // guide's plain-store form -- stores, every wave's drain, barrier, lane-0 release, drain, signal
+        drain_vector_memory();
         const unsigned last = (unsigned)P.maskBlocks - 1u;
         if (atomicInc(mask + all + 2, last) == last) {           // the ticket wraps to 0: the next launch / replay starts from zero
-            __threadfence();                                     // acquire the other workgroups' tickets, release the word below
+            // last ticket: every other mask workgroup's stamps were complete before ITS ticket, which this add has now followed
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            drain_vector_memory();
             __hip_atomic_store(mask + all + 1, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -1238,7 +1314,7 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean(RenderPar
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64], b in [0, depth]
-    if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x); return; }        // the first workgroups build the occupancy mask
+    if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x, reinterpret_cast<unsigned*>(lds_stack), P.maskLdsBytes >> 2); return; }        // the first workgroups build the occupancy mask
     const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (int)(blockDim.x >> 6) + wave);
     if (slot >= P.launchWaves) return;
     trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
@@ -1261,7 +1337,7 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_batch(Ren
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int mb = B.P[0].maskBlocks;                          // mask workgroups per frame (every frame of a batch: the same octree)
-    if ((int)blockIdx.x < mb * B.n) { const int fm = (int)blockIdx.x / mb; mask_block(B.P[fm], (int)blockIdx.x - fm * mb); return; }
+    if ((int)blockIdx.x < mb * B.n) { const int fm = (int)blockIdx.x / mb; mask_block(B.P[fm], (int)blockIdx.x - fm * mb, reinterpret_cast<unsigned*>(lds_stack), B.P[fm].maskLdsBytes >> 2); return; }
     const int g = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - mb * B.n) * (int)(blockDim.x >> 6) + wave);
     const int slot = g / B.n, f = g - slot * B.n;
     const RenderParams& P = B.P[f];
@@ -1553,12 +1629,14 @@ __global__ __launch_bounds__(kBlock) void k_cull_desc(CullParams C, const int4* 
         __hip_atomic_store(&blockCount[blockIdx.x], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&blockFirst[blockIdx.x], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();                                     // release: the partials before the ticket
+        drain_vector_memory();                               // ... and acknowledged before it (the wait the compiler may drop)
         const unsigned t = atomicAdd(&start->ticket, 1u);
         isLast = t == gridDim.x - 1 ? 1 : 0;
     }
     __syncthreads();
     if (!isLast) return;
-    __threadfence();                                         // acquire: every block's partials
+    __threadfence();                                         // acquire: every block's partials (sc1 stores by the signalling lane, sc1 loads below)
+    drain_vector_memory();                                   // the invalidate has completed before the first load
     long long total = 0;
     int f = 0x7fffffff;
     for (int b = threadIdx.x; b < (int)gridDim.x; b += kBlock) {
@@ -2272,7 +2350,7 @@ __global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles(
     const int wave = threadIdx.x >> 6;
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64], b in [0, depth]
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds_stack + (size_t)(blockDim.x >> 6) * (P.depth + 1) * kWave) + wave * kWave;
-    if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x); return; }
+    if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x, reinterpret_cast<unsigned*>(lds_stack), P.maskLdsBytes >> 2); return; }
     const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (int)(blockDim.x >> 6) + wave);
     if (slot >= P.launchWaves) return;
     trace_tile_lean_triangles<MODE, SHADE>(P, Sc, shadow, out, counters, stk, keys, lane, slot);
@@ -2286,7 +2364,7 @@ __global__ __launch_bounds__(kBlock, RTO_TRI_WAVES) void k_trace_lean_triangles_
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int mb = B.P[0].maskBlocks;
-    if ((int)blockIdx.x < mb * B.n) { const int fm = (int)blockIdx.x / mb; mask_block(B.P[fm], (int)blockIdx.x - fm * mb); return; }
+    if ((int)blockIdx.x < mb * B.n) { const int fm = (int)blockIdx.x / mb; mask_block(B.P[fm], (int)blockIdx.x - fm * mb, reinterpret_cast<unsigned*>(lds_stack), B.P[fm].maskLdsBytes >> 2); return; }
     const int g = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - mb * B.n) * (int)(blockDim.x >> 6) + wave);
     const int slot = g / B.n, f = g - slot * B.n;
     const RenderParams& P = B.P[f];
@@ -2638,7 +2716,7 @@ __global__ __launch_bounds__(kBlock) void k_skip_render(RenderParams P, const ui
     __syncthreads();                                                     // before any wave leaves
     // launch geometry of the lean kernels: the first workgroups build the occupancy mask, waves only for the tiles of the solid
     // geometry's screen rectangle in the stream's launch order (costliest tiles of earlier frames first), wide stores for the rest
-    if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x); return; }
+    if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x, reinterpret_cast<unsigned*>(lds_skip), P.maskLdsBytes >> 2); return; }
     const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (kBlock / kWave) + wave);
     if (slot >= P.launchWaves) return;
     int tile, tx, ty;

@@ -573,6 +573,72 @@ def test_frustum_update_reads_nothing_back_and_can_be_captured(ctx, orc, scenes,
         fresh.close()
 
 
+def test_frames_on_other_streams_wait_for_the_frustum_update(ctx, orc, scenes, camera):
+    """rto_update_frustum returns as soon as its kernel is queued on the CONTEXT's stream.  A frame launched right afterwards
+    on another stream -- a caller's, or rto_comm's render stream: what RayTracerBVH::renderSceneComputeWithCulling does on
+    several GPUs -- must still see the new visibility state, not the previous update's (an event behind the update, a stream
+    wait in front of every such launch).  The update is held back here behind a queue of large frames on the context's
+    stream, so that a launch without the wait would provably run first."""
+    torch = pytest.importorskip("torch")
+    cal = scenes("calgary")
+    W, H = 480, 270
+    aspect = W / H
+    upload(ctx, cal)
+    camA = camera("calgary_oblique")
+    cB = orc.Camera(0.9, 2.5, 3000.0)
+    camB = (cB.get_view(), cB.get_pos())
+    nodesB, _ = orc.cull_compact(cal.nodes, cal.min, cal.voxel, camB[0], 45.0, aspect)
+    nodesA, _ = orc.cull_compact(cal.nodes, cal.min, cal.voxel, camA[0], 45.0, aspect)
+    assert len(nodesA) != len(nodesB)
+    fB = rto.make_frame(camB[0], camB[1], aspect, 45.0, W, H)
+    fA = rto.make_frame(camA[0], camA[1], aspect, 45.0, W, H)
+    wantB = orc.render(nodesB, cal.min, cal.voxel, camB[0], camB[1], aspect, 45.0, W, H)[0]
+    wantA_in_B = orc.render(nodesB, cal.min, cal.voxel, camA[0], camA[1], aspect, 45.0, W, H)[0]
+    assert wantA_in_B.tobytes() != orc.render(nodesA, cal.min, cal.voxel, camA[0], camA[1], aspect, 45.0, W, H)[0].tobytes(), \
+        "the two visibility states must give different pictures for this test to mean anything"
+    big = rto.make_frame(camA[0], camA[1], 3840 / 2160, 45.0, 3840, 2160)
+    other = torch.cuda.Stream()
+    out = torch.full((2, H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+    comm = hip.Comm(ctx, 1, 0, hip.comm_unique_id(), band_rows=16)
+    try:
+        ctx.update_frustum(camA[0], 45.0, aspect, enable=True)
+        ctx.render_resident(big)
+        ctx.synchronize()
+        for _ in range(12):                                     # ~1 ms of work queued in front of the update
+            ctx.render_resident(big)
+        ctx.update_frustum(camB[0], 45.0, aspect, enable=True)
+        ctx.render_device(fB, out[0].data_ptr(), None, other.cuda_stream)
+        ctx.render_device(fA, out[1].data_ptr(), None, other.cuda_stream)
+        torch.cuda.synchronize()
+        assert_bit_exact(out[0].cpu().numpy(), wantB, "foreign stream, the update's own camera")
+        assert_bit_exact(out[1].cpu().numpy(), wantA_in_B, "foreign stream, another camera through the new visibility state")
+        # the same through rto_comm's render stream (one-rank communicator, and rehearsing rank 1 of 2)
+        for world, rank in ((0, 0), (2, 1)):
+            ctx.update_frustum(camA[0], 45.0, aspect, enable=True)
+            ctx.synchronize()
+            comm.debug_rehearse(world, rank)
+            for _ in range(12):
+                ctx.render_resident(big)
+            ctx.update_frustum(camB[0], 45.0, aspect, enable=True)
+            out.fill_(7.0)
+            comm.submit(hip.Context.frame_array([fB, fA]), out.data_ptr(), out.stride(0) * 4)
+            comm.flush()
+            rows = np.ones(H, bool) if world == 0 else ((np.arange(H) // 16) % world == rank)
+            assert_bit_exact(out[0].cpu().numpy()[rows], wantB[rows], f"rto_comm (rehearsing {rank} of {world}), the update's camera")
+            assert_bit_exact(out[1].cpu().numpy()[rows], wantA_in_B[rows], f"rto_comm (rehearsing {rank} of {world}), another camera")
+        # switching culling off rewrites the descriptors as well
+        for _ in range(12):
+            ctx.render_resident(big)
+        ctx.update_frustum(camB[0], 45.0, aspect, enable=False)
+        ctx.render_device(fA, out[0].data_ptr(), None, other.cuda_stream)
+        torch.cuda.synchronize()
+        assert_bit_exact(out[0].cpu().numpy(), oracle_frame(orc, cal, camA[0], camA[1], W, H)[0], "foreign stream after culling was switched off")
+    finally:
+        comm.debug_rehearse(0)
+        comm.close()
+        ctx.update_frustum(camA[0], 45.0, aspect, enable=False)
+
+
 def test_occupancy_mask_never_changes_pixels_and_removes_work(ctx, orc, scenes):
     """The occupancy mask (mask_block: built by the first workgroups of every colour / shade launch of the default kernels) is a scheduling device:
     frames with it, without it and the oracle's are bit-identical -- cameras outside, grazing, far away, with the scene partly
@@ -869,6 +935,43 @@ def test_frames_in_flight_on_several_streams_of_one_context(ctx, orc, scenes):
             assert ctx.debug_sort_violations() == 0
     finally:
         ctx.set_launch_order(1, 8)
+
+
+def test_mask_handoff_under_uneven_concurrent_frames(ctx, orc, scenes):
+    """The occupancy mask is handed from the first workgroups of a launch to the other waves of the SAME launch, across CUs and
+    XCDs (mask_block -> tile_may_hit), and a reader that saw "complete" but a stale tile word would paint a black tile over
+    geometry.  The shape /opt/skills/guides/MI355X_MICROARCH.md asks such a hand-off to be tested in: a busy, unevenly loaded
+    chip and warm consumers -- frames of DIFFERENT cameras (cheap, costly, the eye inside the shell, the sphere half off the
+    screen) in flight on three streams of one context, mask mode 1 (built inside the launch), every stream changing camera from
+    frame to frame so that the words a wave reads were last written for another view -- and EVERY pixel of EVERY frame compared
+    with the oracle, not just the last frame per stream."""
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere256")
+    upload(ctx, s)
+    ctx.debug_set_tile_mask(1)
+    W, H = 1920, 1080
+    specs = [(0.5, 0.7, 1.8, None, 45.0), (2.1, 0.4, 1.1, None, 45.0), (0.3, 1.2, 3.5, None, 30.0), (1.0, 0.9, 0.25, None, 70.0),
+             (0.5, 0.7, 1.8, (0.9, 0.2, 0.0), 45.0), (4.0, 0.5, 0.9, (0.0, 0.6, 0.0), 60.0)]
+    frames, wants = [], []
+    for (t, p, r, tgt, fov) in specs:
+        cam = orc.Camera(t, p, r)
+        if tgt is not None:
+            cam.set_target(*[float(x) for x in tgt])
+        frames.append(rto.make_frame(cam.get_view(), cam.get_pos(), W / H, fov, W, H))
+        wants.append(oracle_frame(orc, s, cam.get_view(), cam.get_pos(), W, H, fov=fov)[0])
+    rounds, nstreams = 8, 3
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    bufs = torch.full((nstreams, rounds, H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for j in range(rounds):                      # no host wait anywhere: 24 frames queued on three streams
+        for i in range(nstreams):
+            ctx.render_device(frames[(i * 2 + j) % len(frames)], bufs[i, j].data_ptr(), None, streams[i].cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(nstreams):
+        for j in range(rounds):
+            k = (i * 2 + j) % len(frames)
+            assert_bit_exact(bufs[i, j].cpu().numpy(), wants[k], f"stream {i}, frame {j} (camera {specs[k]})")
+    assert ctx.debug_sort_violations() == 0
 
 
 def test_several_frames_in_one_launch(ctx, orc, scenes):
