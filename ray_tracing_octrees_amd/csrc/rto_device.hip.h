@@ -1254,7 +1254,9 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     // alone -- what was recorded until round 3 -- underrates every tile whose costly rays are not in its top-left corner)
     if (P.tileCost || MODE == kModeTimeline) {
         trips = __builtin_amdgcn_readlane(wave_scan_max_nonneg(trips), kWave - 1);
-        if (P.tileCost && lane == 0 && ty < P.tilesY) P.tileCost[tile] = trips;
+        // -1: no trip, but the occupancy mask said geometry may project here -- the rim of the silhouette, where a camera in
+        // motion finds work a few frames later (k_order_build ranks such tiles ahead of the certainly empty ones)
+        if (P.tileCost && lane == 0 && ty < P.tilesY) P.tileCost[tile] = (trips == 0 && tileLive && P.tileMask) ? -1 : trips;
     }
     const int leafShift = bpos + 1;                                      // on a hit: log2 of the leaf's edge
     cx &= 0x7fffff; cy &= 0x7fffff; cz &= 0x7fffff;                      // plain coordinates for the epilogue
@@ -1395,7 +1397,8 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_build(const int* __restri
     __shared__ int cnt[kWaves][kOrderBuckets];      // pass 1: counts; then each wave's write cursor per bucket
     const int n = boxW * boxH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    auto bucket_at = [&](int rx, int ry) { return min(max(tileCost[(boxY0 + ry) * tilesX + boxX0 + rx], 0), kOrderBuckets - 1); };
+    // bucket 0: nothing there; 1: no work, but inside the occupancy mask's margin (cost -1); 2..63: 1 + min(cost, 62)
+    auto bucket_at = [&](int rx, int ry) { const int c = tileCost[(boxY0 + ry) * tilesX + boxX0 + rx]; return c > 0 ? min(c, kOrderBuckets - 2) + 1 : (c < 0 ? 1 : 0); };
     for (int i = threadIdx.x; i < kWaves * kOrderBuckets; i += kOrderBlock) (&cnt[0][0])[i] = 0;
     if (staged)
         for (int ry = wave; ry < boxH; ry += kWaves)
@@ -1594,9 +1597,15 @@ __global__ __launch_bounds__(kBlock) void k_cull_desc(CullParams C, const int4* 
                                                        uint2* __restrict__ desc, uint8_t* __restrict__ vis,
                                                        int* __restrict__ blockCount, int* __restrict__ blockFirst, StartState* __restrict__ start) {
     __shared__ int redCount[kBlock / kWave], redFirst[kBlock / kWave];
-    __shared__ int isLast;
+    __shared__ int isLast, rootSeen;
     const int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     int cnt = 0, first = 0x7fffffff;
+    // Every block looks at the root itself (one box against six planes): with the root visible -- every update but the
+    // float-rounding edge below and the "everything culled" case -- traversals start at the root, nobody needs the first
+    // visible node, and the survivors are only counted when somebody asks (sync_cull_state): no partials, no ticket, no
+    // fences; the kernel is then a plain streaming pass (8.4 -> ~3 us at config 2: the two fences and the same-address atomics
+    // were most of it).
+    if (threadIdx.x == 0) { const int4 r = descPos[0]; rootSeen = node_visible(C, r.x, r.y, r.z, r.w) ? 1 : 0; }
     if (d < nInternal) {
         const int4 p = descPos[d];
         const int half = p.w >> 1;
@@ -1618,6 +1627,18 @@ __global__ __launch_bounds__(kBlock) void k_cull_desc(CullParams C, const int4* 
             cnt += v ? 1 : 0;
             if (v) first = 0;
         }
+    }
+    __syncthreads();
+    if (rootSeen) {                                              // workgroup-uniform
+        if (d == 0) {
+            StartState st;
+            st.visible = 1; st.desc = 0; st.x = st.y = st.z = 0; st.shift = depth; st.leaf = 0; st.solid = 0;
+            st.rootVisible = 1; st.firstVisible = 0;
+            st.visibleCount = -1;                                // not counted: the flags in `vis` are, when somebody asks
+            st.ticket = 0;
+            *start = st;
+        }
+        return;
     }
     for (int off = 32; off > 0; off >>= 1) { cnt += __shfl_down(cnt, off); first = min(first, __shfl_down(first, off)); }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
