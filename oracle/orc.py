@@ -366,6 +366,16 @@ def build_leaf_triangles(g: Grid, nodes):
 def render_triangles(nodes, tris, tri_offset, grid_min, voxel_size, view, cam_pos, aspect, fov_deg, W, H, shadow=True, nthreads=1):
     nodes = np.ascontiguousarray(nodes); tris = np.ascontiguousarray(tris, dtype=np.float32)
     tri_offset = np.ascontiguousarray(tri_offset, dtype=np.int32)
+    # the C side indexes these arrays without checks: a wrong-length array was a core dump (round 3, gpurun_out/r3_t33.log)
+    if tris.ndim != 2 or tris.shape[1] != 12:
+        raise ValueError(f"render_triangles: tris must have shape (n, 12), got {tris.shape}")
+    if tri_offset.ndim != 1 or len(tri_offset) != len(nodes) + 1:
+        raise ValueError(f"render_triangles: tri_offset needs len(nodes) + 1 = {len(nodes) + 1} entries, got {tri_offset.shape}")
+    if len(tri_offset) and (tri_offset[0] != 0 or tri_offset[-1] != len(tris) or (np.diff(tri_offset) < 0).any()):
+        raise ValueError("render_triangles: tri_offset must run from 0 to len(tris) without decreasing")
+    for name, a, n in (("grid_min", grid_min, 3), ("view", view, 16), ("cam_pos", cam_pos, 3)):
+        if np.asarray(a).size != n:
+            raise ValueError(f"render_triangles: {name} needs {n} floats, got {np.asarray(a).size}")
     out = np.zeros((H, W, 4), np.float32)
     st = _Stats()
     lib().orc_render_triangles(nodes.ctypes.data, len(nodes), tris.ctypes.data, tri_offset.ctypes.data, _f32(grid_min),

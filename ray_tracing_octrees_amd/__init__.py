@@ -9,7 +9,6 @@ Layers (all thin; the product is the HIP library):
                                      CacheUtils, RayTracerBVH) -> librto_host.so
   ray_tracing_octrees_amd.hip       ctypes binding of the C ABI (flat GPUNodes arrays, device pointers)
   ray_tracing_octrees_amd.host      ctypes face of the C++ host layer (same names as the reference)
-  ray_tracing_octrees_amd.tilesplit the multi-GPU split plan (a caller of rto_split_plan_make) + host-staged rehearsal helpers
 
 The HIP library is mandatory: nothing in this package computes pixels on the CPU.
 """

@@ -16,9 +16,11 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import orc  # noqa: E402
-from ray_tracing_octrees_amd import hip, tilesplit  # noqa: E402
+from ray_tracing_octrees_amd import hip  # noqa: E402
+import tilesplit  # noqa: E402  (tests/tilesplit.py: test rig, beside this file)
 
 F = np.float32
 

@@ -1821,7 +1821,7 @@ def _rehearse_every_rank(ctx, comm, frames, wants, worlds, mode, what):
     windows, grouped send/recv, assembly): the rows the PLAN gives to rank r must be the oracle's, and together they are the
     whole frame.  The plan comes from the exported planner, i.e. this also checks that rto_comm_* does what rto_split_plan_make says."""
     import torch
-    from ray_tracing_octrees_amd import tilesplit
+    import tilesplit
 
     H, W = wants[0].shape[:2]
     n = len(frames)

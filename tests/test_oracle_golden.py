@@ -295,3 +295,20 @@ def test_oracle_against_live_reference_random_grids(orc):
         data = (rng.random((dims[2], dims[1], dims[0])) < p).astype(np.uint8)
         g = orc.Grid(dims, np.array([0.5, -2.0, 3.0], np.float32), np.float32(0.3), data)
         assert orc.build_flat_octree(g).tobytes() == orc.ref_build_flat_octree(g).tobytes(), dims
+
+
+def test_render_triangles_refuses_arrays_of_the_wrong_shape(orc, scenes):
+    """The oracle's C side indexes tris / tri_offset unchecked: a camera-aim array passed as tri_offset was a core dump on the GPU
+    box in round 3 (gpurun_out/r3_t33.log).  The wrapper now raises instead."""
+    s = scenes("sphere16")
+    tris, off = orc.build_leaf_triangles(s.grid, s.nodes)
+    cam = orc.Camera(0.5, 0.7, 1.8)
+    args = (s.min, s.voxel, cam.get_view(), cam.get_pos(), 1.0, 45.0, 16, 16)
+    orc.render_triangles(s.nodes, tris, off, *args)
+    for bad_off in (np.zeros(3, np.float32), off[:-1], off + 1, off[::-1].copy()):
+        with pytest.raises(ValueError):
+            orc.render_triangles(s.nodes, tris, bad_off, *args)
+    with pytest.raises(ValueError):
+        orc.render_triangles(s.nodes, tris[:, :9], off, *args)
+    with pytest.raises(ValueError):
+        orc.render_triangles(s.nodes, tris, off, s.min, s.voxel, cam.get_view()[:3], cam.get_pos(), 1.0, 45.0, 16, 16)

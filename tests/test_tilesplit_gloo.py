@@ -10,7 +10,8 @@ import sys
 import numpy as np
 import pytest
 
-from ray_tracing_octrees_amd import hip, tilesplit
+from ray_tracing_octrees_amd import hip
+import tilesplit
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

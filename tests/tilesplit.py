@@ -1,4 +1,5 @@
-"""The split plan of the multi-GPU path, as seen from Python: a caller of the C ABI's planner.
+"""TEST RIG (lives under tests/, not in the product package): the split plan of the multi-GPU path, as seen from Python --
+a caller of the C ABI's planner.
 
 The product's screen split lives below the C boundary (`rto_comm_*`, csrc/rto_comm.inc); everything its ranks must agree
 on -- who renders, which part a rank owns, the column window of every frame that travels, offsets and float counts -- is
@@ -16,7 +17,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import hip
+from ray_tracing_octrees_amd import hip
 
 F = np.float32
 
