@@ -1445,10 +1445,16 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
             skip = raster_tiles(P, v, slot - P.listedSlots, lane, slot, tx, ty, live);
         } else n = 0;
     }
-    for (int i = 0; i < n; i++) {                                // wave-uniform
-        if ((skip >> i) & 1u) continue;
-        const bool tileLive = raster ? ((live >> i) & 1u) != 0 : tile_may_hit(P, tx + i, ty, slot);
-        trace_tile_lean_at<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot, tx + i, ty, tileLive);
+    // two copies of the tile function: the one-tile slots (table or listed: nearly every wave with work) keep the straight-line
+    // code -- wrapped in the raster slots' loop it needed 68 more SGPRs than there are, and every wave paid ~170 v_writelane /
+    // v_readlane for the spills (3 us per config-2 frame)
+    if (!raster) {
+        if (n) trace_tile_lean_at<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot, tx, ty, tile_may_hit(P, tx, ty, slot));
+    } else {
+        for (int i = 0; i < kRasterTiles; i++) {                 // wave-uniform
+            if ((skip >> i) & 1u) continue;
+            trace_tile_lean_at<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot, tx + i, ty, ((live >> i) & 1u) != 0);
+        }
     }
     fill_outside<MODE>(P, out, lane, slot);
 }
