@@ -103,7 +103,6 @@ def parse_args(argv=None):
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1: drive the frames through rto_comm_* with a one-rank RCCL communicator (rehearses the N>1 code path on one GPU)")
     ap.add_argument("--no-tile-mask", action="store_true", help="A/B: switch the occupancy mask of the default kernels off (rto_debug_set_tile_mask)")
-    ap.add_argument("--no-launch-lists", action="store_true", help="A/B: plain launches take their order from the slot -> tile table instead of the device-resident launch lists")
     ap.add_argument("--launcher-dry-run", action="store_true", help="--gpus N without WORLD_SIZE: print the child command line and exit")
     return ap.parse_args(argv)
 
@@ -324,8 +323,6 @@ def main(argv=None):
     ctx.set_launch_order(1 if args.order == "temporal" else 0, args.order_period)
     if args.no_tile_mask:
         ctx.debug_set_tile_mask(False)
-    if args.no_launch_lists:
-        ctx.debug_set_launch_lists(False)
     info = ctx.info()
     use_comm = world > 1 or args.force_comm
     pipelined = use_comm and not args.no_pipeline
@@ -752,7 +749,7 @@ def main(argv=None):
                 "workload_detail": f"BASELINE config {args.config}: {what} ({info.num_nodes} nodes), {W}x{H} primary rays"
                                    f"{', Marching-Cubes leaf triangles + 1 shadow ray per hit' if triangles else ''}, {camtxt}, fov 45",
                 "parallelism": parallelism,
-                "kernel": args.kernel, "tile_mask": (not args.no_tile_mask), "launch_lists": (not args.no_launch_lists),
+                "kernel": args.kernel, "tile_mask": (not args.no_tile_mask),
                 "clock_ramp": (f"{ramp_frames} untimed frames ({args.ramp_ms:.0f} ms) before the {args.warmup} warm-up frames" if ramp_frames else
                                (f"{primed} untimed frames in full batches before the {args.warmup} warm-up frames" if primed else "none")),
             },

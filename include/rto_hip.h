@@ -378,15 +378,6 @@ int  rto_debug_set_tile_order(rto_context* ctx, const int32_t* host_order, int64
  * (0: no mask for this octree). */
 int  rto_debug_set_tile_mask(rto_context* ctx, int enabled);
 int  rto_debug_tile_mask_info(const rto_context* ctx, int* level, int* num_cells);
-/* Launch lists: plain single-frame launches of the default kernels keep their launch order on the device --
- * every wave whose tile had work appends the tile to the list of its cost bucket, the next frame's launch slots read the lists
- * (costliest first), the slots behind walk the box in raster order and render what no listed slot does.  One frame old, no sort
- * kernel between frames.  enabled = 0: such launches use the slot -> tile table of rto_set_launch_order again (A/B runs, tests);
- * 1 (default): on.  Pixels never depend on it. */
-int  rto_debug_set_launch_lists(rto_context* ctx, int enabled);
-/* out[0] = frames rendered through the lists of the last frame's (stream, kind), out[1] = listed slots of its grid, out[2] = the count
- * the host last saw, out[3 + 16 i + b] = tiles in cost bucket b of buffer i (three buffers rotate).  Synchronises. */
-int  rto_debug_launch_lists_info(rto_context* ctx, int32_t out[51]);
 /* Writes the launch-order sort refused because they fell outside the table (must be 0; synchronises). */
 int  rto_debug_sort_violations(rto_context* ctx, int* count);
 /* Device time in ms of the most recent traversal kernel launched by this context

@@ -72,7 +72,6 @@ struct rto_context {
     int numCUs = 256;
     int residentW = 0, residentH = 0;   // size of the frame rto_render_resident left in d_frame
     int orderPolicy = 1;            // 0 = centre-out only, 1 = temporal (falls back to centre-out without history)
-    bool listsEnabled = true;       // launch lists for plain single-frame lean launches (rto_debug_set_launch_lists)
     int orderPeriod = 8;            // rebuild the table every orderPeriod-th frame: cost maps change slowly (tools/order_period.py:
                                     // 8 or 16 beat 4 for a static, an orbiting and a fast-moving camera alike)
     struct OrderState {
@@ -93,22 +92,6 @@ struct rto_context {
         unsigned* d_tileMask = nullptr; // occupancy masks of the frames of one launch: kMaxBatch regions of maskWords words (mask_block)
         size_t maskWords = 0;           // strips * tilesX + 1 of the frame size the buffer was made for
         unsigned long lastUse = 0;      // orderClock value of the last launch on this stream (eviction order)
-        // launch lists (rto_device.hip.h, "launch lists"): plain single-frame launches of the lean kernels keep their launch order on
-        // the device -- every wave with work lists its tile by cost, the next frame's slots read the lists: one frame old, no sort kernel
-        int* d_listCounts = nullptr;    // [3][kListBuckets]
-        int* d_listTiles = nullptr;     // [3][kListBuckets][listCap]
-        int* d_listKey = nullptr;       // [tiles]
-        int* h_listCount = nullptr;     // host-mapped word the kernels leave the previous frame's total in (sizes the next grid; any value is safe)
-        int* d_listCountAlias = nullptr;    // its device address
-        int listCap = 0, listKeyTiles = 0, lastListedSlots = 0;
-        unsigned long listFrame = 0;    // frames rendered through the lists: buffers rotate cur = listFrame % 3
-        void free_all() {
-            (void)hipFree(d_tileCost); (void)hipFree(tab[0].d); (void)hipFree(tab[1].d); (void)hipFree(d_queue); (void)hipFree(d_tileMask);
-            (void)hipFree(d_listCounts); (void)hipFree(d_listTiles); (void)hipFree(d_listKey);
-            if (h_listCount) (void)hipHostFree(h_listCount);
-            d_tileCost = tab[0].d = tab[1].d = d_queue = nullptr; d_tileMask = nullptr;
-            d_listCounts = d_listTiles = d_listKey = h_listCount = d_listCountAlias = nullptr; listCap = listKeyTiles = 0;
-        }
     };
     typedef std::pair<hipStream_t, int> OrderKey;       // launch stream, path (0 octree / 1 triangle / 2 nearest-hit frames): an application that
                                                          // renders two kinds of frame on one stream keeps a history for each
@@ -275,7 +258,7 @@ void rto_destroy(rto_context* c) {
     (void)hipFree(c->d_frame);
     (void)hipFree(c->d_rayX);
     (void)hipFree(c->d_rayY);
-    for (auto& kv : c->orders) kv.second.free_all();
+    for (auto& kv : c->orders) { (void)hipFree(kv.second.d_tileCost); (void)hipFree(kv.second.tab[0].d); (void)hipFree(kv.second.tab[1].d); (void)hipFree(kv.second.d_queue); (void)hipFree(kv.second.d_tileMask); }
     c->orders.clear();
     (void)hipFree(c->d_mcCases);
     (void)hipFree(c->d_steps);
@@ -787,7 +770,7 @@ int rto_forget_stream(rto_context* c, void* hip_stream) {
             RTO_HIP(c, hipDeviceSynchronize());  // no kernel still reads the tables
             synced = true;
         }
-        it->second.free_all();
+        (void)hipFree(it->second.d_tileCost); (void)hipFree(it->second.tab[0].d); (void)hipFree(it->second.tab[1].d); (void)hipFree(it->second.d_queue); (void)hipFree(it->second.d_tileMask);
         if (c->lastOrderKey == it->first) c->lastOrderKey = rto_context::OrderKey(nullptr, -1);
         it = c->orders.erase(it);
     }
@@ -798,31 +781,6 @@ int rto_debug_set_tile_mask(rto_context* c, int enabled) {
     if (!c) return RTO_E_INVALID;
     if (enabled < 0 || enabled > 2) return fail(c, RTO_E_INVALID, "rto_debug_set_tile_mask: 0 off, 1 on, 2 on and complete before the frame starts");
     c->maskMode = enabled;
-    return RTO_OK;
-}
-
-int rto_debug_set_launch_lists(rto_context* c, int enabled) {
-    if (!c) return RTO_E_INVALID;
-    if (enabled != 0 && enabled != 1) return fail(c, RTO_E_INVALID, "rto_debug_set_launch_lists: 0 off, 1 on");
-    c->listsEnabled = enabled != 0;
-    return RTO_OK;
-}
-
-// Developer aid / tests: the launch lists of the last frame's (stream, kind): out[0] = frames rendered through them, out[1] = listed slots of
-// the last grid, out[2] = the count the host last saw, out[3 + 16 i + b] = tiles in bucket b (all shards) of buffer i.  Synchronises.
-int rto_debug_launch_lists_info(rto_context* c, int32_t out[3 + 3 * 16]) {
-    if (!c || !out) return RTO_E_INVALID;
-    std::memset(out, 0, (3 + 3 * kListBuckets) * sizeof(int32_t));
-    auto it = c->orders.find(c->lastOrderKey);
-    if (it == c->orders.end() || !it->second.d_listCounts) return RTO_OK;
-    RTO_HIP(c, hipSetDevice(c->device));
-    RTO_HIP(c, hipDeviceSynchronize());
-    out[0] = (int32_t)it->second.listFrame; out[1] = it->second.lastListedSlots; out[2] = *it->second.h_listCount;
-    int raw[3 * kListCounters];
-    RTO_HIP(c, hipMemcpy(raw, it->second.d_listCounts, sizeof raw, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 3; i++)
-        for (int h = 0; h < kListShards; h++)
-            for (int b = 0; b < kListBuckets; b++) out[3 + kListBuckets * i + b] += raw[i * kListCounters + h * kListBuckets + b];
     return RTO_OK;
 }
 
@@ -1293,7 +1251,6 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     P.tileOrder = nullptr; P.tileCost = nullptr;
     P.start = nullptr;                     // the lean kernels' launchers point it at the device-side start state while culling is active
     P.tileMask = nullptr; P.maskStamp = 0; P.maskAllIndex = 0; P.maskBlocks = 0; P.maskTrustSlots = 0; P.maskCells = nullptr; P.maskNumCells = 0; P.maskLdsBytes = 0;
-    P.listCounts = P.listTiles = P.listKey = P.listHostCount = nullptr; P.listCap = 0; P.listKeyTiles = 0; P.listPrev = P.listCur = P.listNext = 0; P.listedSlots = 0; P.rasterPerRow = 1;
     P.maskInvAspTan = P.maskInvTanH = 0.0f;                                 // prepare_schedule switches the occupancy mask on for lean colour / shade frames
     for (int r = 0; r < 3; r++) for (int k = 0; k < 4; k++) P.viewRows[r * 4 + k] = f->view[k * 4 + r];   // column-major glm matrix -> rows
     {   // rays through pixels outside these rectangles miss the root box / every solid leaf for certain
@@ -1344,7 +1301,8 @@ static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, int p
         for (auto jt = c->orders.begin(); jt != c->orders.end(); ++jt)
             if (jt->second.lastUse < victim->second.lastUse) victim = jt;
         (void)hipDeviceSynchronize();
-        victim->second.free_all();
+        (void)hipFree(victim->second.d_tileCost); (void)hipFree(victim->second.tab[0].d); (void)hipFree(victim->second.tab[1].d);
+        (void)hipFree(victim->second.d_queue); (void)hipFree(victim->second.d_tileMask);
         if (c->lastOrderKey == victim->first) c->lastOrderKey = rto_context::OrderKey(nullptr, -1);
         c->orders.erase(victim);
     }
@@ -1367,7 +1325,7 @@ static int mask_parts_max(int path) {
 // the costs earlier frames recorded.  frameMode: a colour / shade frame (records costs); otherwise (instrumentation) the
 // whole image keeps one wave per tile.  On return Q holds the geometry, the table and the cost pointer.
 static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool frameMode, bool timelineMode, int path, const int rect[4],
-                            RenderParams& Q, rto_context::OrderState** stOut, int maskRegion = -1, bool allowLists = false) {
+                            RenderParams& Q, rto_context::OrderState** stOut, int maskRegion = -1) {
     const RenderParams& P = Q;
     const int tiles = P.tilesX * P.tilesY;
     Q.tileOrder = nullptr; Q.tileCost = nullptr;
@@ -1416,10 +1374,7 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
             RTO_HIP(c, hipMalloc(&o->tab[1].d, (size_t)tiles * sizeof(int)));
             o->tiles = tiles; o->tab[0].valid = o->tab[1].valid = false; o->costValid = false; o->fixed = false;
         }
-        if (std::memcmp(key, o->key, sizeof key) != 0) {
-            o->tab[0].valid = o->tab[1].valid = false; o->costValid = false; o->fixed = false; std::memcpy(o->key, key, sizeof key);
-            if (o->d_listCounts && !capturing) RTO_HIP(c, hipMemsetAsync(o->d_listCounts, 0, 3 * kListCounters * sizeof(int), s));     // another kind of frame: its lists start empty
-        }
+        if (std::memcmp(key, o->key, sizeof key) != 0) { o->tab[0].valid = o->tab[1].valid = false; o->costValid = false; o->fixed = false; std::memcpy(o->key, key, sizeof key); }
         o->active = capturing ? 1 : 0;
         if (capturing) {
             // a capture's first frame on this stream always gets a rebuild node of its own: whatever plain launches, another
@@ -1448,50 +1403,6 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
                              rect[0], rect[2], rect[1], rect[3], Q.boxX0, Q.boxY0, Q.boxW, Q.boxH, Q.traceWaves, Q.launchWaves);
             }
         }
-    }
-    // Launch lists: the order of a plain single-frame launch of a lean kernel lives on the device (one frame old, no sort kernel
-    // between frames).  Not for captured launches (a replay would re-use the buffer indices baked into its nodes), caller-supplied
-    // orders, batches; those keep the table below.
-    if (o && allowLists && !capturing && !fixedOrder && (frameMode || timelineMode) && Q.traceWaves > 0 && c->listsEnabled) {
-        // entries per (bucket, shard) list: an eighth of the tiles -- a bucket that holds every tile of the frame still fits its 16 shards
-        // with room for an uneven hash; a list that overflows sends the tile to the raster slots
-        const int cap = std::max(64, std::min(tiles, 65536) / 8);
-        if (!o->d_listCounts || o->listCap != cap || o->listKeyTiles != tiles) {
-            (void)hipFree(o->d_listCounts); (void)hipFree(o->d_listTiles); (void)hipFree(o->d_listKey);
-            o->d_listCounts = o->d_listTiles = o->d_listKey = nullptr; o->listCap = 0;
-            hipError_t e = hipMalloc(&o->d_listCounts, 3 * kListCounters * sizeof(int));
-            if (e == hipSuccess) e = hipMalloc(&o->d_listTiles, (size_t)3 * kListCounters * cap * sizeof(int));
-            if (e == hipSuccess) e = hipMalloc(&o->d_listKey, (size_t)3 * tiles * sizeof(int));
-            if (e == hipSuccess && !o->h_listCount) {
-                e = hipHostMalloc(reinterpret_cast<void**>(&o->h_listCount), sizeof(int), hipHostMallocMapped);
-                if (e == hipSuccess) { *o->h_listCount = 0; e = hipHostGetDevicePointer(reinterpret_cast<void**>(&o->d_listCountAlias), o->h_listCount, 0); }
-            }
-            if (e == hipSuccess) e = hipMemset(o->d_listCounts, 0, 3 * kListCounters * sizeof(int));
-            if (e == hipSuccess) e = hipMemset(o->d_listKey, 0xff, (size_t)3 * tiles * sizeof(int));   // bucket 255: "never listed"
-            if (e != hipSuccess) {
-                (void)hipFree(o->d_listCounts); (void)hipFree(o->d_listTiles); (void)hipFree(o->d_listKey);
-                o->d_listCounts = o->d_listTiles = o->d_listKey = nullptr;
-                return fail(c, RTO_E_HIP, std::string("render: launch lists: ") + hipGetErrorString(e));
-            }
-            o->listCap = cap; o->listKeyTiles = tiles; o->listFrame = 0;
-        }
-        // the grid's listed region: the previous frames' count as the kernels left it in host memory (read without any ordering:
-        // too small a region only sends the overflow to the raster slots, too large a one costs empty waves)
-        const int seenRaw = *const_cast<volatile int*>(o->h_listCount);
-        const int seen = seenRaw > 0 ? seenRaw : 0;
-        const int boxTiles = Q.boxW * Q.boxH;
-        int listed = std::min(boxTiles, std::max(seen + seen / 8 + 64, 256));
-        listed = (listed + 3) & ~3;
-        Q.rasterPerRow = (Q.boxW + kRasterTiles - 1) / kRasterTiles;
-        Q.listedSlots = listed; o->lastListedSlots = listed;
-        Q.traceWaves = listed + Q.boxH * Q.rasterPerRow;
-        Q.launchWaves = std::max(Q.traceWaves, std::min(Q.fillChunks, 8 * c->numCUs));
-        const unsigned long k = o->listFrame++;
-        Q.listCur = (int)(k % 3); Q.listNext = (int)((k + 1) % 3); Q.listPrev = (int)((k + 2) % 3);
-        Q.listCounts = o->d_listCounts; Q.listTiles = o->d_listTiles; Q.listKey = o->d_listKey; Q.listHostCount = o->d_listCountAlias; Q.listCap = cap; Q.listKeyTiles = tiles;
-        Q.tileOrder = nullptr;
-        Q.tileCost = o->d_tileCost; o->costValid = true;
-        return RTO_OK;
     }
     if (o) {
         rto_context::OrderState::Table& T = o->tab[o->active];
@@ -1595,7 +1506,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
             {
                 const bool maskable = leanKernel && c->kernelMode != RTO_KERNEL_PACKED_PERSISTENT;
-                const int rc = prepare_schedule(c, s, capturing, frameMode, MODE == kModeTimeline, 0, solidRect, Q, &st, maskable ? 0 : -1, maskable);
+                const int rc = prepare_schedule(c, s, capturing, frameMode, MODE == kModeTimeline, 0, solidRect, Q, &st, maskable ? 0 : -1);
                 if (rc != RTO_OK) return rc;
             }
             const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
@@ -1604,7 +1515,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             // 4 resident waves per SIMD when the frame's waves with work would all be resident at once at 6 (see lds_for_occupancy): about
             // 40 % of the box's tiles have work behind the mask, so up to 3 x the machine's slots at 6 per SIMD.  Config 2 (14,280 tiles)
             // 32.8 us at 4 against 36.5 at 6; config 4 (28,652 tiles) 71.6 at 4 against 69.3 at 6.
-            const bool fewWaves = Q.boxW * Q.boxH <= 3 * 6 * 4 * c->numCUs;
+            const bool fewWaves = Q.traceWaves <= 3 * 6 * 4 * c->numCUs;
             const size_t lds = Q.tileMask ? lds_for_occupancy(ldsLean, fewWaves ? 4 : 0) : (leanKernel && !(c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT) ? lds_for_occupancy(ldsLean, 0) : ldsStacks);
             Q.maskLdsBytes = (int)lds;
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone

@@ -118,17 +118,6 @@ struct RenderParams {
     int maskLdsBytes;               // dynamic LDS of the launch: a mask workgroup gathers its stamps there (mask_block)
     float maskInvAspTan, maskInvTanH;   // 1 / (aspect * tan(fov/2)), 1 / tan(fov/2)
     float viewRows[12];             // rows 0..2 of the view matrix
-    // Device-resident launch lists (plain single-frame launches of the lean kernels; "launch lists" below): who had work in the
-    // previous frame of this kind on this stream, by cost.  listCounts == null: off (slot -> tile through tileOrder / centre-out).
-    int* listCounts;                // [3][kListShards][kListBuckets] tiles listed per (bucket, shard) by the frame that wrote buffer i
-    int* listTiles;                 // [3][kListBuckets][kListShards][listCap] the tiles, tx | ty << 16 (tile coordinates of this part's image)
-    int* listKey;                   // [3][listKeyTiles] where the tile's wave listed it in the frame that filled buffer i: bucket << 28 | shard << 24 | rank
-    int listKeyTiles;               // tilesX * tilesY of the frames the arrays were made for
-    int* listHostCount;             // host-mapped word: the previous frame's total, for the host's next grid (any value is safe)
-    int listCap;                    // entries per list
-    int listPrev, listCur, listNext;    // the buffer this frame reads, the one it fills, the one it zeroes
-    int listedSlots;                // launch slots [0, listedSlots) take one listed tile each, costliest bucket first ...
-    int rasterPerRow;               // ... the slots behind walk the box in raster order, kRasterTiles tiles of a row each, and render what no listed slot does
 };
 constexpr int kMaskTrustSlots = 1024;   // the first launch slots (the costliest tiles of the previous frame) never consult the mask
 
@@ -612,104 +601,6 @@ __device__ __forceinline__ int wave_scan_max_nonneg(int v) {       // values >= 
     v = max(v, dpp0<0x142, 0xa>(v));
     v = max(v, dpp0<0x143, 0xc>(v));
     return v;
-}
-
-// ================================================================ launch lists
-// The frame ends when its costliest tiles end, so they must start first -- from costs that are ONE frame old, without a sort
-// kernel between frames.  Every wave whose tile had work appends the tile to a list at the end of its walk: one returning atomic
-// on a counter (its latency hides behind the pixel stores), the tile into listTiles[...][rank], where it went into listKey[tile]
-// -- of the buffer being filled: the raster slots of the same launch still look tiles up in the previous one.  There is one
-// list per (cost bucket, shard): 16 buckets by trip count x 16 shards by a hash of the wave's launch slot.  The shards exist
-// for the atomics only: waves of one bucket end together, and a thousand returning atomics on ONE address complete 20 ns apart
-// -- the waves held their slots for 30 us instead of 15 (measured: 82 us per config-2 frame with 32 unsharded buckets).  A
-// bucket's shards lie 64 bytes apart, in different lines.
-// The next frame of this kind on this stream reads the 256 counters (lane L: four consecutive lists in launch order,
-// costliest bucket first), takes a prefix sum in registers, and launch slot s < listedSlots renders the s-th listed tile.
-// Behind the listed slots come the raster slots: each walks kRasterTiles consecutive tiles of a box row and renders those that
-// no listed slot of THIS launch renders -- decided by looking the tile's key up in the very arrays the listed slots read: a
-// tile is skipped only if listTiles holds it at the key's place, the place lies below its list's count and the slot it maps to
-// exists.  Whatever the arrays hold (first frame, another box, stale keys, a grid sized from an old count), every tile of the
-// box is therefore rendered at least once; twice is harmless (same pixels).  Most raster tiles are empty: several per wave
-// instead of a wave each, their occupancy-mask words fetched together.
-// Three buffers rotate: a frame reads `prev`, fills `cur`, and its slot-0 wave zeroes the counters of `next`.
-constexpr int kListBuckets = 16, kListShards = 16, kListCounters = kListBuckets * kListShards;
-constexpr int kRasterTiles = 8;
-__device__ __forceinline__ int list_bucket(int cost) { return cost < 0 ? 0 : 1 + min((cost - 1) / 5, kListBuckets - 2); }       // cost != 0
-__device__ __forceinline__ int list_shard(int slot) { return (slot ^ (slot >> 4)) & (kListShards - 1); }
-// counter of (buffer, bucket, shard); the lists are read in the order q = (15 - bucket) * 16 + shard
-__device__ __forceinline__ int list_counter(int buffer, int bucket, int shard) { return buffer * kListCounters + shard * kListBuckets + bucket; }
-__device__ __forceinline__ size_t list_base(const RenderParams& P, int buffer, int bucket, int shard) {
-    return ((size_t)(buffer * kListBuckets + bucket) * kListShards + shard) * (size_t)P.listCap;
-}
-
-struct ListView { int c[4], sum, incl, n; };     // lane L: sizes of the lists q = 4L .. 4L+3, their sum, the running total; n: listed slots in use
-__device__ __forceinline__ ListView list_view(const RenderParams& P, int lane, int& total) {
-    ListView v;
-    const int b = kListBuckets - 1 - (lane >> 2), h0 = (lane & 3) * 4;
-#pragma unroll
-    for (int k = 0; k < 4; k++) v.c[k] = min(max(P.listCounts[list_counter(P.listPrev, b, h0 + k)], 0), P.listCap);
-    v.sum = (v.c[0] + v.c[1]) + (v.c[2] + v.c[3]);
-    v.incl = wave_scan_add(v.sum);
-    total = __builtin_amdgcn_readlane(v.incl, kWave - 1);
-    v.n = min(total, P.listedSlots);
-    return v;
-}
-// listed slot s < v.n -> its tile (wave-uniform); false: the entry does not name a tile of the box
-__device__ __forceinline__ bool listed_tile(const RenderParams& P, const ListView& v, int s, int& tx, int& ty) {
-    const int L = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(v.incl > s));
-    int r = s - (__builtin_amdgcn_readlane(v.incl, L) - __builtin_amdgcn_readlane(v.sum, L));
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) { const int ci = __builtin_amdgcn_readlane(v.c[i], L); if (k == i && r >= ci) { r -= ci; k = i + 1; } }
-    const int b = kListBuckets - 1 - (L >> 2), h = (L & 3) * 4 + k;
-    const int e = __builtin_amdgcn_readfirstlane(P.listTiles[list_base(P, P.listPrev, b, h) + r]);
-    tx = e & 0xffff; ty = (int)((unsigned)e >> 16);
-    return tx >= P.boxX0 && tx < P.boxX0 + P.boxW && ty >= P.boxY0 && ty < P.boxY0 + P.boxH;
-}
-// raster slot j: tiles (tx0 + i, ty), i < kRasterTiles; returns the mask of those some listed slot of this launch renders
-// (bits of tiles outside the row are set too: nothing to do there); `live`: the occupancy mask's verdict on the others.
-// The cross-lane reads run with every lane active: a ds_bpermute returns 0 for a source lane that is switched off.
-__device__ __forceinline__ unsigned raster_tiles(const RenderParams& P, const ListView& v, int j, int lane, int slot, int& tx0, int& ty, unsigned& live) {
-    const int ry = j / P.rasterPerRow;
-    const int rx0 = (j - ry * P.rasterPerRow) * kRasterTiles;
-    tx0 = P.boxX0 + rx0; ty = P.boxY0 + ry;
-    const bool mine = lane < kRasterTiles && ry < P.boxH && rx0 + lane < P.boxW;
-    const int tx = tx0 + lane;
-    unsigned key = 0xffffffffu;
-    if (mine) key = (unsigned)P.listKey[(size_t)P.listPrev * P.listKeyTiles + ty * P.tilesX + tx];
-    const unsigned b = key >> 28, h = (key >> 24) & 15u, rank = key & 0xffffffu;
-    const int q = (kListBuckets - 1 - (int)b) * kListShards + (int)h, src = q >> 2, k = q & 3;
-    const int c0 = __shfl(v.c[0], src), c1 = __shfl(v.c[1], src), c2 = __shfl(v.c[2], src), c3 = __shfl(v.c[3], src);
-    const int before = __shfl(v.incl, src) - __shfl(v.sum, src) + (k > 0 ? c0 : 0) + (k > 1 ? c1 : 0) + (k > 2 ? c2 : 0);
-    const int ck = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
-    bool covered = !mine;
-    if (mine && key != 0xffffffffu && (int)rank < ck && before + (int)rank < v.n)
-        covered = P.listTiles[list_base(P, P.listPrev, (int)b, (int)h) + rank] == (tx | (ty << 16));
-    // the occupancy mask for the tiles this wave will render: all words in one round trip (tile_may_hit, per lane)
-    bool alive = true;
-    if (mine && !covered && P.tileMask && ty < P.tilesY && slot >= P.maskTrustSlots &&
-        __hip_atomic_load(P.tileMask + P.maskAllIndex + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp) {
-        asm volatile("" ::: "memory");
-        const int strip = global_row(P, ty * 8) >> 3;
-        alive = __hip_atomic_load(P.tileMask + strip * P.tilesX + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp ||
-                __hip_atomic_load(P.tileMask + P.maskAllIndex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp;
-    }
-    live = (unsigned)__builtin_amdgcn_ballot_w64(alive) & ((1u << kRasterTiles) - 1u);
-    return (unsigned)__builtin_amdgcn_ballot_w64(covered) & ((1u << kRasterTiles) - 1u);
-}
-// a wave lists its tile (cost != 0): the atomic first ...
-__device__ __forceinline__ int list_take_rank(const RenderParams& P, int cost, int lane, int slot) {
-    int rank = -1;
-    if (lane == 0) rank = atomicAdd(&P.listCounts[list_counter(P.listCur, list_bucket(cost), list_shard(slot))], 1);
-    return rank;
-}
-// ... the entry once the rank is back (after the pixel stores)
-__device__ __forceinline__ void list_put(const RenderParams& P, int cost, int rank, int lane, int slot, int tx, int ty, int tile) {
-    if (lane == 0 && rank >= 0 && rank < P.listCap) {
-        const int b = list_bucket(cost), h = list_shard(slot);
-        P.listTiles[list_base(P, P.listCur, b, h) + rank] = tx | (ty << 16);
-        P.listKey[(size_t)P.listCur * P.listKeyTiles + tile] = (int)(((unsigned)b << 28) | ((unsigned)h << 24) | (unsigned)rank);
-    }
 }
 
 // ================================================================ screen-space occupancy mask
@@ -1244,16 +1135,15 @@ __device__ __forceinline__ unsigned child_fail_mask_exact(float gx, float gy, fl
     return fail;
 }
 
-// One tile (tx, ty) of this part's image by one wave.  `slot`: the launch slot the wave came in by (the mask's trusted slots, the
-// timeline record); the fill duty of the slot is the caller's.
 template <int MODE>
-__device__ __forceinline__ void trace_tile_lean_at(const RenderParams& P, const uint2* __restrict__ desc, float4* __restrict__ out,
-                                                   int* __restrict__ stepsOut, Counters* __restrict__ counters, uint2* stk,
-                                                   const int lane, const int slot, const int tx, const int ty, const bool tileLive) {
+__device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uint2* __restrict__ desc, float4* __restrict__ out,
+                                                int* __restrict__ stepsOut, Counters* __restrict__ counters, uint2* stk,
+                                                const int lane, const int slot) {
     unsigned long long tl0 = 0;
     if (MODE == kModeTimeline) tl0 = wall_clock64();
 
-    const int tile = ty * P.tilesX + tx;
+    int tile, tx, ty;
+    resolve_slot(P, slot, tx, ty, tile);
     const int px = tx * 8 + (lane & 7);
     const int ly = ty * 8 + (lane >> 3);
     const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
@@ -1276,6 +1166,7 @@ __device__ __forceinline__ void trace_tile_lean_at(const RenderParams& P, const 
         startVisible = st.visible; startShift = st.shift; startSize = 1 << st.shift; startX = st.x; startY = st.y; startZ = st.z;
         startDesc = st.desc; startLeaf = st.leaf != 0; startSolid = st.solid != 0;
     }
+    const bool tileLive = tile_may_hit(P, tx, ty, slot);                // wave-uniform
     if (inImage && startVisible && tileLive) {
         steps0 = 1;
         if (!outsideRoot) {
@@ -1361,17 +1252,12 @@ __device__ __forceinline__ void trace_tile_lean_at(const RenderParams& P, const 
     }
     // the tile's cost for the launch order: the trips of its BUSIEST ray (a lane keeps the count of its own last trip: lane 0's
     // alone -- what was recorded until round 3 -- underrates every tile whose costly rays are not in its top-left corner)
-    if (P.tileCost || P.listCounts || MODE == kModeTimeline) {
+    if (P.tileCost || MODE == kModeTimeline) {
         trips = __builtin_amdgcn_readlane(wave_scan_max_nonneg(trips), kWave - 1);
         // -1: no trip, but the occupancy mask said geometry may project here -- the rim of the silhouette, where a camera in
-        // motion finds work a few frames later (ranked ahead of the certainly empty tiles)
-        if (trips == 0 && tileLive && P.tileMask) trips = -1;
-        if (P.tileCost && lane == 0 && ty < P.tilesY) P.tileCost[tile] = trips;
+        // motion finds work a few frames later (k_order_build ranks such tiles ahead of the certainly empty ones)
+        if (P.tileCost && lane == 0 && ty < P.tilesY) P.tileCost[tile] = (trips == 0 && tileLive && P.tileMask) ? -1 : trips;
     }
-    // launch lists: a tile with work joins the list of its cost bucket; the rank comes back while the pixels are shaded and stored
-    const bool listIt = (MODE == kModeColor || MODE == kModeShade || MODE == kModeTimeline) && P.listCounts && trips != 0 && ty < P.tilesY;
-    int listRank = -1;
-    if (listIt) listRank = list_take_rank(P, trips, lane, slot);
     const int leafShift = bpos + 1;                                      // on a hit: log2 of the leaf's edge
     cx &= 0x7fffff; cy &= 0x7fffff; cz &= 0x7fffff;                      // plain coordinates for the epilogue
 
@@ -1393,14 +1279,14 @@ __device__ __forceinline__ void trace_tile_lean_at(const RenderParams& P, const 
     const bool mine = valid && !(P.skipOutside && outsideRoot);     // pixels outside the root rectangle belong to the fill duty
     if (MODE == kModeShade) {
         if (mine) __builtin_nontemporal_store(hit ? shade_term(P, G, r, cx, cy, cz, 1 << leafShift) : kShadeMiss, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);
-        if (listIt) list_put(P, trips, listRank, lane, slot, tx, ty, tile);
+        fill_outside<MODE>(P, out, lane, slot);
     } else if (MODE == kModeColor || MODE == kModeTimeline) {
         if (mine) {
             float4 color = make_float4(0.f, 0.f, 0.f, 1.f);
             if (hit) color = shade_color(shade_term(P, G, r, cx, cy, cz, 1 << leafShift));
             store_pixel(out + (size_t)ly * P.W + px, color);
         }
-        if (listIt) list_put(P, trips, listRank, lane, slot, tx, ty, tile);
+        fill_outside<MODE>(P, out, lane, slot);
         if (MODE == kModeTimeline) {
             const int act = __builtin_popcountll(__builtin_amdgcn_ballot_w64(steps0 + S > 1));
             if (lane == 0 && ty < P.tilesY) {
@@ -1417,46 +1303,6 @@ __device__ __forceinline__ void trace_tile_lean_at(const RenderParams& P, const 
         if (inImage) stepsOut[(size_t)py * P.W + px] = hit ? steps : -steps;
         wave_accumulate(counters, steps, hit, inImage);
     }
-}
-
-// What launch slot `slot` does: its tile(s), then its share of the fill duty.
-template <int MODE>
-__device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uint2* __restrict__ desc, float4* __restrict__ out,
-                                                int* __restrict__ stepsOut, Counters* __restrict__ counters, uint2* stk,
-                                                const int lane, const int slot) {
-    int tx = 0, ty = P.tilesY, n = 1;           // tiles (tx + i, ty), i < n, except those of `skip`
-    unsigned skip = 0, live = 0;                // raster slots: the occupancy mask's verdict per tile
-    bool raster = false;
-    if (!P.listCounts) {
-        int tile;
-        if (!resolve_slot(P, slot, tx, ty, tile)) n = 0;
-    } else {
-        int total;
-        const ListView v = list_view(P, lane, total);
-        if (slot == 0) {                                         // housekeeping of the lists: once per launch
-#pragma unroll
-            for (int k = 0; k < kListCounters / kWave; k++) P.listCounts[P.listNext * kListCounters + k * kWave + lane] = 0;
-            if (lane == 0) __hip_atomic_store(P.listHostCount, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        if (slot < P.listedSlots) {
-            if (slot >= v.n || !listed_tile(P, v, slot, tx, ty)) n = 0;
-        } else if (slot < P.traceWaves) {
-            n = kRasterTiles; raster = true;
-            skip = raster_tiles(P, v, slot - P.listedSlots, lane, slot, tx, ty, live);
-        } else n = 0;
-    }
-    // two copies of the tile function: the one-tile slots (table or listed: nearly every wave with work) keep the straight-line
-    // code -- wrapped in the raster slots' loop it needed 68 more SGPRs than there are, and every wave paid ~170 v_writelane /
-    // v_readlane for the spills (3 us per config-2 frame)
-    if (!raster) {
-        if (n) trace_tile_lean_at<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot, tx, ty, tile_may_hit(P, tx, ty, slot));
-    } else {
-        for (int i = 0; i < kRasterTiles; i++) {                 // wave-uniform
-            if ((skip >> i) & 1u) continue;
-            trace_tile_lean_at<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot, tx + i, ty, ((live >> i) & 1u) != 0);
-        }
-    }
-    fill_outside<MODE>(P, out, lane, slot);
 }
 
 #ifndef RTO_LEAN_WAVES

@@ -33,7 +33,7 @@ SYMBOLS = (
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_debug_sort_violations", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
     "rto_comm_unique_id", "rto_comm_create", "rto_comm_create_all", "rto_comm_destroy", "rto_comm_last_error", "rto_comm_submit",
     "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_comm_debug_last_payload", "rto_render_triangles_batch_device",
-    "rto_debug_set_tile_mask", "rto_debug_set_launch_lists", "rto_debug_launch_lists_info", "rto_debug_tile_mask_info", "rto_render_skip_device", "rto_render_skip_host", "rto_probe_skip_device", "rto_probe_skip_host",
+    "rto_debug_set_tile_mask", "rto_debug_tile_mask_info", "rto_render_skip_device", "rto_render_skip_host", "rto_probe_skip_device", "rto_probe_skip_host",
     "rto_scene_bounds_get", "rto_scene_bounds_of_nodes", "rto_split_plan_make", "rto_split_part_of_rank", "rto_split_rows_of_part", "rto_split_row_source",
 )
 SPLIT_MAX_FRAMES = 32
@@ -123,8 +123,6 @@ def load():
     L.rto_debug_update_frustum_planes.argtypes = [vp, C.POINTER(C.c_float), C.c_float]
     L.rto_debug_sort_violations.argtypes = [vp, C.POINTER(C.c_int)]
     L.rto_debug_set_tile_mask.argtypes = [vp, C.c_int]
-    L.rto_debug_set_launch_lists.argtypes = [vp, C.c_int]
-    L.rto_debug_launch_lists_info.argtypes = [vp, vp]
     L.rto_debug_tile_mask_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.rto_update_frustum.argtypes = [vp, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int]
     L.rto_download_visible_nodes.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
@@ -298,15 +296,6 @@ class Context:
         """0 / False: occupancy mask off; 1 / True: on (default); 2: on, built by a launch of its own in front of the frame and
         consulted by every wave (tests).  Pixels never depend on it."""
         self._check(self._L.rto_debug_set_tile_mask(self._h, int(mode)))
-
-    def debug_set_launch_lists(self, enabled: bool):
-        """Device-resident launch lists of plain single-frame launches on (default) / off (the slot -> tile table instead)."""
-        self._check(self._L.rto_debug_set_launch_lists(self._h, 1 if enabled else 0))
-
-    def debug_launch_lists_info(self) -> dict:
-        out = np.zeros(51, np.int32)
-        self._check(self._L.rto_debug_launch_lists_info(self._h, out.ctypes.data))
-        return {"frames": int(out[0]), "listed_slots": int(out[1]), "host_count": int(out[2]), "counts": out[3:].reshape(3, 16).copy()}
 
     def debug_tile_mask_info(self):
         """(depth the mask's cells are taken from, number of cells); (0, 0): no mask for this octree."""
