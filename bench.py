@@ -35,6 +35,7 @@ import argparse
 import hashlib
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -102,6 +103,9 @@ def parse_args(argv=None):
                                                                   "and assembles, ranks 1..N-1 render)")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1: drive the frames through rto_comm_* with a one-rank RCCL communicator (rehearses the N>1 code path on one GPU)")
+    ap.add_argument("--launch-timeout", type=float, default=300.0,
+                    help="N>1: seconds the parent waits for its ranks before it kills their process group and exits 124 (0 = no limit)")
+    ap.add_argument("--launcher-test-command", default="", help=argparse.SUPPRESS)     # tests: python source run in place of the ranks
     ap.add_argument("--no-tile-mask", action="store_true", help="A/B: switch the occupancy mask of the default kernels off (rto_debug_set_tile_mask)")
     ap.add_argument("--launcher-dry-run", action="store_true", help="--gpus N without WORLD_SIZE: print the child command line and exit")
     return ap.parse_args(argv)
@@ -112,6 +116,9 @@ def child_command(args, argv, port: int) -> list[str]:
     """The N fresh ranks `python3 bench.py --gpus N ...` starts: one process per GPU over RCCL, rendezvous on 127.0.0.1."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+COMM_TIMEOUT_MS = 120000     # every rto_comm flush of a bench run: a rank whose peers never arrive fails (RTO_E_TIMEOUT) instead of hanging
 
 
 def free_port() -> int:
@@ -130,11 +137,38 @@ def self_launch(args, argv) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
-    if p.returncode != 0 or len(lines) != 1:
-        sys.stderr.write(p.stderr[-8000:])
-        sys.stderr.write(p.stdout[-4000:])
+    if args.launcher_test_command:                 # tests: a stand-in for the ranks (a process that sleeps, one that prints a line)
+        cmd = [sys.executable, "-c", args.launcher_test_command]
+    # The ranks run in a process group of their own, under a watchdog: a rank that dies before its ncclSend leaves the others
+    # waiting in a collective for ever (rto_comm_flush_timeout bounds that inside a rank; this bounds the whole job).  On expiry
+    # exactly the group started here is killed -- never a pattern, never an exec -- and the exit status is non-zero.
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    timed_out = False
+    try:
+        out, err = p.communicate(timeout=args.launch_timeout if args.launch_timeout > 0 else None)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        for sig, wait in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
+            try:
+                os.killpg(p.pid, sig)              # the session leader's pid is the group's id: the children started above, nothing else
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=wait)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        try:
+            out, err = p.communicate(timeout=10)
+        except subprocess.TimeoutExpired:
+            out, err = "", ""
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    if timed_out or p.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(err[-8000:])
+        sys.stderr.write(out[-4000:])
+        if timed_out:
+            sys.stderr.write(f"\nbench: the {args.gpus}-rank job did not finish within --launch-timeout {args.launch_timeout:g} s: its process group was killed\n")
+            return 124
         sys.stderr.write(f"\nbench: the {args.gpus}-rank job failed (exit status {p.returncode}, {len(lines)} result lines)\n")
         return p.returncode if p.returncode != 0 else 1
     print(lines[0], flush=True)
@@ -384,10 +418,10 @@ def main(argv=None):
         for _ in range(full):
             comm.submit(comm_arr, ptr, stride, comm_mode)
             if not pipelined:
-                comm.flush()
+                comm.flush(COMM_TIMEOUT_MS)
         if rest:
             comm.submit(rto.Context.frame_array([frame] * rest), ptr, stride, comm_mode)
-        comm.flush()
+        comm.flush(COMM_TIMEOUT_MS)
         return comm_frames[(rest or fpg) - 1] if rank == 0 else None
 
     def run_plain_frames(n):
@@ -415,7 +449,7 @@ def main(argv=None):
         while True:
             for _ in range(4):
                 comm.submit(comm_arr, ptr0, H * W * 16, comm_mode)
-            comm.flush()
+            comm.flush(COMM_TIMEOUT_MS)
             rounds += 1
             go_on = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], dtype=torch.float64)
             if dist is not None:
@@ -477,12 +511,12 @@ def main(argv=None):
         one = rto.Context.frame_array([frame])
         ptr = comm_frames.data_ptr() if rank == 0 else 0
         for _ in range(5):
-            comm.submit(one, ptr, H * W * 16, comm_mode); comm.flush()
+            comm.submit(one, ptr, H * W * 16, comm_mode); comm.flush(COMM_TIMEOUT_MS)
         sync_all()
         n_lat = 40
         t_l = time.perf_counter()
         for _ in range(n_lat):
-            comm.submit(one, ptr, H * W * 16, comm_mode); comm.flush()
+            comm.submit(one, ptr, H * W * 16, comm_mode); comm.flush(COMM_TIMEOUT_MS)
         lat = (time.perf_counter() - t_l) / n_lat
         if dist is not None:
             lat = max_over_ranks(lat)

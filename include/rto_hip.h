@@ -32,6 +32,7 @@ extern "C" {
 #define RTO_E_HIP        -3   /* HIP runtime error (message has the hipError)  */
 #define RTO_E_NO_DEVICE  -4   /* no usable gfx950 device / ordinal out of range */
 #define RTO_E_UNSUPPORTED -5  /* e.g. packed kernel requested for a non-canonical array */
+#define RTO_E_TIMEOUT    -6   /* rto_comm_flush_timeout: the collective did not complete; the communicator was aborted and is dead */
 
 /* == struct GPUNodes, S/RayTracerBVH.h:21-26 / GLSL OctreeNodeGPUStruct S/RayTracerBVH.cpp:195-204 */
 typedef struct rto_node {
@@ -247,7 +248,19 @@ int  rto_comm_submit_all(rto_comm* const* comms, int n_comms, const rto_frame* f
 /* single-process group: one frame through all ranks into rank 0's resident framebuffer (cf. rto_render_resident);
  * asynchronous, rto_download_resident / rto_resident_frame of rank 0's context give the assembled frame */
 int  rto_comm_render_resident_all(rto_comm* const* comms, int n_comms, const rto_frame* frame, int mode);
-int  rto_comm_flush(rto_comm* comm);              /* waits until every submitted batch is complete on this rank */
+int  rto_comm_flush(rto_comm* comm);              /* waits until every submitted batch is complete on this rank; reports an asynchronous
+                                                     RCCL error of the communicator (ncclCommGetAsyncError) as RTO_E_HIP and marks it dead */
+/* The same with a limit: polls the communicator's two streams (and its asynchronous error state) for at most timeout_ms.  On expiry
+ * -- a peer died before its ncclSend, a link is down: without a limit rank 0 would sit in hipStreamSynchronize for ever -- or on an
+ * asynchronous RCCL error the communicator is aborted (ncclCommAbort), marked DEAD and RTO_E_TIMEOUT / RTO_E_HIP is returned.  A dead
+ * communicator refuses every further submit / flush (RTO_E_INVALID, "communicator is dead"); rto_comm_destroy still returns (it does
+ * not wait for streams of a dead communicator's aborted collectives beyond their completion by the abort).  timeout_ms <= 0: no limit
+ * (as rto_comm_flush). */
+int  rto_comm_flush_timeout(rto_comm* comm, int timeout_ms);
+/* 1 once the communicator has been aborted (timeout or asynchronous error), else 0. */
+int  rto_comm_is_dead(const rto_comm* comm);
+/* Test hook: marks the communicator as timed out exactly as rto_comm_flush_timeout does on expiry (ncclCommAbort, dead). */
+int  rto_comm_debug_abort(rto_comm* comm);
 /* Developer aid: a ONE-rank communicator renders, ships and assembles as rank as_rank of as_world GPUs (every per-rank cost
  * of an N-GPU split except the other GPUs' traffic); the assembled frames hold that rank's bands only.  as_world = 0: off. */
 int  rto_comm_debug_rehearse(rto_comm* comm, int as_world, int as_rank);
@@ -329,6 +342,19 @@ int  rto_render_triangles_shade_device(rto_context* ctx, const rto_frame* frame,
  * rto_update_frustum the way the reference applies its visibility map (:64-67).  Synchronous, host buffers. */
 int  rto_octree_ray_skip(rto_context* ctx, const float ro[3], const float* rd, int64_t n, float t_min, float t_max,
                          int use_visibility, float* out_t);
+
+/* The reference's CLOSEST-hit traversal -- the earlier compute shader it keeps block-commented in the same file
+ * (453-skeleton/RayTracerBVH.cpp:46-166; traversal :63-138): the rays, slab test, LIFO order and shading of rto_render_device, but no
+ * break on the first accepted leaf and no 512-pop cap: every node whose tNear lies below the best hit so far is visited, the solid
+ * leaf with the smallest tHit = max(0, tNear) wins, a later leaf replacing it only when strictly nearer.  Dead code upstream
+ * (replaced by the "workload limiting" shader rto_render_device implements), the only traversal rule of the reference this library
+ * could not render until round 4.  Pixels are bit-identical to that shader's text compiled under the reference's glm
+ * (oracle/glsl_driver.cpp, tests/golden/glsl_images_small.npz).  RGBA32F, row 0 = top, asynchronous on hip_stream; part as in
+ * rto_render_device; a frustum update in force is honoured the way the reference's culled render is (compacted array).  Stated
+ * node by node over the 60-byte array (k_trace_closest): correct by construction, not tuned.  _host: synchronous; stats (may be
+ * NULL): rays, popped nodes (uncapped), hit pixels. */
+int  rto_render_closest_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part /* NULL = whole frame */, void* d_rgba, void* hip_stream);
+int  rto_render_closest_host(rto_context* ctx, const rto_frame* frame, float* host_rgba, rto_stats* stats /* may be NULL */);
 
 /* The same search as a RENDER MODE (octreeRaySkip "as a second kernel mode = nearest hit"): for every
  * pixel, the ray of generateRay (S/RayTracerBVH.cpp:338-355, origin = cam_pos) goes through

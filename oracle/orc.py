@@ -107,6 +107,8 @@ def lib():
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_Stats), C.c_int]
     L.orc_render_steps.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float,
                                    C.c_int, C.c_int, C.c_void_p]
+    L.orc_render_closest.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float,
+                                     C.c_int, C.c_int, C.c_void_p, C.POINTER(_Stats), C.c_int]
     L.orc_octree_ray_skip.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float]
     L.orc_octree_ray_skip.restype = C.c_float
     L.orc_octree_ray_skip_vis.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float, C.c_void_p]
@@ -270,6 +272,16 @@ def render(nodes, grid_min, voxel_size, view, cam_pos, aspect, fov_deg, W, H, ro
     return out, stats
 
 
+def render_closest(nodes, grid_min, voxel_size, view, cam_pos, aspect, fov_deg, W, H, nthreads=1):
+    """The reference's closest-hit traversal (its earlier, block-commented shader, RayTracerBVH.cpp:63-138): (image, stats)."""
+    nodes = np.ascontiguousarray(nodes)
+    out = np.zeros((H, W, 4), np.float32)
+    st = _Stats()
+    lib().orc_render_closest(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size), _f32(view), _f32(cam_pos),
+                             float(aspect), float(fov_deg), W, H, out.ctypes.data, C.byref(st), nthreads)
+    return out, {k: getattr(st, k) for k in ("rays", "pops", "hits", "capped", "internal", "max_stack")}
+
+
 def render_steps(nodes, grid_min, voxel_size, view, cam_pos, aspect, fov_deg, W, H):
     nodes = np.ascontiguousarray(nodes)
     steps = np.zeros((H, W), np.int32)
@@ -390,6 +402,29 @@ def max_threads() -> int:
 
 # ---------------------------------------------------------------- real reference (optional)
 _ref = None
+
+
+# ---------------------------------------------------------------- the reference's GLSL text compiled as C++ (optional)
+_glsl = {}
+
+
+def glsl_available() -> bool:
+    return all(os.path.exists(os.path.join(os.path.dirname(LIBREF), f"libglsl_{k}.so")) for k in ("first", "closest"))
+
+
+def glsl_render(kind, nodes, grid_min, voxel_size, view, cam_pos, aspect, fov_deg, W, H):
+    """The frame the reference's shader text computes under glm semantics (`make -C oracle glsl`; oracle/glsl_driver.cpp).
+    kind: "first" = the live shader (RayTracerBVH.cpp:221-355), "closest" = the earlier block-commented one (:46-166)."""
+    if kind not in _glsl:
+        L = C.CDLL(os.path.join(os.path.dirname(LIBREF), f"libglsl_{kind}.so"))
+        L.glsl_render.argtypes = [C.c_void_p, C.c_int, _f32p, C.c_float, _f32p, _f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        L.glsl_render.restype = None
+        _glsl[kind] = L
+    nodes = np.ascontiguousarray(nodes)
+    out = np.zeros((H, W, 4), np.float32)
+    _glsl[kind].glsl_render(nodes.ctypes.data, len(nodes), _f32(grid_min), float(voxel_size), _f32(view), _f32(cam_pos),
+                            float(aspect), float(fov_deg), W, H, out.ctypes.data)
+    return out
 
 
 def ref_available() -> bool:

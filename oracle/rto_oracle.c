@@ -583,6 +583,54 @@ static inline trace_result trace(const orc_node* nodes, const frame_consts* fc, 
     return r;
 }
 
+/* The reference's CLOSEST-hit traversal: the earlier shader kept block-commented in the same file (S/RayTracerBVH.cpp:63-138).
+ * Same LIFO order and slab test as trace(); no early break on the first accepted leaf and no step cap: every node whose tNear lies
+ * below the best hit so far is visited, the leaf with the smallest tHit wins (a later leaf replaces it only when strictly closer:
+ * ties go to the leaf popped first).  Dead code upstream -- the only traversal rule of the reference this repo could not render
+ * until round 4 (rto_render_closest_*).  steps: nodes popped (uncapped). */
+static inline trace_result trace_closest(const orc_node* nodes, const frame_consts* fc, v3 ro, v3 rd) {
+    trace_result r; r.hit = 0; r.steps = 0; r.max_sp = 1; r.internal = 0; r.normal = v3_(0, 0, 0);
+    float closestT = 1e30f;                                   /* :66 */
+    int stack[128];                                           /* :71 */
+    int sp = 0;
+    stack[sp++] = 0;
+    v3 gmn = v3_(fc->gridMin[0], fc->gridMin[1], fc->gridMin[2]);
+    float vs = fc->voxelSize;
+    while (sp > 0) {                                          /* :75 */
+        sp--;
+        int nodeIdx = stack[sp];
+        if (nodeIdx < 0) continue;
+        r.steps++;
+        const orc_node* node = &nodes[nodeIdx];
+        v3 nodeMin = v3_(gmn.x + (float)node->x * vs, gmn.y + (float)node->y * vs, gmn.z + (float)node->z * vs);   /* :83-84 */
+        float ext = (float)node->size * vs;
+        v3 nodeMax = v3_(nodeMin.x + ext, nodeMin.y + ext, nodeMin.z + ext);
+        float tNear, tFar;
+        if (!intersect_aabb(ro, rd, nodeMin, nodeMax, &tNear, &tFar)) continue;   /* :87-88 */
+        if (tNear >= closestT) continue;                      /* :91-92 */
+        if (node->isUniform == 1 || node->isLeaf == 1) {      /* :94-122: identical bodies, no break */
+            if (node->isSolid == 1) {
+                float tHit = gmax(0.0f, tNear);
+                if (tHit < closestT && tHit <= tFar) {
+                    closestT = tHit;
+                    r.hit = 1;
+                    v3 center = v3_(0.5f * (nodeMin.x + nodeMax.x), 0.5f * (nodeMin.y + nodeMax.y), 0.5f * (nodeMin.z + nodeMax.z));
+                    v3 p = v3_(ro.x + rd.x * tHit, ro.y + rd.y * tHit, ro.z + rd.z * tHit);
+                    r.normal = v3_normalize(v3_sub(p, center));
+                }
+            }
+            continue;
+        }
+        r.internal++;
+        for (int i = 0; i < 8; i++) {                         /* :125-129 */
+            int childIdx = node->child[i];
+            if (childIdx >= 0) stack[sp++] = childIdx;
+        }
+        if (sp > r.max_sp) r.max_sp = sp;
+    }
+    return r;
+}
+
 static inline void shade_store(const trace_result* tr, float* px) {
     /* :331-336 shade, :366-367 store */
     if (tr->hit) {
@@ -633,6 +681,37 @@ void orc_render(const orc_node* nodes, int64_t n, const float gridMin[3], float 
     if (stats) {
         stats->rays = (uint64_t)W * (uint64_t)(y1 - y0);
         stats->pops = pops; stats->hits = hits; stats->capped = capped; stats->internal = internal;
+        stats->max_stack = max_stack; stats->pad = 0;
+    }
+}
+
+/* The closest-hit frame (trace_closest): same rays, same shade.  stats->pops counts the popped nodes (no cap: `capped` stays 0). */
+void orc_render_closest(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                        const float view[16], const float camPos[3], float aspect, float fovDeg,
+                        int W, int H, float* out, orc_stats* stats, int nthreads) {
+    (void)n;
+    frame_consts fc;
+    frame_setup(&fc, gridMin, voxelSize, view, camPos, aspect, fovDeg, W, H);
+    v3 ro = v3_(camPos[0], camPos[1], camPos[2]);
+    uint64_t pops = 0, hits = 0, internal = 0;
+    unsigned max_stack = 0;
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+:pops,hits,internal) reduction(max:max_stack)
+#endif
+    for (int py = 0; py < H; py++) {
+        for (int px = 0; px < W; px++) {
+            v3 rd;
+            generate_ray(&fc, px, py, &rd);
+            trace_result tr = trace_closest(nodes, &fc, ro, rd);
+            shade_store(&tr, out + ((size_t)py * W + px) * 4);
+            pops += (uint64_t)tr.steps; hits += (uint64_t)tr.hit; internal += (uint64_t)tr.internal;
+            if ((unsigned)tr.max_sp > max_stack) max_stack = (unsigned)tr.max_sp;
+        }
+    }
+    if (stats) {
+        stats->rays = (uint64_t)W * (uint64_t)H;
+        stats->pops = pops; stats->hits = hits; stats->capped = 0; stats->internal = internal;
         stats->max_stack = max_stack; stats->pad = 0;
     }
 }

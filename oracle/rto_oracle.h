@@ -104,6 +104,10 @@ void orc_render(const orc_node* nodes, int64_t n, const float gridMin[3], float 
                 int W, int H, int y0, int y1, float* out, orc_stats* stats, int nthreads);
 
 /* Per-pixel traversal step counts (for tests of the 512 cap). steps: W*H int32. */
+/* closest-hit traversal of the reference's earlier (block-commented) shader, S/RayTracerBVH.cpp:63-138 */
+void orc_render_closest(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
+                        const float view[16], const float camPos[3], float aspect, float fovDeg,
+                        int W, int H, float* out, orc_stats* stats, int nthreads);
 void orc_render_steps(const orc_node* nodes, int64_t n, const float gridMin[3], float voxelSize,
                       const float view[16], const float camPos[3], float aspect, float fovDeg,
                       int W, int H, int32_t* steps);

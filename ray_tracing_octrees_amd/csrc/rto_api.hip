@@ -2238,6 +2238,51 @@ int rto_octree_ray_skip(rto_context* c, const float ro[3], const float* rd, int6
     return RTO_OK;
 }
 
+// ---- the reference's closest-hit traversal (its earlier, block-commented shader: S/RT:46-166) --------------------------------
+static int launch_closest(rto_context* c, const rto_frame* f, const rto_partition* p, float4* d_out, hipStream_t s, bool count) {
+    if (s != c->stream) c->otherStreams = true;
+    RenderParams P;
+    int rc = fill_params(c, f, p, P, s);
+    if (rc != RTO_OK) return rc;
+    if ((rc = order_after_cull(c, s)) != RTO_OK) return rc;
+    const int tiles = P.tilesX * P.tilesY;
+    if (tiles <= 0) return RTO_OK;
+    // with a frustum update in force the traversal runs over the compacted array, as the reference's culled render does (S/RT:765-812)
+    if ((rc = ensure_compact(c, s)) != RTO_OK) return rc;
+    const rto_node* nodes = c->culling ? c->d_compact : c->d_nodes;
+    if (c->culling) P.rootVisible = c->visibleNodes > 0 ? 1 : 0;
+    const int blocks = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
+    if (count) hipLaunchKernelGGL(k_trace_closest<kModeSteps>, dim3(blocks), dim3(kBlock), 0, s, P, nodes, d_out, c->d_counters);
+    else hipLaunchKernelGGL(k_trace_closest<kModeColor>, dim3(blocks), dim3(kBlock), 0, s, P, nodes, d_out, c->d_counters);
+    RTO_HIP(c, hipGetLastError());
+    return RTO_OK;
+}
+
+int rto_render_closest_device(rto_context* c, const rto_frame* f, const rto_partition* p, void* d_out, void* hip_stream) {
+    if (!c) return RTO_E_INVALID;
+    if (!d_out) return fail(c, RTO_E_INVALID, "rto_render_closest_device: d_out is NULL");
+    RTO_HIP(c, hipSetDevice(c->device));
+    return launch_closest(c, f, p, (float4*)d_out, (hipStream_t)hip_stream, false);
+}
+
+int rto_render_closest_host(rto_context* c, const rto_frame* f, float* host_rgba, rto_stats* stats) {
+    if (!c) return RTO_E_INVALID;
+    if (!f || !host_rgba) return fail(c, RTO_E_INVALID, "rto_render_closest_host: NULL argument");
+    RTO_HIP(c, hipSetDevice(c->device));
+    if (f->width <= 0 || f->height <= 0) return fail(c, RTO_E_INVALID, "render: width/height must be positive");
+    const size_t pixels = (size_t)f->width * f->height;
+    int rc = ensure_frame(c, pixels);
+    if (rc != RTO_OK) return rc;
+    if (stats) RTO_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));
+    if ((rc = launch_closest(c, f, nullptr, c->d_frame, c->stream, stats != nullptr)) != RTO_OK) return rc;
+    Counters h{ 0, 0, 0 };
+    if (stats) RTO_HIP(c, hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipMemcpyAsync(host_rgba, c->d_frame, pixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    RTO_HIP(c, hipStreamSynchronize(c->stream));
+    if (stats) { stats->rays = pixels; stats->pops = h.pops; stats->hits = h.hits; stats->capped = 0; }
+    return RTO_OK;
+}
+
 // ---- N1 as a render mode + N1's consumer ------------------------------------------------------------------------------
 static int launch_skip_render(rto_context* c, const rto_frame* f, const rto_partition* p, int use_visibility, float4* d_rgba, float* d_dist, hipStream_t s) {
     if (!d_rgba && !d_dist) return fail(c, RTO_E_INVALID, "rto_render_skip: neither output given");

@@ -360,6 +360,69 @@ __global__ __launch_bounds__(kBlock) void k_trace_generic(RenderParams P, const 
     }
 }
 
+// ================================================================ closest-hit kernel
+// The reference's OTHER traversal rule for this shader: the earlier version kept block-commented in the same file
+// (S/RT:63-138).  Same LIFO order, same slab test and the same `tNear >= closestT` pruning as above, but no break on the first
+// accepted leaf and no step cap: the leaf with the smallest tHit wins, and a later leaf replaces it only when STRICTLY nearer (ties
+// go to the leaf popped first).  Stated node by node over the 60-byte array, in the reference's pop order, so that the winner --
+// which depends on that order through the pruning whenever two boxes' float planes disagree by an ulp -- is the reference's by
+// construction.  Dead code upstream: built for completeness (rto_render_closest_*), not tuned.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_trace_closest(RenderParams P, const rto_node* __restrict__ nodes,
+                                                           float4* __restrict__ out, Counters* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+    const int px = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    const bool inImage = valid && (py < P.H);
+
+    bool hit = false;
+    int steps = 0;
+    float shade = kShadeMiss;
+    if (inImage && P.rootVisible) {
+        Ray r = generate_ray(P, px, py);
+        int stack[128];                 // S/RT:71
+        int sp = 0;
+        stack[sp++] = 0;
+        float closestT = 1e30f;         // S/RT:66
+        int bx = 0, by = 0, bz = 0, bs = 0;
+        while (sp > 0) {                // S/RT:75
+            sp--;
+            int nodeIdx = stack[sp];
+            if (nodeIdx < 0) continue;
+            steps++;
+            const rto_node nd = nodes[nodeIdx];
+            float tNear, tFar, a0, a1, a2, a3, a4, a5;
+            if (!slab_exact(P, r, nd.x, nd.y, nd.z, nd.size, tNear, tFar, a0, a1, a2, a3, a4, a5)) continue;     // S/RT:87-88
+            if (tNear >= closestT) continue;                                                                 // S/RT:91-92
+            if (nd.isUniform == 1 || nd.isLeaf == 1) {                                                       // S/RT:94-122
+                if (nd.isSolid == 1) {
+                    float tHit = gmax(0.0f, tNear);
+                    if (tHit < closestT && tHit <= tFar) { closestT = tHit; hit = true; bx = nd.x; by = nd.y; bz = nd.z; bs = nd.size; }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {                                                                    // S/RT:125-129
+                int c = nd.child[i];
+                if (c >= 0 && sp < 128) stack[sp++] = c;       // (a LIFO walk of an octree of depth d holds at most 7 d + 1 entries)
+            }
+        }
+        if (hit) shade = shade_term(P, r, bx, by, bz, bs);     // the normal of S/RT:101-103 at the winning leaf: p = o + d * tHit, tHit = max(0, tNear) of ITS box
+    }
+    if (MODE == kModeColor) {
+        if (valid) out[(size_t)ly * P.W + px] = shade_color(shade);
+    } else {
+        unsigned long long pops = inImage ? (unsigned long long)steps : 0ull, hits = (inImage && hit) ? 1ull : 0ull;
+        for (int off = 32; off > 0; off >>= 1) { pops += __shfl_down(pops, off); hits += __shfl_down(hits, off); }
+        if (lane == 0) { atomicAdd(&counters->pops, pops); atomicAdd(&counters->hits, hits); }
+        if (valid) out[(size_t)ly * P.W + px] = shade_color(shade);
+    }
+}
+
 // ================================================================ packed kernel
 // 8 child slab tests of the internal node at integer position (cx,cy,cz) whose children
 // have edge `half`.  Returns the 8-bit mask of children k (bit0=+x, bit1=+y, bit2=+z,

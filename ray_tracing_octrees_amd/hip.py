@@ -13,7 +13,7 @@ import numpy as np
 from . import _build
 
 RTO_OK = 0
-RTO_E_INVALID, RTO_E_NO_OCTREE, RTO_E_HIP, RTO_E_NO_DEVICE, RTO_E_UNSUPPORTED = -1, -2, -3, -4, -5
+RTO_E_INVALID, RTO_E_NO_OCTREE, RTO_E_HIP, RTO_E_NO_DEVICE, RTO_E_UNSUPPORTED, RTO_E_TIMEOUT = -1, -2, -3, -4, -5, -6
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_PACKED, KERNEL_PACKED_V1, KERNEL_PACKED_PERSISTENT, KERNEL_PACKED_V3 = 0, 1, 2, 3, 4, 5
 
 # struct GPUNodes (453-skeleton/RayTracerBVH.h:21-26)
@@ -32,8 +32,8 @@ SYMBOLS = (
     "rto_upload_leaf_triangles", "rto_build_leaf_triangles", "rto_download_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_debug_sort_violations", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
     "rto_comm_unique_id", "rto_comm_create", "rto_comm_create_all", "rto_comm_destroy", "rto_comm_last_error", "rto_comm_submit",
-    "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_comm_debug_last_payload", "rto_render_triangles_batch_device",
-    "rto_debug_set_tile_mask", "rto_debug_tile_mask_info", "rto_render_skip_device", "rto_render_skip_host", "rto_probe_skip_device", "rto_probe_skip_host",
+    "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_flush_timeout", "rto_comm_is_dead", "rto_comm_debug_abort", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_comm_debug_last_payload", "rto_render_triangles_batch_device",
+    "rto_debug_set_tile_mask", "rto_debug_tile_mask_info", "rto_render_closest_device", "rto_render_closest_host", "rto_render_skip_device", "rto_render_skip_host", "rto_probe_skip_device", "rto_probe_skip_host",
     "rto_scene_bounds_get", "rto_scene_bounds_of_nodes", "rto_split_plan_make", "rto_split_part_of_rank", "rto_split_rows_of_part", "rto_split_row_source",
 )
 SPLIT_MAX_FRAMES = 32
@@ -147,6 +147,8 @@ def load():
     L.rto_render_triangles_host.argtypes = [vp, C.POINTER(Frame), C.c_int, vp, C.POINTER(Stats)]
     L.rto_octree_ray_skip.argtypes = [vp, C.POINTER(C.c_float), vp, C.c_int64, C.c_float, C.c_float, C.c_int, vp]
     L.rto_render_steps_host.argtypes = [vp, C.POINTER(Frame), vp]
+    L.rto_render_closest_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), vp, vp]
+    L.rto_render_closest_host.argtypes = [vp, C.POINTER(Frame), vp, C.POINTER(Stats)]
     L.rto_render_skip_device.argtypes = [vp, C.POINTER(Frame), C.POINTER(Partition), C.c_int, vp, vp, vp]
     L.rto_render_skip_host.argtypes = [vp, C.POINTER(Frame), C.c_int, vp, vp]
     L.rto_probe_skip_device.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, vp, vp]
@@ -171,6 +173,9 @@ def load():
     L.rto_comm_submit_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Frame), C.c_int, C.c_int, vp, C.c_size_t]
     L.rto_comm_render_resident_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Frame), C.c_int]
     L.rto_comm_flush.argtypes = [vp]
+    L.rto_comm_flush_timeout.argtypes = [vp, C.c_int]
+    L.rto_comm_is_dead.argtypes = [vp]
+    L.rto_comm_debug_abort.argtypes = [vp]
     L.rto_comm_debug_rehearse.argtypes = [vp, C.c_int, C.c_int]
     L.rto_comm_debug_last_payload.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.rto_render_triangles_batch_device.argtypes = [vp, C.POINTER(Frame), C.c_int, C.POINTER(Partition), C.c_int, C.c_int, vp, C.c_size_t, vp]
@@ -435,6 +440,16 @@ class Context:
                                                 1 if use_visibility else 0, out.ctypes.data))
         return out
 
+    def render_closest_host(self, frame: Frame, stats: bool = False):
+        """The reference's closest-hit traversal (its earlier, block-commented shader): RGBA frame [, {rays, pops, hits}]."""
+        out = np.empty((frame.height, frame.width, 4), np.float32)
+        st = Stats()
+        self._check(self._L.rto_render_closest_host(self._h, C.byref(frame), out.ctypes.data, C.byref(st) if stats else None))
+        return (out, {"rays": st.rays, "pops": st.pops, "hits": st.hits}) if stats else out
+
+    def render_closest_device(self, frame: Frame, d_out: int, part: Partition | None = None, stream: int = 0):
+        self._check(self._L.rto_render_closest_device(self._h, C.byref(frame), C.byref(part) if part else None, C.c_void_p(d_out), C.c_void_p(stream)))
+
     def render_skip_host(self, frame: Frame, use_visibility=False, rgba=True, dist=True):
         """Nearest-hit render mode (octreeRaySkip per pixel): (rgba (H, W, 4) or None, dist (H, W) or None)."""
         o_rgba = np.empty((frame.height, frame.width, 4), np.float32) if rgba else None
@@ -568,8 +583,17 @@ class Comm:
         """frames_arr: Context.frame_array([...]); d_frames (rank 0): device pointer of len(frames_arr) RGBA32F frames."""
         self._check(self._L.rto_comm_submit(self._h, frames_arr, len(frames_arr), mode, C.c_void_p(d_frames) if d_frames else None, frame_stride_bytes))
 
-    def flush(self):
-        self._check(self._L.rto_comm_flush(self._h))
+    def flush(self, timeout_ms: int = 0):
+        """Waits for every submitted batch.  timeout_ms > 0: at most that long -- on expiry (a peer that never sent) the
+        communicator is aborted and dead, RtoError(RTO_E_TIMEOUT)."""
+        self._check(self._L.rto_comm_flush_timeout(self._h, int(timeout_ms)))
+
+    def is_dead(self) -> bool:
+        return bool(self._L.rto_comm_is_dead(self._h))
+
+    def debug_abort(self):
+        """Test hook: what a flush timeout does (ncclCommAbort, the communicator is dead)."""
+        self._check(self._L.rto_comm_debug_abort(self._h))
 
     def debug_last_payload(self):
         """(floats shipped for the last batch, floats whole rows would have been) for this rank."""

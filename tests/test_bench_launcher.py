@@ -38,3 +38,27 @@ def test_failing_ranks_give_a_loud_non_zero_exit():
     assert p.returncode != 0
     assert "2-rank job failed" in p.stderr
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]        # no result line on failure
+
+
+def test_ranks_that_hang_are_killed_by_the_watchdog():
+    """A rank that dies before its ncclSend leaves the others in a collective for ever: the parent waits --launch-timeout seconds,
+    kills exactly the process group it started (fresh children, never an exec), says what they printed and exits 124."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    stub = "import sys, time; print('rank 0: waiting in a collective', flush=True); sys.stderr.write('rank 1 died\\n'); sys.stderr.flush(); time.sleep(600)"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-timeout", "3", "--launcher-test-command", stub],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 124, (p.returncode, p.stderr[-500:])
+    assert time.time() - t0 < 60
+    assert "did not finish within --launch-timeout 3 s" in p.stderr and "rank 1 died" in p.stderr and "waiting in a collective" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+
+
+def test_the_watchdog_lets_a_finished_job_through():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    stub = "print('{\"metric\": \"stub\", \"value\": 1}')"
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-timeout", "30", "--launcher-test-command", stub],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.strip() == '{"metric": "stub", "value": 1}'

@@ -1404,6 +1404,69 @@ def test_nearest_hit_render_mode_equals_the_reference_vectors(ctx, orc, scenes, 
         ctx.update_frustum(view, 45.0, aspect, enable=False)
 
 
+@pytest.mark.parametrize("scene", ["sphere32", "sphere64", "odd", "calgary"])
+def test_closest_hit_mode_equals_the_earlier_shader(ctx, orc, scenes, golden, scene):
+    """rto_render_closest_*: the reference's closest-hit traversal (the shader it keeps block-commented, RayTracerBVH.cpp:46-166).
+    Expected pixels: that shader's TEXT compiled as C++ under the reference's glm (tests/golden/glsl_images_small.npz, made by
+    tests/golden/make_golden_glsl.py) -- and the oracle's restatement, which the CPU suite pins to the same frames.  Outside,
+    inside-the-shell and axis-aligned cameras; counters too."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_glsl", os.path.join(ROOT, "tests", "golden", "make_golden_glsl.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    z = golden("glsl_images_small.npz")
+    s = scenes(scene)
+    upload(ctx, s)
+    W, H, cams = m.CASES[scene]
+    for i, cspec in enumerate(cams):
+        view, pos, fov = m.camera(cspec)
+        f = rto.make_frame(view, pos, W / H, fov, W, H)
+        got, st = ctx.render_closest_host(f, stats=True)
+        assert got.tobytes() == z[f"{scene}_cam{i}_closest"].tobytes(), f"{scene} camera {i}: closest-hit frame vs the shader text under glm"
+        want, wst = orc.render_closest(s.nodes, s.min, s.voxel, view, pos, W / H, fov, W, H)
+        assert_bit_exact(got, want, f"{scene} camera {i}: closest-hit frame vs the oracle")
+        assert (st["pops"], st["hits"]) == (wst["pops"], wst["hits"])
+        assert_bit_exact(ctx.render_closest_host(f), want, f"{scene} camera {i}: without counters")
+        # the live shader's frame through the same context, against ITS text
+        assert ctx.render_host(f).tobytes() == z[f"{scene}_cam{i}_first"].tobytes(), f"{scene} camera {i}: first-hit frame vs the live shader's text"
+
+
+def test_closest_hit_mode_at_config2_size_and_with_culling(ctx, orc, scenes, camera):
+    """The closest-hit mode at BASELINE config 2's size (256^3, 1920x1080) against the oracle, a 3-way partition on a caller's
+    stream, and through a frustum update (the reference's culled render walks the compacted array)."""
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere256")
+    upload(ctx, s)
+    W, H = 1920, 1080
+    nthr = min(16, orc.max_threads())
+    for cam in (orc.Camera(0.5, 0.7, 1.8), orc.Camera(1.0, 0.9, 0.25)):
+        view, pos = cam.get_view(), cam.get_pos()
+        f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+        want, wst = orc.render_closest(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H, nthreads=nthr)
+        got, st = ctx.render_closest_host(f, stats=True)
+        assert_bit_exact(got, want, "closest-hit mode, 256^3 at 1080p")
+        assert (st["pops"], st["hits"]) == (wst["pops"], wst["hits"])
+    part = hip.Partition(3, 1, 16)
+    rows = partition_row_map(H, 3, 1, 16)
+    pb = torch.full((len(rows), W, 4), 7.0, dtype=torch.float32, device="cuda")
+    other = torch.cuda.Stream()
+    ctx.render_closest_device(f, pb.data_ptr(), part, other.cuda_stream)
+    torch.cuda.synchronize()
+    assert_bit_exact(pb.cpu().numpy(), want[rows], "closest-hit mode, part 1 of 3 on a caller's stream")
+    cal = scenes("calgary")
+    upload(ctx, cal)
+    view, pos = camera("calgary_oblique")
+    Wc, Hc = 480, 270
+    nodes_c, _ = orc.cull_compact(cal.nodes, cal.min, cal.voxel, view, 45.0, Wc / Hc)
+    fc = rto.make_frame(view, pos, Wc / Hc, 45.0, Wc, Hc)
+    try:
+        ctx.update_frustum(view, 45.0, Wc / Hc, enable=True)
+        wantc, _ = orc.render_closest(nodes_c, cal.min, cal.voxel, view, pos, Wc / Hc, 45.0, Wc, Hc)
+        assert_bit_exact(ctx.render_closest_host(fc), wantc, "closest-hit mode through a frustum update")
+    finally:
+        ctx.update_frustum(view, 45.0, Wc / Hc, enable=False)
+
+
 def test_nearest_hit_render_mode_at_config2_size(ctx, orc, scenes, camera):
     """The same at BASELINE config 2's size (256^3 sphere, 1920x1080) against the oracle; where both modes hit, the nearest-hit
     distance never exceeds the distance of the reference's first-in-DFS-order hit (the reason SURVEY.md section 8f wants the mode)."""
@@ -1814,6 +1877,46 @@ def test_comm_one_rank_through_the_c_abi(ctx, orc, scenes):
             comm.debug_rehearse(4, 4)
     finally:
         comm.close()
+
+
+def test_comm_timeout_and_dead_communicator(ctx, orc, scenes):
+    """The failure path of the collective (nothing upstream to mirror: the reference is single-GPU).  A flush with a limit returns in
+    time on a healthy communicator; an aborted one -- what a flush timeout or an asynchronous RCCL error leaves behind -- is DEAD: it
+    refuses submits and flushes with RTO_E_INVALID, reports so, and rto_comm_destroy still returns; the context renders on, and a new
+    communicator on the same context works."""
+    torch = pytest.importorskip("torch")
+    s = scenes("sphere32")
+    upload(ctx, s)
+    W, H = 160, 96
+    cam = orc.Camera(0.5, 0.7, 1.8)
+    f = rto.make_frame(cam.get_view(), cam.get_pos(), W / H, 45.0, W, H)
+    want = oracle_frame(orc, s, cam.get_view(), cam.get_pos(), W, H)[0]
+    arr = hip.Context.frame_array([f])
+    out = torch.full((H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+    comm = hip.Comm(ctx, 1, 0, hip.comm_unique_id(), band_rows=16)
+    try:
+        comm.submit(arr, out.data_ptr(), 0)
+        comm.flush(timeout_ms=60000)
+        assert not comm.is_dead()
+        assert_bit_exact(out.cpu().numpy(), want, "healthy communicator, flush with a limit")
+        comm.submit(arr, out.data_ptr(), 0)
+        comm.debug_abort()                                      # what the expiry of a flush timeout does
+        assert comm.is_dead()
+        for call in (lambda: comm.submit(arr, out.data_ptr(), 0), lambda: comm.flush(), lambda: comm.flush(timeout_ms=10)):
+            with pytest.raises(rto.RtoError) as e:
+                call()
+            assert e.value.code == hip.RTO_E_INVALID and "dead" in str(e.value)
+    finally:
+        comm.close()                                            # must return
+    assert_bit_exact(ctx.render_host(f), want, "the context renders on after its communicator died")
+    again = hip.Comm(ctx, 1, 0, hip.comm_unique_id(), band_rows=16)
+    try:
+        out.fill_(7.0)
+        again.submit(arr, out.data_ptr(), 0)
+        again.flush(timeout_ms=60000)
+        assert_bit_exact(out.cpu().numpy(), want, "a new communicator on the same context")
+    finally:
+        again.close()
 
 
 def _rehearse_every_rank(ctx, comm, frames, wants, worlds, mode, what):

@@ -312,3 +312,49 @@ def test_render_triangles_refuses_arrays_of_the_wrong_shape(orc, scenes):
         orc.render_triangles(s.nodes, tris[:, :9], off, *args)
     with pytest.raises(ValueError):
         orc.render_triangles(s.nodes, tris, off, s.min, s.voxel, cam.get_view()[:3], cam.get_pos(), 1.0, 45.0, 16, 16)
+
+
+def _glsl_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_glsl", os.path.join(os.path.dirname(__file__), "golden", "make_golden_glsl.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("scene", ["sphere32", "sphere64", "odd", "calgary"])
+def test_oracle_equals_the_reference_glsl_text_under_glm(orc, scenes, golden, scene):
+    """The mechanical cross-check of rows A3-A6.  The reference's GLSL functions (RayTracerBVH.cpp:221-355, and the earlier
+    block-commented closest-hit shader at :46-166) were cut out of the reference file by `make -C oracle glsl`, compiled as C++
+    against the reference's vendored glm (`out T x` -> `T& x` the only edit) and run over whole frames: outside, inside-the-shell
+    and axis-aligned cameras, the odd grid, the shipped Calgary grid.  The oracle -- the hand restatement every GPU test compares
+    with -- must produce the same float bits for every pixel: against the recorded frames always, against the compiled text
+    itself where oracle/_ref/libglsl_*.so exists.  (glm stands in for a GLSL compiler: corroboration, not an execution of the
+    reference's kernel.)"""
+    m = _glsl_cases()
+    z = golden("glsl_images_small.npz")
+    s = scenes(scene)
+    W, H, cams = m.CASES[scene]
+    for i, spec in enumerate(cams):
+        view, pos, fov = m.camera(spec)
+        first, _ = orc.render(s.nodes, s.min, s.voxel, view, pos, W / H, fov, W, H)
+        closest, st = orc.render_closest(s.nodes, s.min, s.voxel, view, pos, W / H, fov, W, H)
+        assert first.tobytes() == z[f"{scene}_cam{i}_first"].tobytes(), f"{scene} camera {i}: first-hit oracle vs the shader text"
+        assert closest.tobytes() == z[f"{scene}_cam{i}_closest"].tobytes(), f"{scene} camera {i}: closest-hit oracle vs the earlier shader's text"
+        assert st["capped"] == 0 and st["hits"] == int((closest[..., 0] != 0).sum())
+        if orc.glsl_available():
+            assert orc.glsl_render("first", s.nodes, s.min, s.voxel, view, pos, W / H, fov, W, H).tobytes() == first.tobytes()
+            assert orc.glsl_render("closest", s.nodes, s.min, s.voxel, view, pos, W / H, fov, W, H).tobytes() == closest.tobytes()
+
+
+def test_closest_hit_is_never_farther_than_first_hit(orc, scenes):
+    """What distinguishes the two traversal rules of the reference: the live shader stops at the first accepted solid leaf in LIFO
+    order (and after 512 pops), the earlier one goes on until nothing nearer is left.  So every first-hit pixel is a closest-hit
+    pixel too, and where they differ the closest-hit leaf is at least as near."""
+    s = scenes("sphere32")
+    cam = orc.Camera(2.0, 0.3, 0.2)                       # inside the shell: the two rules disagree on thousands of pixels
+    W, H = 96, 64
+    first, st1 = orc.render(s.nodes, s.min, s.voxel, cam.get_view(), cam.get_pos(), W / H, 45.0, W, H)
+    closest, st2 = orc.render_closest(s.nodes, s.min, s.voxel, cam.get_view(), cam.get_pos(), W / H, 45.0, W, H)
+    assert st2["hits"] >= st1["hits"] and ((first[..., 0] != 0) <= (closest[..., 0] != 0)).all()
+    assert (first.view(np.uint32) != closest.view(np.uint32)).any()
