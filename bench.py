@@ -309,7 +309,6 @@ def main(argv=None):
         args.graph_frames = 0          # plain launches without per-launch events beat the graph replay at every K (tools/steps_sweep.sh: K = 20: 0.0405 vs 0.0435 ms)
     if args.rehearse_world > 1:
         args.no_verify, args.cpu_frames, args.force_comm = True, 0, True     # the assembled frames hold one rank's bands only
-        os.environ.setdefault("RTO_REHEARSE_NO_CLEAR", "1")                  # the per-batch clear of the absent ranks' rows is test scaffolding, not a rank's work
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         sys.exit(self_launch(args, argv))
@@ -381,6 +380,7 @@ def main(argv=None):
             if world != 1:
                 raise SystemExit("--rehearse-world needs --gpus 1 --force-comm")
             comm.debug_rehearse(args.rehearse_world, args.rehearse_rank)   # this GPU plays that rank: per-rank cost of the split, no peer traffic
+            comm.debug_set_rehearsal_clear(False)                          # the per-batch clear of the absent ranks' rows is test scaffolding, not a rank's work
         comm_mode = _hip.RESIDENT_TRIANGLES_SHADOW if triangles else _hip.RESIDENT_OCTREE
 
     stream = torch.cuda.Stream()          # kernels and events order themselves on this side stream
@@ -573,8 +573,8 @@ def main(argv=None):
                 "kernel": kernel_name,
                 "model": f"{SIMDS} SIMD-32 x {CLOCK_GHZ} GHz / {VALU_CYCLES_PER_WAVE_INST} cycles per wave64 VALU instruction; achieved = SQ_INSTS_VALU per launch (PMC) / kernel_ms_avg",
                 "launch_order": order_key, "frames_per_launch": 1,
-                "kernel_ms_avg": round(k_avg, 5), "kernel_ms_median": round(k_med, 5), "kernel_ms_min": round(k_min, 5), "kernel_launches_timed": n_k,
-                "kernel_ms_how": (f"avg: HIP events at both ends of the timed region on the launch stream / its {args.steps} launches (gaps between launches included: an upper bound); median / min: of the per-launch event pairs"
+                "kernel_ms_avg": round(k_avg, 5), "kernel_ms_event_pair_median": round(k_med, 5), "kernel_ms_event_pair_min": round(k_min, 5), "kernel_launches_timed": n_k,
+                "kernel_ms_how": (f"avg: HIP events at both ends of the timed region on the launch stream / its {args.steps} launches (gaps between launches included: an upper bound); kernel_ms_event_pair_*: median / min of a SEPARATE pass with an event pair around every launch (another clock: reads 2-3 us more per launch, not comparable with kernel_ms_avg)"
                                   if graph is None else f"HIP event pairs around each of {n_k} plain launches"),
                 "kernel_ms_event_pairs": {"avg": round(p_avg, 5), "median": round(k_med, 5), "min": round(k_min, 5), "launches": n_k,
                                           "how": f"a HIP event pair around each of {n_k} launches of the timed workload (plain launches, right after the timed region), on the launch stream"},

@@ -266,6 +266,7 @@ int  rto_comm_debug_abort(rto_comm* comm);
 int  rto_comm_debug_rehearse(rto_comm* comm, int as_world, int as_rank);
 /* Developer aid: floats this rank shipped for the batch submitted last -- only the columns of the geometry's screen rectangle
  * travel, rank 0 paints the background itself -- and what whole rows would have been. */
+int  rto_comm_debug_set_rehearsal_clear(rto_comm* comm, int enabled);   /* rehearsals: per-batch clear of the absent ranks' rows (default on; timing runs switch it off) */
 int  rto_comm_debug_last_payload(const rto_comm* comm, int64_t* packed_floats, int64_t* full_floats);
 void* rto_comm_stream(rto_comm* comm);            /* hipStream_t the gathers and (rank 0) the assembled frames are ordered on */
 
@@ -404,6 +405,9 @@ int  rto_debug_set_tile_order(rto_context* ctx, const int32_t* host_order, int64
  * (0: no mask for this octree). */
 int  rto_debug_set_tile_mask(rto_context* ctx, int enabled);
 int  rto_debug_tile_mask_info(const rto_context* ctx, int* level, int* num_cells);
+/* Test hook: from now on the k-th (1-based) allocation of the frustum-update / rto_comm buffers of this PROCESS fails (k <= 0: never).
+ * An explicit call -- the library reads no environment variable (A/B knobs exist only in -DRTO_DEV_KNOBS builds). */
+int  rto_debug_fault_alloc(long k);
 /* Writes the launch-order sort refused because they fell outside the table (must be 0; synchronises). */
 int  rto_debug_sort_violations(rto_context* ctx, int* count);
 /* Device time in ms of the most recent traversal kernel launched by this context

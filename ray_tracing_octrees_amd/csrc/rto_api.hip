@@ -158,13 +158,27 @@ static int fail(rto_context* ctx, int code, const std::string& msg) {
             return fail(ctx, RTO_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
-// Test hook: RTO_FAULT_ALLOC=<k> makes the k-th (1-based) buffer allocation of the frustum-update buffers / rto_comm buffers
-// fail, so that the all-or-nothing clean-up below can be exercised (tests/test_gpu_parity.py); unset: never.
+// A/B knobs and developer aids read from the environment exist only in builds made with -DRTO_DEV_KNOBS (tools/build_variants.sh):
+// the shipped library reads NO environment variable -- a stray RTO_* in a user's environment cannot change what it does.
+static inline long long dev_env(const char* name, long long unset) {
+#if defined(RTO_DEV_KNOBS)
+    const char* e = std::getenv(name);
+    return (e && *e) ? std::atoll(e) : unset;
+#else
+    (void)name;
+    return unset;
+#endif
+}
+
+// Test hook (rto_debug_fault_alloc(k), an explicit call: never the environment): the k-th (1-based) buffer allocation of the
+// frustum-update buffers / rto_comm buffers from now on fails, so that the all-or-nothing clean-up below can be exercised
+// (tests/test_gpu_parity.py, tests/_fault_alloc_worker.py).  0: never.
+static long g_faultCountdown = 0;
 static hipError_t fallible_malloc(void** p, size_t bytes) {
-    static long countdown = []() { const char* e = std::getenv("RTO_FAULT_ALLOC"); return e ? std::atol(e) : 0L; }();
-    if (countdown > 0 && --countdown == 0) { *p = nullptr; return hipErrorOutOfMemory; }
+    if (g_faultCountdown > 0 && --g_faultCountdown == 0) { *p = nullptr; return hipErrorOutOfMemory; }
     return hipMalloc(p, bytes);
 }
+extern "C" int rto_debug_fault_alloc(long k) { g_faultCountdown = k > 0 ? k : 0; return RTO_OK; }
 
 static void free_cull_buffers(rto_context* c) {
     (void)hipFree(c->d_cullBlockCount); c->d_cullBlockCount = nullptr;
@@ -412,7 +426,7 @@ struct BuildScratch {
 constexpr int kMaskMaxCells = 8192;      // config 2: 5,624 cells (depth 5) serve as well as 20,504 (depth 6): 38.7 us either way; projecting them costs a quarter
 static int build_cells_impl(rto_context* c);
 static int build_cells(rto_context* c) {
-    static const bool trace = std::getenv("RTO_BUILD_TRACE") != nullptr;     // developer aid: host time of this step, on stderr
+    static const bool trace = dev_env("RTO_BUILD_TRACE", 0) != 0;            // developer aid (dev builds): host time of this step, on stderr
     if (!trace) return build_cells_impl(c);
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = build_cells_impl(c);
@@ -443,7 +457,7 @@ static int build_cells_impl(rto_context* c) {
     for (int L = 1; L <= c->depth && L <= kMaxDepth; L++) {
         solidAbove += counts[kMaxDepth + 1 + L];
         const long long n = counts[L] + solidAbove;
-        static const long long cellsEnv = []() { const char* e = std::getenv("RTO_MASK_CELLS"); return e ? std::atoll(e) : 0LL; }();      // A/B knob
+        static const long long cellsEnv = dev_env("RTO_MASK_CELLS", 0);      // A/B knob (dev builds)
         if (n > (cellsEnv > 0 ? cellsEnv : (long long)kMaskMaxCells)) break;
         level = L; best = n;
     }
@@ -1176,7 +1190,7 @@ static void root_rectangle_box(RenderParams& P, int minFillWaves) {
     else {
         // tile box, rounded outwards to multiples of 4 tiles: under a moving camera the box (and with it the launch-order
         // table) then changes 4x less often; the extra tiles are waves without work
-        static const int rnd = []() { const char* e = std::getenv("RTO_BOX_ROUND"); const int v = e ? std::atoi(e) : 0;      // A/B knob
+        static const int rnd = []() { const int v = (int)dev_env("RTO_BOX_ROUND", 0);      // A/B knob (dev builds)
                                       return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ? v - 1 : 3; }();
         const int tx0 = (x0 / 8) & ~rnd, ty0 = (lyA / 8) & ~rnd;
         const int tx1 = std::min(P.tilesX - 1, ((x1 / 8) | rnd)), ty1 = std::min(P.tilesY - 1, (((lyB - 1) / 8) | rnd));
@@ -1316,7 +1330,7 @@ static rto_context::OrderState* order_state(rto_context* c, hipStream_t s, int p
 // 21.9 -> 20.2, 8 GPUs (7 rendering parts) 14.4 -> 14.3.  The triangle frames (path 1) keep it for whole frames: a rank of 8 at
 // config 5 measured 93.5 us with it against 91.5 without.  RTO_MASK_PARTS_MAX overrides both (A/B runs; 1: whole frames only).
 static int mask_parts_max(int path) {
-    static const int v = []() { const char* e = std::getenv("RTO_MASK_PARTS_MAX"); return e ? std::atoi(e) : 0; }();
+    static const int v = (int)dev_env("RTO_MASK_PARTS_MAX", 0);
     return v > 0 ? v : (path == 1 ? 1 : 8);
 }
 
@@ -1353,7 +1367,7 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
         Q.maskStamp = c->maskStamp;
         Q.maskAllIndex = (int)(words - 3);
         Q.maskBlocks = (c->numCells + lean_block(path) - 1) / lean_block(path);
-        static const int trustEnv = []() { const char* e = std::getenv("RTO_MASK_TRUST"); return e ? std::atoi(e) : -1; }();     // A/B knob
+        static const int trustEnv = (int)dev_env("RTO_MASK_TRUST", -1);      // A/B knob (dev builds)
         Q.maskTrustSlots = c->maskMode == 2 ? 0 : (trustEnv >= 0 ? trustEnv : kMaskTrustSlots);
         Q.maskCells = c->d_cells; Q.maskNumCells = c->numCells;
         Q.maskInvAspTan = 1.0f / (P.aspect * P.tanHalfFov); Q.maskInvTanH = 1.0f / P.tanHalfFov;
@@ -1393,7 +1407,7 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
         // (S/RT:363), so the rectangle of the solid leaves' bounding box replaces the root box's
         Q.rootX0 = rect[0]; Q.rootY0 = rect[1]; Q.rootX1 = rect[2]; Q.rootY1 = rect[3];
         root_rectangle_box(Q, 8 * c->numCUs);
-        static const bool trace = std::getenv("RTO_TRACE_GEOMETRY") != nullptr;      // developer aid
+        static const bool trace = dev_env("RTO_TRACE_GEOMETRY", 0) != 0;      // developer aid (dev builds)
         if (trace) {
             static int last[4] = { -1, -1, -1, -1 };
             const int now[4] = { Q.boxX0, Q.boxY0, Q.boxW, Q.boxH };
@@ -1442,8 +1456,8 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
 // RTO_LEAN_BLOCK / RTO_TRI_BLOCK = <64|128|256> override (A/B runs).
 static int lean_block(int path) {
     static const int b[2] = {
-        []() { const char* e = std::getenv("RTO_LEAN_BLOCK"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 256; }(),
-        []() { const char* e = std::getenv("RTO_TRI_BLOCK"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 64; }() };
+        []() { const int v = (int)dev_env("RTO_LEAN_BLOCK", 0); return (v == 64 || v == 128 || v == 256) ? v : 256; }(),
+        []() { const int v = (int)dev_env("RTO_TRI_BLOCK", 0); return (v == 64 || v == 128 || v == 256) ? v : 64; }() };
     return b[path == 1 ? 1 : 0];
 }
 static int lean_wpb(int path) { return lean_block(path) / kWave; }
@@ -1457,7 +1471,7 @@ static int lean_wpb(int path) { return lean_block(path) / kWave; }
 // CU hands its LDS out in two halves --, 53 KB gives 2 per SIMD: 46.7 us.)  Launches of several frames have waves to spare and
 // keep 6.  RTO_WAVES_PER_SIMD=<n> overrides (A/B runs); 0 = never pad.
 static size_t lds_for_occupancy(size_t lds, int wavesDefault) {
-    static const int forced = []() { const char* e = std::getenv("RTO_WAVES_PER_SIMD"); return e ? std::atoi(e) : -1; }();
+    static const int forced = (int)dev_env("RTO_WAVES_PER_SIMD", -1);
     const int waves = forced >= 0 ? forced : wavesDefault;
     if (waves <= 0) return lds;
     const size_t groupsPerCU = (size_t)waves * 4 / (size_t)lean_wpb(0);     // 4 SIMDs per CU

@@ -1,4 +1,4 @@
-"""Worker for test_partial_allocation_failures_leave_nothing_behind: run with RTO_FAULT_ALLOC=<k> in the environment, which
+"""Worker for test_partial_allocation_failures_leave_nothing_behind: `worker.py <what> <k>` calls rto_debug_fault_alloc(k), which
 makes the k-th buffer allocation of the frustum update / of rto_comm fail (fallible_malloc in csrc/rto_api.hip).  The call
 that hits the failure must report it; the same call repeated must then succeed from scratch and render the oracle's frame
 (all-or-nothing clean-up: no half-allocated state survives)."""
@@ -18,6 +18,7 @@ from ray_tracing_octrees_amd import hip  # noqa: E402
 
 def main():
     what = sys.argv[1]
+    assert hip.load().rto_debug_fault_alloc(int(sys.argv[2])) == 0
     W, H = 160, 96
     g = orc.test_sphere_grid(32)
     nodes = orc.build_flat_octree(g)

@@ -1997,14 +1997,14 @@ def test_config5_every_rank_of_8_gpus_at_full_size(ctx, orc, scenes, camera):
 
 @pytest.mark.parametrize("what,allocs", [("frustum", 5), ("comm", 6)])
 def test_partial_allocation_failures_leave_nothing_behind(what, allocs):
-    """Fault injection (RTO_FAULT_ALLOC=k: the k-th buffer allocation fails): whichever of its allocations fails, a frustum
+    """Fault injection (rto_debug_fault_alloc(k): the k-th buffer allocation fails): whichever of its allocations fails, a frustum
     update / a communicator submit reports the failure, keeps no half-allocated state, and the repeated call works."""
     import subprocess
     import sys
 
     for k in range(1, allocs + 1):
-        env = dict(os.environ, RTO_FAULT_ALLOC=str(k), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fault_alloc_worker.py"), what], env=env, capture_output=True, text=True, timeout=300)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fault_alloc_worker.py"), what, str(k)], env=env, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, f"{what}, allocation {k}: " + p.stdout[-1500:] + p.stderr[-2500:]
 
 
@@ -2083,7 +2083,7 @@ def test_bench_line_contract_small_run():
     assert d["frames_per_launch"]["ms_per_frame"] > 0 and d["frames_per_launch"]["frames_equal_the_timed_frame"] is True and d["orbit"]["frames"] == 8
     assert d["dropin_call"]["ms_per_call"] > 0 and d["dropin_call"]["frame_equals_timed_frame"] is True
     assert len(d["config"]["workload"]) <= 120 and d["config"]["workload"].startswith("cfg2:") and len(d["config"]["clock_ramp"]) <= 120
-    assert "one kernel launch per frame" in d["config"]["parallelism"] and d["roofline"]["kernel_ms_median"] > 0
+    assert "one kernel launch per frame" in d["config"]["parallelism"] and d["roofline"]["kernel_ms_event_pair_median"] > 0
 
 
 def test_camera_a_hair_outside_the_root_box(ctx, orc):

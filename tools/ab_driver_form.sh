@@ -6,7 +6,7 @@ for rep in 1 2 3; do
     python3 - "$m" "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[2]); r = d["roofline"]
-print(f"{sys.argv[1] or 'mask':15s} ms/frame {d['ms_per_step']:.5f}  kernel avg {r['kernel_ms_avg']:.5f} med {r['kernel_ms_median']:.5f} min {r['kernel_ms_min']:.5f}  4-per-launch {d['frames_per_launch']['ms_per_frame']:.5f} dropin {d['dropin_call']['ms_per_call']:.5f} / {d['dropin_call']['ms_per_call_without_update']:.5f}")
+print(f"{sys.argv[1] or 'mask':15s} ms/frame {d['ms_per_step']:.5f}  kernel avg {r['kernel_ms_avg']:.5f} med {r['kernel_ms_event_pair_median']:.5f} min {r['kernel_ms_event_pair_min']:.5f}  4-per-launch {d['frames_per_launch']['ms_per_frame']:.5f} dropin {d['dropin_call']['ms_per_call']:.5f} / {d['dropin_call']['ms_per_call_without_update']:.5f}")
 PY
   done
 done

@@ -6,7 +6,7 @@ for w in 0 4 5; do
     python3 - "$w" "$m" "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[3]); r = d["roofline"]
-print(f"waves/SIMD {sys.argv[1]:>2s} {sys.argv[2] or 'mask':15s} ms/frame {d['ms_per_step']:.5f}  kernel avg {r['kernel_ms_avg']:.5f} min {r['kernel_ms_min']:.5f}  4-per-launch {d['frames_per_launch']['ms_per_frame']:.5f}")
+print(f"waves/SIMD {sys.argv[1]:>2s} {sys.argv[2] or 'mask':15s} ms/frame {d['ms_per_step']:.5f}  kernel avg {r['kernel_ms_avg']:.5f} min {r['kernel_ms_event_pair_min']:.5f}  4-per-launch {d['frames_per_launch']['ms_per_frame']:.5f}")
 PY
   done
 done

@@ -6,7 +6,7 @@ for st in 20 20 40 100 200 1000; do
     python3 - "$st" "$g" "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[3]); r = d["roofline"]
-print(f"steps {sys.argv[1]:>5s} {sys.argv[2] or 'graph':18s} ms/frame {d['ms_per_step']:.5f}  region gpu {r['timed_region_gpu_ms_per_frame']:.5f} kernel avg {r['kernel_ms_avg']:.5f} min {r['kernel_ms_min']:.5f}")
+print(f"steps {sys.argv[1]:>5s} {sys.argv[2] or 'graph':18s} ms/frame {d['ms_per_step']:.5f}  region gpu {r['timed_region_gpu_ms_per_frame']:.5f} kernel avg {r['kernel_ms_avg']:.5f} min {r['kernel_ms_event_pair_min']:.5f}")
 PY
   done
 done
