@@ -87,6 +87,8 @@ struct rto_context {
         int tiles = 0;                  // tile count the buffers are sized for
         long key[7] = { 0, 0, 0, 0, 0, 0, 0 };   // W, H, numParts, part, bandRows, tiles, path (0 octree / 1 triangles) of the frames the history belongs to
         bool costValid = false;         // a frame of this geometry has recorded its costs
+        float lastCam[19] = { 0 };      // inverse view + eye of the last single-frame launch: a camera in motion rebuilds the table for every frame
+        bool haveCam = false;
         bool fixed = false;             // debug: the caller supplied the table (over ALL tiles), do not rebuild it
         int* d_queue = nullptr;         // persistent-threads variant: the slot counter (zeroed in front of every launch)
         unsigned* d_tileMask = nullptr; // occupancy masks of the frames of one launch: kMaxBatch regions of maskWords words (mask_block)
@@ -258,8 +260,6 @@ int rto_create(int device_ordinal, rto_context** out) {
         rto_destroy(c);
         return fail(nullptr, RTO_E_HIP, msg);
     }
-    // the launch-order kernel stages one byte per tile of the box in LDS (up to 144 KB of the CU's 160 KB)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_order_build), hipFuncAttributeMaxDynamicSharedMemorySize, kOrderLdsTiles);
     *out = c;
     return RTO_OK;
 }
@@ -1339,7 +1339,7 @@ static int mask_parts_max(int path) {
 // the costs earlier frames recorded.  frameMode: a colour / shade frame (records costs); otherwise (instrumentation) the
 // whole image keeps one wave per tile.  On return Q holds the geometry, the table and the cost pointer.
 static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool frameMode, bool timelineMode, int path, const int rect[4],
-                            RenderParams& Q, rto_context::OrderState** stOut, int maskRegion = -1) {
+                            RenderParams& Q, rto_context::OrderState** stOut, int maskRegion = -1, bool single = false) {
     const RenderParams& P = Q;
     const int tiles = P.tilesX * P.tilesY;
     Q.tileOrder = nullptr; Q.tileCost = nullptr;
@@ -1386,6 +1386,7 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
             RTO_HIP(c, hipMalloc(&o->d_tileCost, (size_t)tiles * sizeof(int)));
             RTO_HIP(c, hipMalloc(&o->tab[0].d, (size_t)tiles * sizeof(int)));
             RTO_HIP(c, hipMalloc(&o->tab[1].d, (size_t)tiles * sizeof(int)));
+            RTO_HIP(c, hipMemset(o->d_tileCost, 0, (size_t)tiles * sizeof(int)));
             o->tiles = tiles; o->tab[0].valid = o->tab[1].valid = false; o->costValid = false; o->fixed = false;
         }
         if (std::memcmp(key, o->key, sizeof key) != 0) { o->tab[0].valid = o->tab[1].valid = false; o->costValid = false; o->fixed = false; std::memcpy(o->key, key, sizeof key); }
@@ -1428,14 +1429,25 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
         // A rebuild for age alone (same box size: a camera that stands still or only pans) doubles the next interval, up to 8
         // periods: the costs of such frames change slowly, and a build (13 us at config 2) every 8th frame was 4 % of a frame.
         const bool resized = !T.valid || box[2] != T.box[2] || box[3] != T.box[3];
-        if (!fixedOrder && Q.traceWaves > 0 && (resized || T.age >= c->orderPeriod * T.stretch)) {
-            // (the back-off also under a moving camera: keeping the period at 8 while the view changes was measured on an orbit of
-            //  0.01 rad per frame -- 46.7 us per frame against 46.1 with it; the rebuilds cost what the fresher table gains)
-            T.stretch = resized ? 1 : std::min(T.stretch * 2, 8);
+        // A camera in motion: the costs are stale after ONE frame (the rays that wander along the silhouette are in other tiles every
+        // frame), and with the 16-workgroup sort a rebuild costs ~2.5 us + a launch gap -- less than a stale table does (orbit of 0.01
+        // rad per frame: 32.5 us per frame rebuilt every frame, 36 / 38 / 39 every 2nd / 4th / 8th).  Single-frame launches only: the
+        // frames of a batch share one table.  A camera that stands still backs off as before.
+        bool moved = false;
+        if (single && frameMode) {
+            float cam[19];
+            std::memcpy(cam, P.invView, 16 * sizeof(float)); std::memcpy(cam + 16, P.camPos, 3 * sizeof(float));
+            moved = o->haveCam && std::memcmp(cam, o->lastCam, sizeof cam) != 0;
+            std::memcpy(o->lastCam, cam, sizeof cam); o->haveCam = true;
+        }
+        if (!fixedOrder && Q.traceWaves > 0 && (resized || moved || T.age >= c->orderPeriod * T.stretch)) {
+            T.stretch = (resized || moved) ? 1 : std::min(T.stretch * 2, 8);
             if (o->costValid) {
-                const int staged = Q.traceWaves <= kOrderLdsTiles ? 1 : 0;
-                hipLaunchKernelGGL(k_order_build, dim3(1), dim3(kOrderBlock), staged ? (size_t)((Q.traceWaves + 15) & ~15) : 0, s, o->d_tileCost, Q.tilesX,
-                                   Q.boxX0, Q.boxY0, Q.boxW, Q.boxH, staged, T.d, c->d_sortViolations);
+                const size_t stage = (size_t)(((Q.traceWaves + kOrderGroups - 1) / kOrderGroups + 15) & ~15);      // one byte per tile of a workgroup's sample
+                if (stage > 60 * 1024) return fail(c, RTO_E_UNSUPPORTED, "render: frame too large for the launch-order sort (more than 983,040 tiles in the geometry's box)");
+                static const int groups = []() { const int g = (int)dev_env("RTO_ORDER_GROUPS", kOrderGroups); return (g == 16 || g == 32 || g == 64) ? g : kOrderGroups; }();   // A/B knob (dev builds)
+                hipLaunchKernelGGL(k_order_build, dim3(groups), dim3(kOrderBlock * kOrderGroups / groups), stage, s, o->d_tileCost, Q.tilesX,
+                                   Q.boxX0, Q.boxY0, Q.boxW, Q.boxH, T.d, c->d_sortViolations);
                 std::memcpy(T.box, box, sizeof box);
                 T.valid = true; T.age = 0;
             } else T.valid = false;
@@ -1520,7 +1532,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
             {
                 const bool maskable = leanKernel && c->kernelMode != RTO_KERNEL_PACKED_PERSISTENT;
-                const int rc = prepare_schedule(c, s, capturing, frameMode, MODE == kModeTimeline, 0, solidRect, Q, &st, maskable ? 0 : -1);
+                const int rc = prepare_schedule(c, s, capturing, frameMode, MODE == kModeTimeline, 0, solidRect, Q, &st, maskable ? 0 : -1, true);
                 if (rc != RTO_OK) return rc;
             }
             const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
@@ -2030,7 +2042,7 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
         rto_context::OrderState* st = nullptr;
         const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
         const bool leanTri = c->d_triRec && c->kernelMode != RTO_KERNEL_PACKED_V3;
-        if ((rc = prepare_schedule(c, s, capturing, !count, false, 1, solidRect, P, &st, leanTri ? 0 : -1)) != RTO_OK) return rc;
+        if ((rc = prepare_schedule(c, s, capturing, !count, false, 1, solidRect, P, &st, leanTri ? 0 : -1, true)) != RTO_OK) return rc;
     }
     const bool noEvents = capturing || c->eventsOff;
     hipEvent_t evA = c->ev0, evB = c->ev1;                 // a timing-ring slot per launch that records events (rto_timing_begin)
@@ -2315,7 +2327,7 @@ static int launch_skip_render(rto_context* c, const rto_frame* f, const rto_part
     // launch geometry, launch order and occupancy mask of the first-hit frames (path 2: tables of its own kind on the stream)
     rto_context::OrderState* st = nullptr;
     const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
-    if ((rc = prepare_schedule(c, s, stream_is_capturing(s), true, false, 2, solidRect, P, &st, 0)) != RTO_OK) return rc;
+    if ((rc = prepare_schedule(c, s, stream_is_capturing(s), true, false, 2, solidRect, P, &st, 0, true)) != RTO_OK) return rc;
     P.maskLdsBytes = (int)lds;
     const int blocks = (P.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave) + P.maskBlocks;
     if (c->maskMode == 2 && P.maskBlocks > 0)

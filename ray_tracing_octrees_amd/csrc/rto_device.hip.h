@@ -666,6 +666,89 @@ __device__ __forceinline__ int wave_scan_max_nonneg(int v) {       // values >= 
     return v;
 }
 
+// ================================================================ launch order
+// Launch order of the box's tiles by descending cost (trip count an earlier frame recorded; 64 buckets), built by G workgroups
+// that never talk to each other: workgroup w owns the tiles i = w, w + G, w + 2G, ... of the box (raster order: a strided
+// sample, so every workgroup sees the same cost distribution), sorts ITS tiles by a counting sort in LDS, and writes its p-th
+// costliest tile to table position p * G + w.  The table is then the interleave of G sorted samples -- globally sorted up to the
+// sampling noise, which is all a launch order needs -- and a permutation of the box's tiles BY CONSTRUCTION, whatever the cost
+// array holds (stale values, tiles that were outside the box when it was written): every cost is read ONCE (its bucket is
+// staged in LDS), and positions p * G + w, p < |sample w|, are exactly 0 .. n-1.  No state between calls, nothing shared between
+// workgroups: safe as a node of a captured graph.  Entries: x | y << 16 relative to the box's corner.
+// 4.8 us at config 2 against the 13 us of round 3's single-workgroup sort: cheap enough to run in front of EVERY frame of a camera
+// in motion, whose costs are stale after one frame (the rays that wander along the silhouette are in other tiles every frame).
+// (Tried and dropped in round 4: the same sort run by workgroups INSIDE the frame's own launch, for the next frame -- no launch, no
+//  gap, but the tiles that matter, the costliest, finish last and had not recorded their cost yet: orbit 38.8 us per frame against
+//  38.0 with the explicit rebuild, a static camera 34.4 against 33.5.)
+constexpr int kOrderBuckets = 64;
+constexpr int kOrderBlock = 1024;
+constexpr int kOrderGroups = 16;
+
+// sample w of G; `stage`: LDS, one byte per tile of the sample; `cnt`: LDS, kOrderBuckets ints
+__device__ __forceinline__ void order_sort_sample(const int* __restrict__ tileCost, int tilesX, int boxX0, int boxY0, int boxW, int boxH, int w, int G,
+                                                  int* __restrict__ order, int* __restrict__ violations, unsigned char* stage, int* cnt) {
+    const int n = boxW * boxH;
+    const int cw = (n - w + G - 1) / G;
+    const int lane = threadIdx.x & 63, bd = (int)blockDim.x;
+    auto tile_of_elem = [&](int e, int& rx, int& ry) { const int i = e * G + w; ry = i / boxW; rx = i - ry * boxW; };
+    if ((int)threadIdx.x < kOrderBuckets) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // Bucket 0 -- tiles whose wave did not walk: with the occupancy mask more than half of a box -- is counted and placed by
+    // ballot (one LDS atomic per wave): 64 lanes adding to ONE counter serialise.
+    // bucket 0: nothing there; 1: no work, but inside the occupancy mask's margin (cost -1); 2..63: 1 + min(cost, 62)
+    for (int e0 = (int)(threadIdx.x & ~63u); e0 < cw; e0 += bd) {           // wave-uniform trip count: ballots inside
+        const int e = e0 + lane;
+        int b = -1;
+        if (e < cw) {
+            int rx, ry;
+            tile_of_elem(e, rx, ry);
+            const int c = tileCost[(boxY0 + ry) * tilesX + boxX0 + rx];
+            b = c > 0 ? min(c, kOrderBuckets - 2) + 1 : (c < 0 ? 1 : 0);
+            stage[e] = (unsigned char)b;
+        }
+        const unsigned long long zeros = __builtin_amdgcn_ballot_w64(b == 0);
+        if (b > 0) atomicAdd(&cnt[b], 1);
+        if (zeros && lane == (int)__builtin_ctzll(zeros)) atomicAdd(&cnt[0], (int)__builtin_popcountll(zeros));
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < kWave) {                 // write cursors: costlier buckets first.  Lane b owns bucket 63 - b.
+        const int b = kOrderBuckets - 1 - lane;
+        const int total = cnt[b];
+        int incl = total;
+        for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        cnt[b] = incl - total;
+    }
+    __syncthreads();
+    for (int e0 = (int)(threadIdx.x & ~63u); e0 < cw; e0 += bd) {
+        const int e = e0 + lane;
+        const int b = e < cw ? (int)stage[e] : -1;
+        const unsigned long long zeros = __builtin_amdgcn_ballot_w64(b == 0);
+        int r = -1;
+        if (b > 0) r = atomicAdd(&cnt[b], 1);
+        if (zeros) {
+            const int leader = (int)__builtin_ctzll(zeros);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&cnt[0], (int)__builtin_popcountll(zeros));
+            base = __shfl(base, leader);
+            if (b == 0) r = base + (int)__builtin_popcountll(zeros & ((1ull << lane) - 1ull));
+        }
+        if (b < 0) continue;
+        int rx, ry;
+        tile_of_elem(e, rx, ry);
+        // cannot fall outside by construction (both passes see the same staged buckets); refused writes are counted and tests assert 0
+        const int pos = r * G + w;
+        if (r >= 0 && r < cw && pos < n) order[pos] = rx | (ry << 16);
+        else atomicAdd(violations, 1);
+    }
+}
+
+__global__ __launch_bounds__(kOrderBlock) void k_order_build(const int* __restrict__ tileCost, int tilesX, int boxX0, int boxY0, int boxW, int boxH,
+                                                              int* __restrict__ order, int* __restrict__ violations) {
+    extern __shared__ unsigned char order_stage[];  // one byte per tile of the sample
+    __shared__ int cnt[kOrderBuckets];
+    order_sort_sample(tileCost, tilesX, boxX0, boxY0, boxW, boxH, (int)blockIdx.x, kOrderGroups, order, violations, order_stage, cnt);
+}
+
 // ================================================================ screen-space occupancy mask
 // About two thirds of the rays inside the solid geometry's screen rectangle miss everything (config 2: the corners of the
 // sphere's bounding box, the ring around its silhouette) -- and each still costs its wave the ray set-up (two inversesqrt,
@@ -1439,84 +1522,6 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_persisten
             left = kPersistChunk;
         }
     }
-}
-
-// Launch order of the box's tiles: a counting sort by descending cost (trip count an earlier frame recorded, 64
-// buckets of min(trips, 63)) done by ONE 1,024-thread block -- a few thousand tiles, no inter-block state: whatever the
-// cost array holds (stale values, tiles that were outside the box when it was written), the result is a permutation of
-// the box's tiles (entries x | y << 16 relative to the box's corner), so every tile is rendered exactly once.  Wave w owns the box rows w, w+16, ...
-// (lanes walk a row: no division anywhere); the buckets of its tiles are staged in LDS by one pass of independent,
-// coalesced loads (reading the costs inside the counting loops cost a dependent global load per step, 80 us per build),
-// then counted and placed with LDS atomics.  Tiles of one bucket keep their wave order; within a wave the order is the
-// atomics'.
-constexpr int kOrderBuckets = 64;
-constexpr int kOrderBlock = 1024;
-constexpr int kOrderLdsTiles = 144 * 1024;          // buckets staged in LDS (1 byte per tile); larger boxes re-read the costs
-
-__global__ __launch_bounds__(kOrderBlock) void k_order_build(const int* __restrict__ tileCost, int tilesX, int boxX0, int boxY0, int boxW, int boxH,
-                                                              int staged, int* __restrict__ order, int* __restrict__ violations) {
-    constexpr int kWaves = kOrderBlock / kWave;
-    extern __shared__ unsigned char stagedBucket[];  // [boxH][boxW] when staged
-    __shared__ int cnt[kWaves][kOrderBuckets];      // pass 1: counts; then each wave's write cursor per bucket
-    const int n = boxW * boxH;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // bucket 0: nothing there; 1: no work, but inside the occupancy mask's margin (cost -1); 2..63: 1 + min(cost, 62)
-    auto bucket_at = [&](int rx, int ry) { const int c = tileCost[(boxY0 + ry) * tilesX + boxX0 + rx]; return c > 0 ? min(c, kOrderBuckets - 2) + 1 : (c < 0 ? 1 : 0); };
-    for (int i = threadIdx.x; i < kWaves * kOrderBuckets; i += kOrderBlock) (&cnt[0][0])[i] = 0;
-    if (staged)
-        for (int ry = wave; ry < boxH; ry += kWaves)
-            for (int rx0 = lane; rx0 < boxW; rx0 += 4 * kWave) {          // four independent loads in flight per lane
-                int v[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) v[q] = rx0 + q * kWave < boxW ? bucket_at(rx0 + q * kWave, ry) : 0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) if (rx0 + q * kWave < boxW) stagedBucket[ry * boxW + rx0 + q * kWave] = (unsigned char)v[q];
-            }
-    __syncthreads();
-    // Bucket 0 -- tiles whose wave did not walk: with the occupancy mask more than half of a box -- is counted and placed by
-    // ballot (one LDS atomic per wave and row chunk): 64 lanes adding to ONE counter serialise.
-    for (int ry = wave; ry < boxH; ry += kWaves)
-        for (int rx0 = 0; rx0 < boxW; rx0 += kWave) {                   // wave-uniform trip count: ballots inside
-            const int rx = rx0 + lane;
-            const bool in = rx < boxW;
-            const int b = in ? (staged ? (int)stagedBucket[ry * boxW + rx] : bucket_at(rx, ry)) : -1;
-            const unsigned long long zeros = __builtin_amdgcn_ballot_w64(b == 0);
-            if (b > 0) atomicAdd(&cnt[wave][b], 1);
-            if (zeros && lane == (int)__builtin_ctzll(zeros)) atomicAdd(&cnt[wave][0], (int)__builtin_popcountll(zeros));
-        }
-    __syncthreads();
-    // write cursors: costlier buckets first, within a bucket wave 0 first.  Wave 0 does it: lane b owns bucket 63 - b.
-    if (wave == 0) {
-        const int b = kOrderBuckets - 1 - lane;
-        int total = 0;
-        for (int w = 0; w < kWaves; w++) total += cnt[w][b];
-        int incl = total;
-        for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-        int run = incl - total;                                   // tiles of costlier buckets
-        for (int w = 0; w < kWaves; w++) { const int h = cnt[w][b]; cnt[w][b] = run; run += h; }
-    }
-    __syncthreads();
-    for (int ry = wave; ry < boxH; ry += kWaves)
-        for (int rx0 = 0; rx0 < boxW; rx0 += kWave) {
-            const int rx = rx0 + lane;
-            const bool in = rx < boxW;
-            const int b = in ? (staged ? (int)stagedBucket[ry * boxW + rx] : bucket_at(rx, ry)) : -1;
-            const unsigned long long zeros = __builtin_amdgcn_ballot_w64(b == 0);
-            int pos = -1;
-            if (b > 0) pos = atomicAdd(&cnt[wave][b], 1);
-            if (zeros) {
-                const int leader = (int)__builtin_ctzll(zeros);
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&cnt[wave][0], (int)__builtin_popcountll(zeros));
-                base = __shfl(base, leader);
-                if (b == 0) pos = base + (int)__builtin_popcountll(zeros & ((1ull << lane) - 1ull));
-            }
-            if (!in) continue;
-            // cannot fall outside by construction (both passes see the same buckets: the kernel that writes the costs runs
-            // before or after this one on the stream, never beside it); refused writes are counted and tests assert 0
-            if (pos >= 0 && pos < n) order[pos] = rx | (ry << 16);           // relative to the box: a box of the same size elsewhere can use the table
-            else atomicAdd(violations, 1);
-        }
 }
 
 // ================================================================ frustum culling (N3)
