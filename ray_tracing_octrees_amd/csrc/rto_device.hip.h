@@ -2870,7 +2870,9 @@ __global__ __launch_bounds__(kWave) void k_probe_skip(ProbeParams Q, const uint2
     const uint4 lutA = reinterpret_cast<const uint4*>(kSkipPerm.v)[lane * 2], lutB = reinterpret_cast<const uint4*>(kSkipPerm.v)[lane * 2 + 1];
     const uint2 rootDesc = desc[0];                                       // warms the root's line while the rays are set up
     float t = 1e30f;
-    SkipRay r = skip_ray(0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
+    // the probe's direction as three plain floats: a SkipRay that lives across the barrier below was kept in SCRATCH (24 bytes: two
+    // scratch stores at the kernel's head, two before the rank step, the loads in front of the traversal -- in a one-wave latency chain)
+    float pdx = 1.f, pdy = 1.f, pdz = 1.f;
     if (lane < 49) {
         const int gridSize = 7;
         const float sampleOffset = 0.2f;
@@ -2888,12 +2890,13 @@ __global__ __launch_bounds__(kWave) void k_probe_skip(ProbeParams Q, const uint2
         for (int rr = 0; rr < 4; rr++) wp[rr] = (Q.invV[rr] * vp[0] + Q.invV[4 + rr] * vp[1]) + (Q.invV[8 + rr] * vp[2] + Q.invV[12 + rr] * vp[3]);
         const float qx = wp[0] - Q.eye[0], qy = wp[1] - Q.eye[1], qz = wp[2] - Q.eye[2];
         const float inv = inversesqrt(qx * qx + qy * qy + qz * qz);
-        r = skip_ray(Q.eye[0], Q.eye[1], Q.eye[2], qx * inv, qy * inv, qz * inv);
+        pdx = qx * inv; pdy = qy * inv; pdz = qz * inv;
     }
     reinterpret_cast<uint4*>(permLut)[lane * 2] = lutA; reinterpret_cast<uint4*>(permLut)[lane * 2 + 1] = lutB;
     asm volatile("" :: "v"(rootDesc.x), "v"(rootDesc.y));
     __syncthreads();
     if (lane < 49) {
+        const SkipRay r = skip_ray(Q.eye[0], Q.eye[1], Q.eye[2], pdx, pdy, pdz);
         int a, b, cc, dd;
         t = skip_traverse(desc, vis, useVis != 0, Q.rootSize, Q.gx, Q.gy, Q.gz, Q.vs, r, 0.0f, 1e30f, stk, a, b, cc, dd, nullptr, permLut);
         if (probeT) probeT[lane] = t;
