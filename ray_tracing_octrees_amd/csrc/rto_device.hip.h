@@ -791,6 +791,21 @@ __device__ __forceinline__ void mask_block(const RenderParams& P, int blockInFra
     const int all = P.maskAllIndex;
     const int i = blockInFrame * (int)blockDim.x + (int)threadIdx.x;
     int kind = 0, tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;          // 0: stamps nothing, 1: the tile rectangle, 2: the "whole frame" word
+    // The first 8 words of the dynamic LDS hold the workgroup's tile bounding box and its "whole frame" flag (a static __shared__
+    // array would add to every workgroup's LDS request, which the launchers size to the byte for a residency of 4 or 6 waves per
+    // SIMD); the bitmap follows.  When a bitmap of the WHOLE frame fits (1080p: 4 KB) there is no bounding box to agree on: the
+    // bitmap is cleared before the projection and two barriers do (with the box: four) -- the mask is complete ~1 us earlier,
+    // and every wave that starts before that sets up rays for nothing.
+    int* box = reinterpret_cast<int*>(bits);
+    int& wholeFrame = box[4];
+    bits += 8; capWords -= 8;
+    const bool wide = (P.tilesX & 3) == 0;                                   // every mask row starts 16-byte aligned: runs of 4 set tiles leave as one store
+    const int frameRowWords = (P.tilesX + 31) >> 5, frameWords = frameRowWords * ((P.H + 7) >> 3);
+    const bool whole = frameWords <= capWords;                               // workgroup-uniform (every workgroup of the launch, in fact)
+    if (whole) {
+        for (int w = threadIdx.x; w < frameWords; w += blockDim.x) bits[w] = 0u;
+        if (threadIdx.x == 0) wholeFrame = 0;
+    }
     if (i < P.maskNumCells) {
         const int4 c = P.maskCells[i];
         const float vs = P.voxelSize;
@@ -822,23 +837,21 @@ __device__ __forceinline__ void mask_block(const RenderParams& P, int blockInFra
             }
         }
     }
-    // the workgroup's tile bounding box (the first 8 words of the dynamic LDS: a static __shared__ array would add to every
-    // workgroup's LDS request, which the launchers size to the byte for a residency of 4 or 6 waves per SIMD)
-    int* box = reinterpret_cast<int*>(bits);
-    int& wholeFrame = box[4];
-    bits += 8; capWords -= 8;
-    if (threadIdx.x == 0) { box[0] = box[1] = 0x7fffffff; box[2] = box[3] = -1; wholeFrame = 0; }
-    __syncthreads();
-    if (kind == 1) { atomicMin(&box[0], tx0); atomicMin(&box[1], ty0); atomicMax(&box[2], tx1); atomicMax(&box[3], ty1); }
-    if (kind == 2) wholeFrame = 1;
-    __syncthreads();
-    const bool wide = (P.tilesX & 3) == 0;                                   // every mask row starts 16-byte aligned: runs of 4 set tiles leave as one store
-    const int bx0 = wide ? box[0] & ~3 : box[0], by0 = box[1], bx1 = box[2], by1 = box[3];
+    int bx0 = 0, by0 = 0, bx1 = P.tilesX - 1, by1 = ((P.H + 7) >> 3) - 1;
+    if (!whole) {                                                            // the workgroup's tile bounding box
+        if (threadIdx.x == 0) { box[0] = box[1] = 0x7fffffff; box[2] = box[3] = -1; wholeFrame = 0; }
+        __syncthreads();
+        if (kind == 1) { atomicMin(&box[0], tx0); atomicMin(&box[1], ty0); atomicMax(&box[2], tx1); atomicMax(&box[3], ty1); }
+        if (kind == 2) wholeFrame = 1;
+        __syncthreads();
+        bx0 = wide ? box[0] & ~3 : box[0]; by0 = box[1]; bx1 = box[2]; by1 = box[3];
+    }
     const int rowWords = (bx1 - bx0 + 32) >> 5, rows = by1 - by0 + 1;        // a bitmap row: whole words
     const int words = rowWords * rows;
     if (bx1 >= bx0 && words <= capWords) {                                   // workgroup-uniform
-        for (int w = threadIdx.x; w < words; w += blockDim.x) bits[w] = 0u;
-        __syncthreads();
+        if (!whole) for (int w = threadIdx.x; w < words; w += blockDim.x) bits[w] = 0u;
+        __syncthreads();                                                     // the bitmap is clear
+        if (whole && kind == 2) wholeFrame = 1;
         if (kind == 1) {
             const int a = tx0 - bx0, b = tx1 - bx0;
             for (int wi = a >> 5; wi <= (b >> 5); wi++) {
