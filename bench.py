@@ -596,7 +596,7 @@ def main(argv=None):
                 roofline["achieved"] = round(achieved, 1)
                 roofline["frac"] = round(achieved / VALU_PEAK_GINST, 4)
                 roofline["valu_insts_per_launch"] = int(insts)
-                # The same duration priced two other ways ("Reading frac"): at the issue cost measured for
+                # The same duration priced two other ways (docs/LAB_NOTES.md, "Reading `frac`"): at the issue cost measured for
                 # this loop's instruction mix (tools/ubench/valu_rate*.hip: 2.3-2.6 cycles for the full-rate third, 4.1-4.4 for
                 # the rest), and with round 2's instruction count for the same frame -- frac falls when a change removes
                 # instructions faster than time (the occupancy mask), this one does not.
