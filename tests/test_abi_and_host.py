@@ -90,6 +90,21 @@ def test_product_package_never_touches_the_oracle():
     assert "torch" not in text.lower()
 
 
+def test_shipped_library_reads_no_environment_variable():
+    """A stray RTO_* variable in a user's environment must not change what the library does (round 3 shipped eight A/B knobs and a
+    fault-injection hook read from the environment).  The knobs now exist only in -DRTO_DEV_KNOBS builds (tools/build_variants.sh),
+    test hooks are explicit calls: the shipped librto_hip.so does not even import getenv and holds no RTO_ variable name."""
+    import subprocess
+    path = hip.lib_path()
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined, "librto_hip.so imports getenv"
+    blob = open(path, "rb").read()
+    header = open(os.path.join(ROOT, "include", "rto_hip.h"), "rb").read()
+    api_names = set(re.findall(rb"RTO_[A-Z][A-Z_0-9]*", header))              # constants of the ABI may appear in error messages
+    names = {n for n in set(re.findall(rb"RTO_[A-Z][A-Z_0-9]{3,}", blob)) if not any(n == a or a.startswith(n) or n.startswith(a) for a in api_names)}
+    assert not names, f"environment-variable names in the shipped library: {sorted(names)}"
+
+
 # ---------------------------------------------------------------- host layer vs reference goldens
 @pytest.mark.parametrize("dim", [16, 32])
 def test_host_octree_equals_reference_arrays(golden, dim):
