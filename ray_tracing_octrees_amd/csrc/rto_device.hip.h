@@ -2278,10 +2278,6 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
             alive = !dead && !leaf;
             waiting += __builtin_popcountll(__builtin_amdgcn_ballot_w64(haveLeaf));
             if (waiting >= RTO_TRI_BATCH) break;
-#if defined(RTO_TRI_ADAPT)
-            // A/B: also when few lanes still walk beside many that wait (a trip costs the same whoever walks)
-            if (waiting >= RTO_TRI_ADAPT_MIN && (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(alive)) * RTO_TRI_ADAPT < waiting) break;
-#endif
         }
         rounds++;
         // ---- the waiting lanes' triangles, tested by ALL 64 lanes (S/RT semantics of the pop: it happens only below the
