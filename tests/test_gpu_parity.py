@@ -219,6 +219,10 @@ def test_random_cameras_at_full_size(ctx, orc, scenes, scene):
         for k in range(2):
             grgba, gt = ctx.render_skip_host(f)
         assert gt.tobytes() == nt.tobytes() and grgba.tobytes() == nrgba.tobytes(), f"{scene} seed {seed} ({kind}): nearest-hit mode"
+        cw, cst = orc.render_closest(s.nodes, s.min, s.voxel, view, pos, W / H, fov, W, H, nthreads=min(16, orc.max_threads()))
+        cg, cgs = ctx.render_closest_host(f, stats=True)     # the reference's closest-hit shader (round 4)
+        assert_bit_exact(cg, cw, f"{scene} seed {seed} ({kind}): closest-hit mode")
+        assert (cgs["pops"], cgs["hits"]) == (cst["pops"], cst["hits"]), (scene, seed, kind, "closest-hit counters")
         if tris is not None:
             wt, wst = orc.render_triangles(s.nodes, tris, off, s.min, s.voxel, view, pos, W / H, fov, W, H, shadow=True, nthreads=min(16, orc.max_threads()))
             for k in range(2):                                  # the colour kernel (mask, launch order), then the instrumented one
