@@ -2273,6 +2273,15 @@ static int launch_closest(rto_context* c, const rto_frame* f, const rto_partitio
     if ((rc = order_after_cull(c, s)) != RTO_OK) return rc;
     const int tiles = P.tilesX * P.tilesY;
     if (tiles <= 0) return RTO_OK;
+    // canonical trees without a frustum update in force: the descriptor form (k_closest_lean); RTO_KERNEL_GENERIC keeps the node-by-node form
+    if (c->canonical && c->numInternal > 0 && !c->culling && c->kernelMode != RTO_KERNEL_GENERIC) {
+        const int blocksL = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
+        const size_t lds = (size_t)(kBlock / kWave) * (P.depth + 1) * kWave * sizeof(uint2);
+        if (count) hipLaunchKernelGGL(k_closest_lean<kModeSteps>, dim3(blocksL), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_counters);
+        else hipLaunchKernelGGL(k_closest_lean<kModeColor>, dim3(blocksL), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_counters);
+        RTO_HIP(c, hipGetLastError());
+        return RTO_OK;
+    }
     // with a frustum update in force the traversal runs over the compacted array, as the reference's culled render does (S/RT:765-812)
     if ((rc = ensure_compact(c, s)) != RTO_OK) return rc;
     const rto_node* nodes = c->culling ? c->d_compact : c->d_nodes;

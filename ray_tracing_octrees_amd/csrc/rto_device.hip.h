@@ -1464,6 +1464,85 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     }
 }
 
+// ================================================================ closest-hit kernel on the descriptor tree
+// k_trace_closest's traversal (the reference's earlier shader, S/RT:63-138) for canonical trees: same pop order -- an internal
+// node's children 7 .. 0, a child's whole subtree before its next sibling -- and the same decisions at every pop (the child's own
+// slab test and `tNear >= closestT` with the closestT of THAT moment, S/RT:87-92), so the winner is the reference's in every float
+// corner; but 8 bytes per visited internal node instead of 60 per popped node, the stack in LDS ([level][lane]: pending children
+// | internal mask, first internal child), and empty leaves -- popped upstream to no effect -- never looked at.  One loop trip =
+// one popped child that can matter.  Pops: every entered internal node pushes 8 children and, without an early exit, every one
+// is popped: 1 + 8 x entered (frustum culling removes children: such frames take k_trace_closest over the compacted array).
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_closest_lean(RenderParams P, const uint2* __restrict__ desc, float4* __restrict__ out,
+                                                          Counters* __restrict__ counters) {
+    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;    // entry b = stk[b * 64]: the node whose children have edge 2^b
+    const int tile = blockIdx.x * (kBlock / kWave) + wave;
+    const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+    const int px = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    const bool inImage = valid && (py < P.H);
+    const Geo G = geo_of(P);
+
+    bool hit = false, active = false, enter = false;
+    long long entered = 0;
+    int steps0 = 0;
+    float closestT = 1e30f;                                  // S/RT:66
+    int bx = 0, by = 0, bz = 0, bs = 0;                      // the best leaf so far
+    Ray r;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+    if (inImage && P.rootVisible) {
+        steps0 = 1;                                          // the root's own pop
+        r = generate_ray_tab(P, px, py);
+        float tNear, tFar, a0, a1, a2, a3, a4, a5;
+        active = enter = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= closestT);
+    }
+    unsigned cur = 0, lvlPending = 0;
+    int cx = 0, cy = 0, cz = 0, bpos = P.depth - 1;          // the node to enter: position, log2 of its children's edge
+    while (active) {
+        if (enter) {                                         // S/RT:125-129: the node's children are pushed -- those that can matter, as a mask
+            entered++;
+            const uint2 d = desc[cur];
+            const unsigned fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, cx, cy, cz, 1 << bpos);
+            const unsigned im = (d.x >> 8) & 0xffu;
+            const unsigned cand = ((d.x | im) & 0xffu) & ~fail8;     // solid leaves and internal children whose box the ray meets
+            stk[bpos * kWave] = make_uint2(cand | (im << 8), d.y);
+            lvlPending = cand ? (lvlPending | (1u << bpos)) : (lvlPending & ~(1u << bpos));
+            enter = false;
+        }
+        if (lvlPending == 0) break;                          // S/RT:75: the stack is empty
+        const int Lb = __builtin_ctz(lvlPending);            // the deepest node with children still on the stack: LIFO
+        const uint2 e = stk[Lb * kWave];
+        const int j = 31 - __builtin_clz(e.x & 0xffu);      // children pop 7 .. 0
+        const unsigned bit = 1u << j, left = e.x ^ bit;
+        stk[Lb * kWave].x = left;
+        if ((left & 0xffu) == 0) lvlPending &= ~(1u << Lb);
+        const int h = 1 << Lb, keep = ~(2 * h - 1);
+        const int chx = (cx & keep) + ((j & 1) ? h : 0), chy = (cy & keep) + ((j & 2) ? h : 0), chz = (cz & keep) + ((j & 4) ? h : 0);
+        float tNear, tFar, a0, a1, a2, a3, a4, a5;
+        const bool pass = slab_exact(G, r, chx, chy, chz, h, tNear, tFar, a0, a1, a2, a3, a4, a5);     // S/RT:87-88, at THIS pop
+        if (pass && !(tNear >= closestT)) {                  // S/RT:91-92, with the closestT of this moment
+            const unsigned im = (e.x >> 8) & 0xffu;
+            if (im & bit) {                                  // an internal child: its subtree before the next sibling
+                cur = e.y + (unsigned)__builtin_popcount(im & (bit - 1u));
+                cx = chx; cy = chy; cz = chz; bpos = Lb - 1; enter = true;
+            } else {                                         // a solid leaf, S/RT:96-104 (== :110-118): strictly nearer replaces, no break
+                const float tHit = gmax(0.0f, tNear);
+                if (tHit < closestT && tHit <= tFar) { closestT = tHit; hit = true; bx = chx; by = chy; bz = chz; bs = h; }
+            }
+        }
+    }
+    const float shade = hit ? shade_term(P, G, r, bx, by, bz, bs) : kShadeMiss;
+    if (valid) out[(size_t)ly * P.W + px] = shade_color(shade);
+    if (MODE == kModeSteps) {
+        unsigned long long pops = inImage ? (unsigned long long)(steps0 + 8 * entered) : 0ull, hits = (inImage && hit) ? 1ull : 0ull;
+        for (int off = 32; off > 0; off >>= 1) { pops += __shfl_down(pops, off); hits += __shfl_down(hits, off); }
+        if (lane == 0) { atomicAdd(&counters->pops, pops); atomicAdd(&counters->hits, hits); }
+    }
+}
+
 #ifndef RTO_LEAN_WAVES
 #define RTO_LEAN_WAVES 6
 #endif
