@@ -485,6 +485,9 @@ def main(argv=None):
 
     # ---- timed region: exactly K frames ------------------------------------------------------------
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # torch creates a HIP event at its FIRST record (hipEventCreate: 9-17 us, tools/launch_phases.py --once): record both once here
+    # so that the timed region pays for K frames and two event records, not for creating the bench's own instruments
+    ev_a.record(stream); ev_b.record(stream)
     sync_all()
     t0 = time.perf_counter()
     ev_a.record(stream)

@@ -2278,7 +2278,8 @@ static int launch_closest(rto_context* c, const rto_frame* f, const rto_partitio
         const int blocksL = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
         const size_t lds = (size_t)(kBlock / kWave) * (P.depth + 1) * kWave * sizeof(uint2);
         if (count) hipLaunchKernelGGL(k_closest_lean<kModeSteps>, dim3(blocksL), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_counters);
-        else hipLaunchKernelGGL(k_closest_lean<kModeColor>, dim3(blocksL), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_counters);
+        else if (c->kernelMode == RTO_KERNEL_PACKED_V1) hipLaunchKernelGGL(k_closest_lean<kModeColor>, dim3(blocksL), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_counters);
+        else hipLaunchKernelGGL(k_closest_near_first, dim3(blocksL), dim3(kBlock), lds, s, P, c->d_desc, d_out);
         RTO_HIP(c, hipGetLastError());
         return RTO_OK;
     }

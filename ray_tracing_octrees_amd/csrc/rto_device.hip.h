@@ -1543,6 +1543,109 @@ __global__ __launch_bounds__(kBlock) void k_closest_lean(RenderParams P, const u
     }
 }
 
+// The same winner, near children first.  The exhaustive traversal above ends with the leaf of least tHit among those whose every
+// ancestor passes its own slab test (S/RT:87-88) and `tHit <= tFar`, ties to the leaf popped first: a subtree is cut only when
+// its tNear >= closestT, a child's tNear is never below its parent's (the planes nest and every float step is monotone; a NaN
+// axis the parent's min/max swallow only lowers the parent's tNear), so nothing cut could have replaced the winner.  That set
+// and that order do not depend on the order of the walk: this kernel walks children in ray-sign order (child j ^ flip ascending),
+// finds a near leaf early, cuts on `tNear > best` (a tie must still be looked at) and on tNear >= 1e30 (closestT's start, S/RT:66),
+// and resolves equal tHit by the pop order of the LIFO walk: children pop 7 .. 0, so at the highest level where two leaves' paths
+// part the greater child index pops first.  No pop count comes out of it (kModeSteps launches k_closest_lean).
+__device__ __forceinline__ bool pops_before(int ax, int ay, int az, int bx, int by, int bz) {
+    const unsigned m = (unsigned)((ax ^ bx) | (ay ^ by) | (az ^ bz));
+    if (m == 0) return false;
+    const int top = 31 - __builtin_clz(m);
+    const int ja = ((ax >> top) & 1) | (((ay >> top) & 1) << 1) | (((az >> top) & 1) << 2);
+    const int jb = ((bx >> top) & 1) | (((by >> top) & 1) << 1) | (((bz >> top) & 1) << 2);
+#ifdef RTO_TEST_WRONG_TIE      // tools/build_variants.sh only: the tie test must fail with this
+    return ja < jb;
+#else
+    return ja > jb;
+#endif
+}
+__device__ __forceinline__ unsigned flip_children(unsigned m, unsigned flip) {      // bit i of the result = bit (i ^ flip) of m
+    if (flip & 1u) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+    if (flip & 2u) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+    if (flip & 4u) m = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+    return m;
+}
+__global__ __launch_bounds__(kBlock) void k_closest_near_first(RenderParams P, const uint2* __restrict__ desc, float4* __restrict__ out) {
+    extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;
+    const int tile = blockIdx.x * (kBlock / kWave) + wave;
+    const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+    const int px = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+    const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
+    const int py = global_row(P, ly);
+    const bool inImage = valid && (py < P.H);
+    const Geo G = geo_of(P);
+
+    bool hit = false, active = false, enter = false;
+    float best = 1e30f;
+    int bx = 0, by = 0, bz = 0, bs = 0;
+    unsigned flip = 0;
+    Ray r;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+    if (inImage && P.rootVisible) {
+        r = generate_ray_tab(P, px, py);
+        flip = (r.dx < 0.0f ? 1u : 0u) | (r.dy < 0.0f ? 2u : 0u) | (r.dz < 0.0f ? 4u : 0u);
+        float tNear, tFar, a0, a1, a2, a3, a4, a5;
+        active = enter = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+    }
+    // as in trace_tile_lean: a wave without a non-finite ray takes the 8 verdicts of a node from the select form (no NaN can occur),
+    // and here the cut `tNear > best` rides in its upper clamp (a child passes when max(tNear, eps) <= min(tFar, clamp))
+    const bool risky = active && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
+                                   __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
+    const bool anyRisky = __builtin_amdgcn_ballot_w64(risky) != 0ull;
+    const unsigned sgnX = (unsigned)((int)__float_as_uint(r.ix) >> 31), sgnY = (unsigned)((int)__float_as_uint(r.iy) >> 31),
+                   sgnZ = (unsigned)((int)__float_as_uint(r.iz) >> 31);
+    const float kBelow1e30 = __uint_as_float(0x7149f2c9u);
+    unsigned cur = 0, lvlPending = 0;
+    int cx = 0, cy = 0, cz = 0, bpos = P.depth - 1;
+    while (active) {
+        if (enter) {
+            const uint2 d = desc[cur];
+            unsigned fail8;
+            if (anyRisky) fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, cx, cy, cz, 1 << bpos);
+            else fail8 = child_fail_mask_fast<true, false>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, sgnX, sgnY, sgnZ, cx, cy, cz,
+                                                           (float)(1 << bpos), __uint_as_float(1u), gmax(__uint_as_float(1u), gmin(best, kBelow1e30)));   // never below eps: best may be 0 and a tie at 0 still counts; the pop re-tests exactly
+            const unsigned im = (d.x >> 8) & 0xffu;
+            const unsigned cand = flip_children(((d.x | im) & 0xffu) & ~fail8, flip);      // bit i: child i ^ flip
+            stk[bpos * kWave] = make_uint2(cand | (im << 8), d.y);
+            lvlPending = cand ? (lvlPending | (1u << bpos)) : (lvlPending & ~(1u << bpos));
+            enter = false;
+        }
+        if (lvlPending == 0) break;
+        const int Lb = __builtin_ctz(lvlPending);
+        const uint2 e = stk[Lb * kWave];
+        const int i = __builtin_ctz(e.x & 0xffu);           // the nearest child left: the ray's own octant first
+        const unsigned left = e.x ^ (1u << i);
+        stk[Lb * kWave].x = left;
+        if ((left & 0xffu) == 0) lvlPending &= ~(1u << Lb);
+        const int j = i ^ (int)flip;
+        const unsigned bit = 1u << j;
+        const int h = 1 << Lb, keep = ~(2 * h - 1);
+        const int chx = (cx & keep) + ((j & 1) ? h : 0), chy = (cy & keep) + ((j & 2) ? h : 0), chz = (cz & keep) + ((j & 4) ? h : 0);
+        float tNear, tFar, a0, a1, a2, a3, a4, a5;
+        const bool pass = slab_exact(G, r, chx, chy, chz, h, tNear, tFar, a0, a1, a2, a3, a4, a5);
+        if (pass && !(tNear >= 1e30f) && !(tNear > best)) {
+            const unsigned im = (e.x >> 8) & 0xffu;
+            if (im & bit) {
+                cur = e.y + (unsigned)__builtin_popcount(im & (bit - 1u));
+                cx = chx; cy = chy; cz = chz; bpos = Lb - 1; enter = true;
+            } else {
+                const float tHit = gmax(0.0f, tNear);
+                if (tHit <= tFar && (tHit < best || (hit && tHit == best && pops_before(chx, chy, chz, bx, by, bz)))) {
+                    best = tHit; hit = true; bx = chx; by = chy; bz = chz; bs = h;
+                }
+            }
+        }
+    }
+    const float shade = hit ? shade_term(P, G, r, bx, by, bz, bs) : kShadeMiss;
+    if (valid) out[(size_t)ly * P.W + px] = shade_color(shade);
+}
+
 #ifndef RTO_LEAN_WAVES
 #define RTO_LEAN_WAVES 6
 #endif

@@ -1471,6 +1471,50 @@ def test_closest_hit_mode_at_config2_size_and_with_culling(ctx, orc, scenes, cam
         ctx.update_frustum(view, 45.0, Wc / Hc, enable=False)
 
 
+def test_closest_hit_ties_go_to_the_leaf_popped_first(ctx, orc):
+    """Equal tHit at two leaves: the reference's walk (children pop 7 .. 0, strictly nearer replaces) keeps the one popped first.
+    The near-first kernel (default) resolves the tie by that order without walking it; the pop-order kernel and the node-by-node
+    kernel walk it.  Rays made to tie: unit voxels on integer planes, cameras on integer points looking along axes, face
+    diagonals and body diagonals (an odd frame size puts the centre ray exactly on an edge shared by four leaves, a diagonal
+    ray through corner after corner), a random half-full grid with one merged block so the tied leaves differ in size and state."""
+    rng = np.random.default_rng(2024)
+    n = 16
+    data = (rng.random((n, n, n)) < 0.5).astype(np.uint8)
+    data[4:8, 4:8, 8:12] = 1                                            # one 4^3 leaf
+    data[8:10, 8:10, 8:10] = 0                                          # and a hole at the centre
+    g = orc.Grid((n, n, n), np.zeros(3, np.float32), np.float32(1.0), data)
+    nodes = orc.build_flat_octree(g)
+    ctx.set_kernel(rto.KERNEL_AUTO)
+    ctx.upload_octree(nodes, g.min, g.voxel_size)
+    W = H = 33
+    centre = np.array([8.0, 8.0, 8.0], np.float32)
+    dirs = [d for d in np.ndindex(3, 3, 3) if d != (1, 1, 1)]           # 26 directions: axes, face diagonals, body diagonals
+    differ = 0
+    for d in dirs:
+        off = (np.array(d, np.float32) - 1.0) * np.float32(24.0)
+        pos = centre + off
+        fwd = -off / np.linalg.norm(off)
+        up = np.array([0.0, 1.0, 0.0], np.float32) if abs(fwd[1]) < 0.9 else np.array([0.0, 0.0, 1.0], np.float32)
+        sx = np.cross(fwd, up); sx = sx / np.linalg.norm(sx)
+        uy = np.cross(sx, fwd)
+        view = np.eye(4, dtype=np.float32)                              # column-major, as glm::lookAt lays it out
+        view[0, :3], view[1, :3], view[2, :3] = sx, uy, -fwd
+        view[0, 3], view[1, 3], view[2, 3] = -np.dot(sx, pos), -np.dot(uy, pos), np.dot(fwd, pos)
+        view = np.ascontiguousarray(view.T.astype(np.float32)).reshape(16)
+        for fov in (90.0, 53.13010235415598):                           # tan(fov/2) = 1 and 1/2: pixel directions are small rationals
+            f = rto.make_frame(view, pos, 1.0, fov, W, H)
+            want, wst = orc.render_closest(nodes, g.min, g.voxel_size, view, pos, 1.0, fov, W, H)
+            first, _ = orc.render(nodes, g.min, g.voxel_size, view, pos, 1.0, fov, W, H)
+            differ += int((first.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
+            for kname, kernel in (("near first", rto.KERNEL_AUTO), ("pop order", rto.KERNEL_PACKED_V1), ("node by node", rto.KERNEL_GENERIC)):
+                ctx.set_kernel(kernel)
+                assert_bit_exact(ctx.render_closest_host(f), want, f"closest hit from {tuple(int(x) for x in off)}, fov {fov:.0f}, {kname}")
+            ctx.set_kernel(rto.KERNEL_AUTO)
+            got, st = ctx.render_closest_host(f, stats=True)
+            assert (st["pops"], st["hits"]) == (wst["pops"], wst["hits"])
+    assert differ > 0                                                   # the two shaders do disagree on this grid: the test can see a wrong winner
+
+
 def test_nearest_hit_render_mode_at_config2_size(ctx, orc, scenes, camera):
     """The same at BASELINE config 2's size (256^3 sphere, 1920x1080) against the oracle; where both modes hit, the nearest-hit
     distance never exceeds the distance of the reference's first-in-DFS-order hit (the reason SURVEY.md section 8f wants the mode)."""

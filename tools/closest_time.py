@@ -1,5 +1,6 @@
-"""tools/closest_time.py -- the closest-hit mode (rto_render_closest_*) at config 2's size: kernel time of the descriptor-tree
-form (k_closest_lean) and of the node-by-node form (k_trace_closest, selected by RTO_KERNEL_GENERIC), as wall time over 200 back-to-back launches."""
+"""tools/closest_time.py -- the closest-hit mode (rto_render_closest_*) at config 2's size: time per frame of the near-first
+descriptor-tree form (k_closest_near_first, default), of the pop-order form (k_closest_lean, RTO_KERNEL_PACKED_V1) and of the
+node-by-node form (k_trace_closest, RTO_KERNEL_GENERIC), as wall time over 200 back-to-back launches."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,7 +17,8 @@ W, H = 1920, 1080
 fr = hip.make_frame(cam.getView(), cam.getPos(), W / H, 45.0, W, H)
 out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
 ref = None
-for name, mode in (("descriptor tree", hip.KERNEL_AUTO), ("node by node", hip.KERNEL_GENERIC)):
+for name, mode in (("descriptor tree, near children first", hip.KERNEL_AUTO), ("descriptor tree, the reference's pop order", hip.KERNEL_PACKED_V1),
+                   ("node by node", hip.KERNEL_GENERIC)):
     ctx.set_kernel(mode)
     ts = []
     for i in range(8):
