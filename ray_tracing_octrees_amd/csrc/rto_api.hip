@@ -1338,6 +1338,7 @@ static int mask_parts_max(int path) {
 // path): waves for the tiles of `rect`'s box only, the outside shared out as fill chunks, the box's tiles in the order of
 // the costs earlier frames recorded.  frameMode: a colour / shade frame (records costs); otherwise (instrumentation) the
 // whole image keeps one wave per tile.  On return Q holds the geometry, the table and the cost pointer.
+constexpr int kMovedPeriod = 4;     // a camera in motion: the launch-order table is rebuilt every 4th frame (see prepare_schedule)
 static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool frameMode, bool timelineMode, int path, const int rect[4],
                             RenderParams& Q, rto_context::OrderState** stOut, int maskRegion = -1, bool single = false) {
     const RenderParams& P = Q;
@@ -1429,10 +1430,12 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
         // A rebuild for age alone (same box size: a camera that stands still or only pans) doubles the next interval, up to 8
         // periods: the costs of such frames change slowly, and a build (13 us at config 2) every 8th frame was 4 % of a frame.
         const bool resized = !T.valid || box[2] != T.box[2] || box[3] != T.box[3];
-        // A camera in motion: the costs are stale after ONE frame (the rays that wander along the silhouette are in other tiles every
-        // frame), and with the 16-workgroup sort a rebuild costs ~2.5 us + a launch gap -- less than a stale table does (orbit of 0.01
-        // rad per frame: 32.5 us per frame rebuilt every frame, 36 / 38 / 39 every 2nd / 4th / 8th).  Single-frame launches only: the
-        // frames of a batch share one table.  A camera that stands still backs off as before.
+        // A camera in motion (single-frame launches; the frames of a batch share one table): rebuilt every kMovedPeriod-th frame.  What
+        // a table that is a few frames old gets wrong is not the rank of the tiles with work -- of config 2's 436 tiles of 40 trips
+        // and more, 4 had fewer one frame (0.01 rad) earlier -- but the tiles the moving mask newly covers, which it holds among the
+        // work-less ones at the end; the rim (tile_may_hit) takes care of those.  Orbit of 0.01 rad per frame, us per frame, table
+        // rebuilt every 1st / 4th / 8th frame: 38.6 / 36.4 / 36.4 with the rim, 40.5 / 38.5 / 38.6 without; a build is 4.7 us + a
+        // launch gap.  A camera that stands still backs off as before.
         bool moved = false;
         if (single && frameMode) {
             float cam[19];
@@ -1440,6 +1443,8 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
             moved = o->haveCam && std::memcmp(cam, o->lastCam, sizeof cam) != 0;
             std::memcpy(o->lastCam, cam, sizeof cam); o->haveCam = true;
         }
+        static const int movedPeriod = (int)dev_env("RTO_ORDER_MOVED_PERIOD", kMovedPeriod);   // A/B knob (dev builds)
+        if (moved && T.valid && T.age < movedPeriod) moved = false;
         if (!fixedOrder && Q.traceWaves > 0 && (resized || moved || T.age >= c->orderPeriod * T.stretch)) {
             T.stretch = (resized || moved) ? 1 : std::min(T.stretch * 2, 8);
             if (o->costValid) {

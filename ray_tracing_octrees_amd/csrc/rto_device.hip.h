@@ -119,6 +119,7 @@ struct RenderParams {
     float maskInvAspTan, maskInvTanH;   // 1 / (aspect * tan(fov/2)), 1 / tan(fov/2)
     float viewRows[12];             // rows 0..2 of the view matrix
 };
+constexpr int kRimTiles = 2;            // see the cost record of trace_tile_lean
 constexpr int kMaskTrustSlots = 1024;   // the first launch slots (the costliest tiles of the previous frame) never consult the mask
 
 // ---------------------------------------------------------------- scalar helpers
@@ -638,7 +639,15 @@ __device__ __forceinline__ bool resolve_slot(const RenderParams& P, int slot, in
 // anyway) do not even look, a later wave looks only once the "complete" word carries this frame's stamp and otherwise walks
 // its tile as if there were no mask.  Tiles without work sort to the END of the launch order, and by the time their waves
 // start the mask is long complete.  Agent-scope loads: the words were written by other workgroups, possibly on another XCD.
-__device__ __forceinline__ bool tile_may_hit(const RenderParams& P, int tx, int ty, int slot) {
+//
+// The rim.  A tile the mask does not cover records its cost for the launch order right here: 0, or -1 when the mask covers a
+// tile within kRimTiles tiles of it -- the rim of the silhouette, where a camera in motion finds work a frame or a few later;
+// k_order_build ranks such tiles ahead of the certainly empty ones.  Without the rim the tiles a moving mask newly covers
+// (12-14 trips, 6 us each) start among the ~8,000 work-less tiles at the very end of the launch and end the frame alone
+// (config 2, a camera 0.01 rad from the one the costs come from: 36.8 us against 33.8; tools/timeline_simd.py learn=).
+// It costs no extra round trip: the look-up is ONE load either way -- lane k reads the k-th word of the (2 kRimTiles + 1)^2
+// neighbourhood, every other lane the "whole frame" word -- where it used to be two loads of one word each.
+__device__ __forceinline__ bool tile_may_hit(const RenderParams& P, int tx, int ty, int slot, int lane = -1, int tile = 0) {
     if (!P.tileMask || ty >= P.tilesY || slot < P.maskTrustSlots) return true;
     if (__hip_atomic_load(P.tileMask + P.maskAllIndex + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.maskStamp) return true;   // not complete (yet)
     asm volatile("" ::: "memory");                             // the loads below are issued after this poll has matched, never hoisted above it
@@ -646,8 +655,17 @@ __device__ __forceinline__ bool tile_may_hit(const RenderParams& P, int tx, int 
     // agent-scope loads themselves (they do not read this CU's or this XCD's stale lines) and are issued after the branch on
     // the load above has resolved; the words they read were stored, and released, before the "complete" word.
     const int strip = global_row(P, ty * 8) >> 3;
-    return __hip_atomic_load(P.tileMask + strip * P.tilesX + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp ||
-           __hip_atomic_load(P.tileMask + P.maskAllIndex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp;
+    if (lane < 0)
+        return __hip_atomic_load(P.tileMask + strip * P.tilesX + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp ||
+               __hip_atomic_load(P.tileMask + P.maskAllIndex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp;
+    constexpr int kSide = 2 * kRimTiles + 1, kCentre = kRimTiles * kSide + kRimTiles;
+    const int ns = strip + lane / kSide - kRimTiles, nx = tx + lane % kSide - kRimTiles;
+    const bool inside = lane < kSide * kSide && nx >= 0 && nx < P.tilesX && ns >= 0 && ns < ((P.H + 7) >> 3);
+    const bool on = __hip_atomic_load(P.tileMask + (inside ? ns * P.tilesX + nx : P.maskAllIndex), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.maskStamp;
+    const unsigned long long seen = __builtin_amdgcn_ballot_w64(on);
+    const bool live = ((seen >> kCentre) & 1ull) != 0ull || (seen >> 63) != 0ull;      // lane 63 always reads the "whole frame" word
+    if (!live && P.tileCost && lane == 0) P.tileCost[tile] = (seen & ((1ull << (kSide * kSide)) - 1ull)) ? -1 : 0;
+    return live;
 }
 
 // Wave64 inclusive scans in registers (gfx9 DPP: shifts inside the rows of 16 lanes, then the two row broadcasts), no LDS
@@ -1325,7 +1343,7 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
         startVisible = st.visible; startShift = st.shift; startSize = 1 << st.shift; startX = st.x; startY = st.y; startZ = st.z;
         startDesc = st.desc; startLeaf = st.leaf != 0; startSolid = st.solid != 0;
     }
-    const bool tileLive = tile_may_hit(P, tx, ty, slot);                // wave-uniform
+    const bool tileLive = tile_may_hit(P, tx, ty, slot, lane, tile);    // wave-uniform
     if (inImage && startVisible && tileLive) {
         steps0 = 1;
         if (!outsideRoot) {
@@ -1413,9 +1431,9 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     // alone -- what was recorded until round 3 -- underrates every tile whose costly rays are not in its top-left corner)
     if (P.tileCost || MODE == kModeTimeline) {
         trips = __builtin_amdgcn_readlane(wave_scan_max_nonneg(trips), kWave - 1);
-        // -1: no trip, but the occupancy mask said geometry may project here -- the rim of the silhouette, where a camera in
-        // motion finds work a few frames later (k_order_build ranks such tiles ahead of the certainly empty ones)
-        if (P.tileCost && lane == 0 && ty < P.tilesY) P.tileCost[tile] = (trips == 0 && tileLive && P.tileMask) ? -1 : trips;
+        // -1: no trip, but the occupancy mask said geometry may project here (a tile the mask does not cover recorded its cost when it
+        // looked the mask up: see tile_may_hit)
+        if (P.tileCost && lane == 0 && ty < P.tilesY && tileLive) P.tileCost[tile] = (trips == 0 && P.tileMask) ? -1 : trips;
     }
     const int leafShift = bpos + 1;                                      // on a hit: log2 of the leaf's edge
     cx &= 0x7fffff; cy &= 0x7fffff; cz &= 0x7fffff;                      // plain coordinates for the epilogue
@@ -2370,7 +2388,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     bool hitPrimary = false;
     Ray r;
     bool alive = false;            // walking the tree
-    const bool tileLive = tile_may_hit(P, tx, ty, slot);     // the occupancy mask (colour / shade frames): wave-uniform
+    const bool tileLive = tile_may_hit(P, tx, ty, slot, lane, tile);     // the occupancy mask (colour / shade frames): wave-uniform; a tile outside it records its cost there
     if (inImage && tileLive) {
         stepsTotal = 1;            // the root's own pop of the primary ray
         if (!outside) {
@@ -2612,7 +2630,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
         int cost = trips;
         for (int off = 32; off > 0; off >>= 1) cost = max(cost, __shfl_xor(cost, off));
         cost += 3 * rounds + chunks;
-        if (lane == 0 && ty < P.tilesY) P.tileCost[tile] = cost >> 3;
+        if (lane == 0 && ty < P.tilesY && tileLive) P.tileCost[tile] = cost >> 3;
     }
     if (valid && !(P.skipOutside && outside)) {
         if (SHADE) __builtin_nontemporal_store(shade, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);

@@ -15,8 +15,15 @@ cam = rto.Camera(theta, 0.7, 1.8)
 f = rto.make_frame(cam.getView(), cam.getPos(), W / H, 45.0, W, H)
 if "nomask" in sys.argv:
     ctx.debug_set_tile_mask(False)
-for _ in range(12):
-    ctx.render_host(f)
+learn = next((float(a.split("=")[1]) for a in sys.argv if a.startswith("learn=")), None)    # learn=<theta>: the launch-order table comes from THAT camera's costs
+if learn is not None:
+    camL = rto.Camera(learn, 0.7, 1.8)
+    fL = rto.make_frame(camL.getView(), camL.getPos(), W / H, 45.0, W, H)
+    for _ in range(12):
+        ctx.render_host(fL)
+else:
+    for _ in range(12):
+        ctx.render_host(f)
 rec = ctx.debug_timeline(f)
 rec = ctx.debug_timeline(f)
 tiles = np.arange(len(rec))
@@ -50,6 +57,15 @@ for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 48), (48, 80)):
     m = first & (it >= lo) & (it < hi)
     if m.any():
         print(f"  iters [{lo},{hi}): {m.sum():5d} waves, duration mean {(e - s)[m].mean():6.2f} p90 {np.percentile((e - s)[m], 90):6.2f} max {(e - s)[m].max():6.2f}")
+if "brief" in sys.argv:
+    late = np.argsort(-e)[:12]
+    print("the 12 waves that end last:")
+    for i in late:
+        print(f"    slot {slot[i]:5d} tile ({tiles[i] % tx:3d},{tiles[i] // tx:3d}) start {s[i]:6.2f} end {e[i]:6.2f} iters {it[i]:3d}")
+    for lo, hi in ((0, 1024), (1024, 2048), (2048, 4096), (4096, 6144), (6144, 20000)):
+        m = (slot >= lo) & (slot < hi)
+        if m.any(): print(f"  slots [{lo},{hi}): start mean {s[m].mean():6.2f} max {s[m].max():6.2f}, iters mean {it[m].mean():5.1f} max {it[m].max()}, end max {e[m].max():6.2f}")
+    sys.exit(0)
 # where the dispatcher put the first workgroups: slot -> (xcc, se, sh, cu, simd, wave_id)
 o = np.argsort(slot)
 print("slot -> xcc se sh cu simd wave | start us  (first 48 slots, then every 256th)")
