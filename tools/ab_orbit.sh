@@ -1,16 +1,9 @@
 #!/bin/bash
-# tools/ab_orbit.sh -- on the GPU box: static frame and orbit leg of the bench for the in-tree library and every A/B build under build/variants/
+# tools/ab_orbit.sh [LIB...] -- on the GPU box: standing frame, orbit leg and the orbit with 4 cameras per launch for the in-tree library and the given A/B builds, two rounds
 R=$(cd "$(dirname "$0")/.." && pwd); cd "$R"
-run() {
-  RTO_HIP_LIB=$2 python3 bench.py --steps 400 --warmup 20 --cpu-frames 0 --dropin-frames 0 --frames-per-launch 1 --orbit-frames 240 2>&1 | tail -1 | python3 -c "
+for rep in 1 2; do for lib in "" "$@"; do
+  RTO_HIP_LIB=${lib:+$R/$lib} python3 bench.py --steps 400 --warmup 20 --cpu-frames 0 --dropin-frames 0 --no-verify --orbit-frames 240 2>/dev/null | tail -1 | python3 -c "
 import json,sys
-t=sys.stdin.read()
-try:
-    j=json.loads(t); o=j.get('orbit') or {}
-    print('%-10s static %.5f orbit %.5f verified=%s' % ('$1', j['ms_per_step'], o.get('ms_per_frame', 0), j.get('verified_against_oracle')), flush=True)
-except Exception: print('$1 FAILED', t[-300:])"
-}
-for rep in 1 2; do
-run base ""
-for f in build/variants/librto_hip_*.so; do n=$(basename "$f" .so); run "${n#librto_hip_}" "$R/$f"; done
-done
+j=json.loads(sys.stdin.read()); o=j.get('orbit') or {}
+print('%-36s static %.5f orbit %.5f, 4 cameras per launch %.5f; standing, 4 per launch %.5f' % ('${lib:-in-tree}', j['ms_per_step'], o.get('ms_per_frame', 0), (o.get('frames_per_launch') or {}).get('ms_per_frame', 0), (j.get('frames_per_launch') or {}).get('ms_per_frame', 0)), flush=True)"
+done; done
