@@ -708,6 +708,43 @@ def test_occupancy_mask_never_changes_pixels_and_removes_work(ctx, orc, scenes):
     ctx.debug_set_tile_mask(1)
 
 
+def test_work_less_tiles_next_to_work_are_marked_for_the_launch_order(ctx, orc, scenes):
+    """The rim (tile_may_hit): a tile outside the occupancy mask records cost -1 instead of 0 when the mask covers a tile within two
+    tiles of it, and k_order_build starts such tiles ahead of the certainly empty ones -- where a camera in motion finds its new
+    work.  Mask mode 2 (complete before the frame): every tile within two tiles of a tile whose wave walked has a non-zero cost,
+    far tiles keep 0, the table stays a permutation, and frames of a camera that moves on stay bit-exact."""
+    s = scenes("sphere64")
+    upload(ctx, s)
+    W, H = 1280, 720
+    tX, tY = W // 8, H // 8
+    try:
+        ctx.debug_set_tile_mask(2)
+        cams = [orc.Camera(0.5 + 0.02 * i, 0.7, 2.2) for i in range(6)]
+        for i, cam in enumerate(cams):
+            view, pos = cam.get_view(), cam.get_pos()
+            f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+            want, _ = oracle_frame(orc, s, view, pos, W, H)
+            assert_bit_exact(ctx.render_host(f), want, f"camera {i} of a moving sequence")
+            assert ctx.debug_sort_violations() == 0
+            cost = ctx.debug_tile_cost().reshape(tY, tX)
+            walked = cost > 0
+            assert walked.any()
+            near = np.zeros_like(walked)
+            ys, xs = np.nonzero(walked)
+            for dy in range(-2, 3):
+                for dx in range(-2, 3):
+                    yy, xx = np.clip(ys + dy, 0, tY - 1), np.clip(xs + dx, 0, tX - 1)
+                    near[yy, xx] = True
+            # inside the launch box every tile's cost was written by this frame; the box contains the walked tiles' neighbourhood
+            # except where it ends: compare inside the walked tiles' own bounding box
+            y0, y1, x0, x1 = ys.min(), ys.max(), xs.min(), xs.max()
+            inner = np.zeros_like(walked); inner[y0:y1 + 1, x0:x1 + 1] = True
+            assert (cost[near & inner] != 0).all(), f"camera {i}: a tile next to work recorded cost 0"
+            assert ((cost == -1) & inner).any(), f"camera {i}: no rim tile at all"
+    finally:
+        ctx.debug_set_tile_mask(1)
+
+
 def test_persistent_kernel_in_a_graph_with_an_odd_frame_count(ctx, orc, scenes):
     """The persistent-threads kernel takes launch slots from a global counter; every launch zeroes its own counter with a
     memset node, so a captured sequence of ANY length replays exactly (an odd number of frames used to leave the next
