@@ -351,9 +351,12 @@ int  rto_octree_ray_skip(rto_context* ctx, const float ro[3], const float* rd, i
  * (replaced by the "workload limiting" shader rto_render_device implements), the only traversal rule of the reference this library
  * could not render until round 4.  Pixels are bit-identical to that shader's text compiled under the reference's glm
  * (oracle/glsl_driver.cpp, tests/golden/glsl_images_small.npz).  RGBA32F, row 0 = top, asynchronous on hip_stream; part as in
- * rto_render_device; a frustum update in force is honoured the way the reference's culled render is (compacted array).  Stated
- * node by node over the 60-byte array (k_trace_closest): correct by construction, not tuned.  _host: synchronous; stats (may be
- * NULL): rays, popped nodes (uncapped), hit pixels. */
+ * rto_render_device; a frustum update in force is honoured the way the reference's culled render is (compacted array).  Three
+ * kernels, one frame: canonical trees walk the descriptor tree near children first (k_closest_near_first: the winner of the
+ * exhaustive walk is the leaf of least tHit among those whose ancestors all pass their slab tests, ties to the leaf popped
+ * first, whatever the order of the walk); the counters come from the same pops made in the reference's order
+ * (k_closest_lean); arbitrary arrays, culled frames and RTO_KERNEL_GENERIC go node by node over the 60-byte array
+ * (k_trace_closest).  _host: synchronous; stats (may be NULL): rays, popped nodes (uncapped), hit pixels. */
 int  rto_render_closest_device(rto_context* ctx, const rto_frame* frame, const rto_partition* part /* NULL = whole frame */, void* d_rgba, void* hip_stream);
 int  rto_render_closest_host(rto_context* ctx, const rto_frame* frame, float* host_rgba, rto_stats* stats /* may be NULL */);
 
