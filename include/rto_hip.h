@@ -151,6 +151,12 @@ int  rto_update_frustum(rto_context* ctx, const float view[16], float fov_deg, f
  * normalised) and margin instead of the ones S/RT:731-755 derives -- lets a test build situations real cameras cannot,
  * e.g. a culled root with surviving descendants (S/RT:765-812 then starts at whatever lands at compacted index 0). */
 int  rto_debug_update_frustum_planes(rto_context* ctx, const float planes[24], float margin);
+/* rto_update_frustum first asks, on the host, whether the planes can cull ANY node: every box lies in the root's, so a lower
+ * bound of the positive-vertex value over all nodes is one expression per plane; when it exceeds the float evaluation's
+ * possible error a thousandfold for all six planes -- with the reference's margin of 150 units: every camera near a scene a
+ * few units across -- every node is visible, the device state that says so is written once and further such updates launch
+ * NOTHING (identical results, S/RT:743-802's loop passes every node as well).  enabled = 0 forces the kernel (A/B, tests). */
+int  rto_debug_set_frustum_shortcut(rto_context* ctx, int enabled);
 /* Copies the compacted array (== m_visibleNodes, S/RayTracerBVH.cpp:775-802) to the host for parity
  * checks.  out may be NULL to query the count only. */
 int  rto_download_visible_nodes(rto_context* ctx, rto_node* out, int64_t capacity, int64_t* count);

@@ -59,6 +59,8 @@ struct rto_context {
     int* d_cullBlockFirst = nullptr;
     StartState* d_start = nullptr;
     bool cullAsync = false;          // the flags in force come from k_cull_desc
+    bool visAllOnes = false;         // d_vis, the descriptors' visibility bits and d_start say "every node visible" (rto_update_frustum's host-side proof left them so)
+    bool cullShortcut = true;        // rto_debug_set_frustum_shortcut
     bool cullStateStale = false;     // rootVisible / visibleNodes below are older than d_start
     bool cullCaptured = false;       // an update was stream-captured: replays change d_start behind the host's back
     hipEvent_t evCull = nullptr;     // recorded on c->stream behind the last kernel that rewrote the visibility state (descriptor bits, d_vis,
@@ -185,7 +187,7 @@ extern "C" int rto_debug_fault_alloc(long k) { g_faultCountdown = k > 0 ? k : 0;
 static void free_cull_buffers(rto_context* c) {
     (void)hipFree(c->d_cullBlockCount); c->d_cullBlockCount = nullptr;
     (void)hipFree(c->d_cullBlockFirst); c->d_cullBlockFirst = nullptr;
-    c->cullAsync = false; c->cullStateStale = false; c->cullCaptured = false;
+    c->cullAsync = false; c->cullStateStale = false; c->cullCaptured = false; c->visAllOnes = false;
     (void)hipFree(c->d_vis); c->d_vis = nullptr;
     (void)hipFree(c->d_remap); c->d_remap = nullptr;
     (void)hipFree(c->d_blockCount); c->d_blockCount = nullptr;
@@ -956,6 +958,33 @@ static int ensure_compact(rto_context* c, hipStream_t s) {
     return RTO_OK;
 }
 
+// Is every node of the tree visible under these planes, by a margin no float rounding can close?  Frustum::testAABB's
+// positive-vertex test (node_visible) culls a node when (n . p) + d < 0 for one plane, p the corner of the node's box -- widened by
+// `margin` -- farthest along n.  Every node's box lies inside the root's [g, g + rootSize vs]: per axis the p-vertex coordinate is at
+// least g + margin where n > 0 and at most g + rootSize vs - margin where n < 0, so
+//     L = sum_a (n_a > 0 ? n_a (g_a + margin) : n_a (g_a + rootSize vs - margin)) + d
+// bounds every node's value from below (exact arithmetic).  The device evaluates the value with ~10 float operations on terms of
+// magnitude M = sum_a |n_a| (|g_a| + rootSize vs + margin) + |d|: its rounding error is below 1e-6 M; L >= 1e-3 M for all six planes
+// therefore proves that k_cull_desc would flag EVERY node visible.  With the reference's margin of 150 units (S/RT:755) that is
+// the case for every camera near a scene a few units across (config 2: L ~ 148 against M ~ 260) -- the reference's CPU loop then
+// passes every node too, every frame.
+static bool every_node_visible(const rto_context* c, const float planes[24], float margin) {
+    const double span = (double)c->rootSize * (double)c->voxelSize;
+    if (!(margin >= 0.0f) || !std::isfinite(span)) return false;
+    for (int i = 0; i < 6; i++) {
+        const float* pl = planes + 4 * i;
+        double L = (double)pl[3], M = std::fabs((double)pl[3]);
+        for (int a = 0; a < 3; a++) {
+            const double n = (double)pl[a], g = (double)c->gridMin[a];
+            if (!std::isfinite(n) || !std::isfinite(g)) return false;
+            L += n > 0.0 ? n * (g + (double)margin) : n * (g + span - (double)margin);
+            M += std::fabs(n) * (std::fabs(g) + span + (double)margin);
+        }
+        if (!std::isfinite(L) || !std::isfinite(M) || !(L >= 1e-3 * M)) return false;
+    }
+    return true;
+}
+
 static int update_frustum_planes(rto_context* c, const float planes[24], float margin) {
     const int64_t n = c->numNodes;
     const int nb = (int)((n + kBlock - 1) / kBlock);
@@ -990,6 +1019,23 @@ static int update_frustum_planes(rto_context* c, const float planes[24], float m
     // it -- rto_download_visible_nodes, the generic kernel: ensure_compact().  The packed kernels render from the visibility
     // bits in the descriptors, which is all a frustum update has to refresh for them.
     c->compactValid = false;
+    if (canon && c->cullShortcut && !capturing && !c->cullCaptured && every_node_visible(c, planes, margin)) {
+        // Proven on the host: the update flags every node.  The device state that says so is written once; while it stands, an
+        // update launches nothing at all.
+        if (!c->visAllOnes) {
+            RTO_HIP(c, hipMemsetAsync(c->d_vis, 1, (size_t)n, c->stream));
+            hipLaunchKernelGGL(k_desc_visall, dim3((unsigned)((c->numInternal + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->numInternal, c->d_desc);
+            hipLaunchKernelGGL(k_start_at_root, dim3(1), dim3(1), 0, c->stream, c->d_start, c->depth, (long long)n);
+            RTO_HIP(c, hipGetLastError());
+            c->visAllOnes = true;
+            const int rcEv = cull_state_written(c);
+            if (rcEv != RTO_OK) return rcEv;
+        }
+        c->culling = true; c->cullAsync = true; c->cullStateStale = false;
+        c->rootVisible = 1; c->visibleNodes = n;
+        return RTO_OK;
+    }
+    c->visAllOnes = false;
     if (canon) {
         // one launch, nothing read back, capturable: flags, descriptor masks, and -- on the device -- where traversals start
         hipLaunchKernelGGL(k_cull_desc, dim3(nbInt), dim3(kBlock), 0, c->stream, C, c->d_descPos, c->d_descFirstChild, c->d_nodes, c->numInternal, c->depth,
@@ -1031,6 +1077,7 @@ int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, floa
             if (rcEv != RTO_OK) return rcEv;
         }
         c->culling = false; c->cullAsync = false; c->cullStateStale = false; c->rootVisible = 1; c->visibleNodes = c->numNodes;
+        c->visAllOnes = false;              // d_start / d_vis are not maintained while culling is off
         return RTO_OK;
     }
     if (!view) return fail(c, RTO_E_INVALID, "rto_update_frustum: view is NULL");
@@ -1040,6 +1087,13 @@ int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, floa
     rtmath::mat4 vp = proj * rtmath::mat4::from(view);
     rtmath::frustum_planes(vp, planes);
     return update_frustum_planes(c, planes, 150.0f);
+}
+
+int rto_debug_set_frustum_shortcut(rto_context* c, int enabled) {
+    if (!c) return RTO_E_INVALID;
+    c->cullShortcut = enabled != 0;
+    if (!c->cullShortcut) c->visAllOnes = false;
+    return RTO_OK;
 }
 
 int rto_debug_update_frustum_planes(rto_context* c, const float planes[24], float margin) {

@@ -1865,6 +1865,16 @@ __global__ __launch_bounds__(kBlock) void k_desc_pos(const rto_node* __restrict_
     descPos[d] = make_int4(c0->x, c0->y, c0->z, c0->size * 2);
 }
 
+// what k_cull_desc leaves when every node is visible (rto_update_frustum's host-side proof): traversals start at the root
+__global__ void k_start_at_root(StartState* __restrict__ start, int depth, long long visibleCount) {
+    StartState st;
+    st.visible = 1; st.desc = 0; st.x = st.y = st.z = 0; st.shift = depth; st.leaf = 0; st.solid = 0;
+    st.rootVisible = 1; st.firstVisible = 0;
+    st.visibleCount = visibleCount;
+    st.ticket = 0;
+    *start = st;
+}
+
 // The whole frustum update of a canonical tree in ONE launch, nothing read back (rto_update_frustum): thread d tests the 8
 // children of internal node d (every node but the root is the child of exactly one internal node; thread 0 adds the root) with
 // the same float operations as k_cull_flags on the same integer coordinates -- positions come from descPos (16 B per internal

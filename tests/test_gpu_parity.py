@@ -446,6 +446,48 @@ def test_frustum_update_equals_reference_compaction(ctx, orc, scenes, camera, ca
         assert_bit_exact(ctx.render_host(f2), full, f"culling off {kname}")
 
 
+def test_frustum_update_proven_on_the_host_equals_the_kernel(ctx, orc, scenes):
+    """rto_update_frustum asks the host first whether the planes can cull any node at all (a lower bound of the positive-vertex
+    value over every box inside the root's, a thousandfold above the float evaluation's error); when not, it writes the "every node
+    visible" state once and launches nothing.  Same outcome as the kernel, which the debug switch forces: survivors (all nodes,
+    == the oracle's compaction), frames, counters -- for cameras around a small scene (the reference's 150-unit margin: proven),
+    across an interleaved culling update with planes that DO cull (custom planes, margin 0: not proven), and back."""
+    s = scenes("sphere64")
+    upload(ctx, s)
+    W, H = 320, 200
+    aspect = W / H
+    n = len(s.nodes)
+    try:
+        for i, cam in enumerate((orc.Camera(0.5, 0.7, 1.8), orc.Camera(2.1, -0.4, 0.9), orc.Camera(0.0, 1.5, 6.0))):
+            view, pos = cam.get_view(), cam.get_pos()
+            want_nodes, vis = orc.cull_compact(s.nodes, s.min, s.voxel, view, 45.0, aspect)
+            assert len(want_nodes) == n                           # the reference's loop passes every node here
+            f = rto.make_frame(view, pos, aspect, 45.0, W, H)
+            want, st = orc.render(want_nodes, s.min, s.voxel, view, pos, aspect, 45.0, W, H)
+            outs = []
+            for shortcut in (True, False, True):
+                ctx.debug_set_frustum_shortcut(shortcut)
+                ctx.update_frustum(view, 45.0, aspect, enable=True)
+                ctx.update_frustum(view, 45.0, aspect, enable=True)          # a second update in the same state
+                assert ctx.info().culling_active == 1 and ctx.info().visible_nodes == n
+                assert ctx.download_visible_nodes().tobytes() == want_nodes.tobytes()
+                assert_bit_exact(ctx.render_host(f), want, f"camera {i}, host-side proof {'on' if shortcut else 'off'}")
+                gs = ctx.frame_stats(f)
+                assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"])
+                t = ctx.octree_ray_skip(pos, np.array([[0, 0, -1], [0.2, -0.3, -0.9], [-0.5, 0.1, -0.8], [0.1, 0.1, -1]], np.float32),
+                                        use_visibility=True)
+                outs.append(t.tobytes())
+            assert outs[0] == outs[1] == outs[2]
+            # an update that does cull, in between: a plane through the middle of the grid, no margin
+            planes = np.array([[1, 0, 0, 0.1], [-1, 0, 0, 50], [0, 1, 0, 50], [0, -1, 0, 50], [0, 0, 1, 50], [0, 0, -1, 50]], np.float32)
+            ctx.debug_set_frustum_shortcut(True)
+            ctx.debug_update_frustum_planes(planes, 0.0)
+            assert 0 < ctx.info().visible_nodes < n
+    finally:
+        ctx.debug_set_frustum_shortcut(True)
+        ctx.update_frustum(np.eye(4, dtype=np.float32).reshape(16), 45.0, aspect, enable=False)
+
+
 @pytest.mark.parametrize("first_survivor", ["solid leaf", "internal node"])
 def test_culled_root_with_surviving_descendants_follows_the_reference(ctx, orc, first_survivor):
     """A7, literally (RayTracerBVH.cpp:765-812): when the frustum test drops the ROOT but keeps descendants, the reference's
