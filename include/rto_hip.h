@@ -145,7 +145,8 @@ int  rto_forget_stream(rto_context* ctx, void* hip_stream);
  * device).  The compacted array itself is made when somebody needs it (rto_download_visible_nodes, the generic kernel).
  * Ordering: frames on the context's own stream are ordered around the update by the stream; if frames were launched on other
  * streams since the last update (or ever captured on one), the device is waited for first.  Other arrays: per-node test,
- * one read-back (synchronous). */
+ * one read-back (synchronous).  Before any of that the host asks whether the planes can cull a node at all (see
+ * rto_debug_set_frustum_shortcut): when provably not, nothing is launched. */
 int  rto_update_frustum(rto_context* ctx, const float view[16], float fov_deg, float aspect, int enable);
 /* Developer aid: the same update with caller-supplied planes (LEFT, RIGHT, TOP, BOTTOM, NEAR, FAR as nx, ny, nz, d;
  * normalised) and margin instead of the ones S/RT:731-755 derives -- lets a test build situations real cameras cannot,
