@@ -691,7 +691,8 @@ def main(argv=None):
                 torch.cuda.synchronize()
                 wall = time.perf_counter() - t_o
                 orbit = {"frames": n_orbit, "rad_per_frame": 0.01, "launches": "plain stream launches, one per frame; launch-order table rebuilt when the geometry's tile box "
-                         f"changes size, every 4th frame of a camera in motion and at least every {args.order_period}-th frame (k_order_build inside the timed sequence)",
+                         f"changes size, every 4th frame of a camera in motion and at least every {args.order_period}-th frame (k_order_build inside the timed sequence); "
+                         f"untimed before it: the same orbit round and round for {args.ramp_ms:.0f} ms (clock ramp, as before the headline's region)",
                          "ms_per_frame": round(wall / n_orbit * 1e3, 5), "gpu_ms_per_frame": round(ea.elapsed_time(eb) / n_orbit, 5),
                          "Mrays_per_s": round(rays * n_orbit / wall / 1e6, 1)}
                 if not args.no_verify:
@@ -769,7 +770,7 @@ def main(argv=None):
                       "ms_per_call_without_update": legs["no_update"], "calls": args.dropin_frames,
                       "Mrays_per_s": round(rays / legs["update_every_frame"] / 1e3, 1), "frame_equals_timed_frame": bool(dropin_ok),
                       "what": "C++ RayTracerBVH::renderSceneComputeWithCulling(camera, W, H, aspect, 45, updateFrustum=true) per frame, as main.cpp:1357-1363 calls it "
-                              "(plain launches, host never waits inside the loop); median of 3 runs.  ms_per_call: the library as shipped -- at this scene "
+                              "(plain launches, host never waits inside the loop); median of 3 runs after an untimed clock ramp of the same calls.  ms_per_call: the library as shipped -- at this scene "
                               "rto_update_frustum proves on the host that the reference's 150-unit margin lets no node be culled and launches nothing; "
                               "ms_per_call_update_kernel_forced: the same call with that proof switched off (k_cull_desc tests every node every frame)"}
             del rt
