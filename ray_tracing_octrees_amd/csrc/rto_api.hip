@@ -2338,7 +2338,16 @@ static int launch_closest(rto_context* c, const rto_frame* f, const rto_partitio
         const size_t lds = (size_t)(kBlock / kWave) * (P.depth + 1) * kWave * sizeof(uint2);
         if (count) hipLaunchKernelGGL(k_closest_lean<kModeSteps>, dim3(blocksL), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_counters);
         else if (c->kernelMode == RTO_KERNEL_PACKED_V1) hipLaunchKernelGGL(k_closest_lean<kModeColor>, dim3(blocksL), dim3(kBlock), lds, s, P, c->d_desc, d_out, c->d_counters);
-        else hipLaunchKernelGGL(k_closest_near_first, dim3(blocksL), dim3(kBlock), lds, s, P, c->d_desc, d_out);
+        else {
+            // launch geometry, launch order and occupancy mask of the first-hit frames (path 3: tables of its own kind on the stream)
+            rto_context::OrderState* st = nullptr;
+            const int solidRect[4] = { P.solidX0, P.solidY0, P.solidX1, P.solidY1 };
+            if ((rc = prepare_schedule(c, s, stream_is_capturing(s), true, false, 3, solidRect, P, &st, 0, true)) != RTO_OK) return rc;
+            P.maskLdsBytes = (int)lds;
+            const int blocksN = (P.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave) + P.maskBlocks;
+            if (c->maskMode == 2 && P.maskBlocks > 0) hipLaunchKernelGGL(k_closest_near_first, dim3(P.maskBlocks), dim3(kBlock), lds, s, P, c->d_desc, d_out);
+            hipLaunchKernelGGL(k_closest_near_first, dim3(blocksN), dim3(kBlock), lds, s, P, c->d_desc, d_out);
+        }
         RTO_HIP(c, hipGetLastError());
         return RTO_OK;
     }

@@ -1590,13 +1590,21 @@ __device__ __forceinline__ unsigned flip_children(unsigned m, unsigned flip) {  
 __global__ __launch_bounds__(kBlock) void k_closest_near_first(RenderParams P, const uint2* __restrict__ desc, float4* __restrict__ out) {
     extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // launch geometry of the lean kernels: the first workgroups build the occupancy mask (a tile no solid leaf projects into holds no
+    // hit under this rule either), waves only for the tiles of the solid geometry's screen rectangle in the stream's launch order,
+    // wide stores for the rest
+    if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x, reinterpret_cast<unsigned*>(lds_stack), P.maskLdsBytes >> 2); return; }
+    const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (kBlock / kWave) + wave);
+    if (slot >= P.launchWaves) return;
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;
-    const int tile = blockIdx.x * (kBlock / kWave) + wave;
-    const int tx = tile % P.tilesX, ty = tile / P.tilesX;
+    int tile, tx, ty;
+    resolve_slot(P, slot, tx, ty, tile);
     const int px = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
     const bool valid = (ty < P.tilesY) && (px < P.W) && (ly < P.localRows);
     const int py = global_row(P, ly);
     const bool inImage = valid && (py < P.H);
+    const bool outside = px < P.rootX0 || px > P.rootX1 || py < P.rootY0 || py > P.rootY1;     // the solid leaves' rectangle: no hit outside it
+    const bool tileLive = tile_may_hit(P, tx, ty, slot, lane, tile);                             // wave-uniform; a tile outside the mask records its cost there
     const Geo G = geo_of(P);
 
     bool hit = false, active = false, enter = false;
@@ -1605,7 +1613,7 @@ __global__ __launch_bounds__(kBlock) void k_closest_near_first(RenderParams P, c
     unsigned flip = 0;
     Ray r;
     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
-    if (inImage && P.rootVisible) {
+    if (inImage && P.rootVisible && !outside && tileLive) {
         r = generate_ray_tab(P, px, py);
         flip = (r.dx < 0.0f ? 1u : 0u) | (r.dy < 0.0f ? 2u : 0u) | (r.dz < 0.0f ? 4u : 0u);
         float tNear, tFar, a0, a1, a2, a3, a4, a5;
@@ -1621,8 +1629,10 @@ __global__ __launch_bounds__(kBlock) void k_closest_near_first(RenderParams P, c
     const float kBelow1e30 = __uint_as_float(0x7149f2c9u);
     unsigned cur = 0, lvlPending = 0;
     int cx = 0, cy = 0, cz = 0, bpos = P.depth - 1;
+    int entered = 0;                                        // internal nodes this lane entered: the tile's cost is its busiest lane's
     while (active) {
         if (enter) {
+            entered++;
             const uint2 d = desc[cur];
             unsigned fail8;
             if (anyRisky) fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, cx, cy, cz, 1 << bpos);
@@ -1654,14 +1664,26 @@ __global__ __launch_bounds__(kBlock) void k_closest_near_first(RenderParams P, c
                 cx = chx; cy = chy; cz = chz; bpos = Lb - 1; enter = true;
             } else {
                 const float tHit = gmax(0.0f, tNear);
-                if (tHit <= tFar && (tHit < best || (hit && tHit == best && pops_before(chx, chy, chz, bx, by, bz)))) {
+                // three plain booleans, not `tHit < best || (hit && tHit == best && pops_before(..))`: ROCm 7.2's structurizer turned the
+                // short-circuit form, inside this divergent loop, into exec-mask bookkeeping that lost the update for a lane whose first
+                // candidate was a degenerate touch (tNear == tFar) -- one pixel of the Calgary golden frame, found when the launch geometry
+                // changed which rays share a wave (docs/LAB_NOTES.md)
+                const bool nearer = tHit < best;
+                const bool tie = hit && tHit == best;
+                const bool first = pops_before(chx, chy, chz, bx, by, bz);
+                if (tHit <= tFar && (nearer || (tie && first))) {
                     best = tHit; hit = true; bx = chx; by = chy; bz = chz; bs = h;
                 }
             }
         }
     }
+    if (P.tileCost && tileLive) {
+        const int cost = __builtin_amdgcn_readlane(wave_scan_max_nonneg(entered), kWave - 1);
+        if (lane == 0 && ty < P.tilesY) P.tileCost[tile] = (cost == 0 && P.tileMask) ? -1 : (cost + 3) >> 2;
+    }
     const float shade = hit ? shade_term(P, G, r, bx, by, bz, bs) : kShadeMiss;
-    if (valid) out[(size_t)ly * P.W + px] = shade_color(shade);
+    if (valid && !(P.skipOutside && outside)) store_pixel(out + (size_t)ly * P.W + px, shade_color(shade));
+    fill_outside<kModeColor>(P, out, lane, slot);
 }
 
 #ifndef RTO_LEAN_WAVES

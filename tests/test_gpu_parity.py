@@ -114,6 +114,16 @@ def test_fuzz_random_scenes_and_cameras(ctx, orc, seed):
             grgba, gt_ = ctx.render_skip_host(f)
         assert gt_.tobytes() == nt.tobytes(), f"seed {seed} {kind} {g.dims} {W}x{H} fov {fov}: nearest-hit distances"
         assert_bit_exact(grgba, nrgba, f"seed {seed} {kind} nearest-hit colours")
+        # the closest-hit mode (the reference's earlier shader): near-first, pop-order and node-by-node kernels; twice each (the second
+        # frame runs under the launch order and the rim the first one left)
+        cwant, cst = orc.render_closest(s.nodes, s.min, s.voxel, view, pos, aspect, fov, W, H)
+        for kname, kernel in (("near first", rto.KERNEL_AUTO), ("pop order", rto.KERNEL_PACKED_V1), ("node by node", rto.KERNEL_GENERIC)):
+            ctx.set_kernel(kernel)
+            for rep in range(2):
+                assert_bit_exact(ctx.render_closest_host(f), cwant, f"seed {seed} {kind} {g.dims} {W}x{H} fov {fov} closest hit, {kname}, frame {rep}")
+        ctx.set_kernel(rto.KERNEL_AUTO)
+        _, gcs = ctx.render_closest_host(f, stats=True)
+        assert (gcs["pops"], gcs["hits"]) == (cst["pops"], cst["hits"]), f"seed {seed} {kind} closest-hit counters"
         if shot == 0:
             tris, off = orc.build_leaf_triangles(s.grid, s.nodes)
             ctx.build_leaf_triangles(g.data)                            # GPU builder == oracle's buffer, then render from it
