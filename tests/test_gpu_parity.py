@@ -493,6 +493,17 @@ def test_frustum_update_proven_on_the_host_equals_the_kernel(ctx, orc, scenes):
             ctx.debug_set_frustum_shortcut(True)
             ctx.debug_update_frustum_planes(planes, 0.0)
             assert 0 < ctx.info().visible_nodes < n
+        # a scene thousands of units across: the margin no longer covers it, whatever the proof says both paths equal the reference's loop
+        cal = scenes("calgary")
+        upload(ctx, cal)
+        for cam in (orc.Camera(0.6, 0.5, 3500.0), orc.Camera(1.2, 0.1, 900.0), orc.Camera(2.5, 0.8, 200.0)):
+            view = cam.get_view()
+            want_nodes, vis = orc.cull_compact(cal.nodes, cal.min, cal.voxel, view, 45.0, aspect)
+            for shortcut in (True, False):
+                ctx.debug_set_frustum_shortcut(shortcut)
+                ctx.update_frustum(view, 45.0, aspect, enable=True)
+                assert ctx.info().visible_nodes == len(want_nodes)
+                assert ctx.download_visible_nodes().tobytes() == want_nodes.tobytes()
     finally:
         ctx.debug_set_frustum_shortcut(True)
         ctx.update_frustum(np.eye(4, dtype=np.float32).reshape(16), 45.0, aspect, enable=False)
