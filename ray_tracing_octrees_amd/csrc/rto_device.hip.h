@@ -2611,7 +2611,9 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
                     if (nx * r.dx + ny * r.dy + nz * r.dz > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
                     ndotl = gmax(0.0f, nx * lnx + ny * lny + nz * lnz);
                     shade = ndotl;
-                    if (shadow) {
+                    // a hit that faces away from the light is black whatever its shadow ray finds: only the instrumented frames (which
+                    // count that ray's pops) still trace it
+                    if (shadow && (MODE == kModeSteps || ndotl > 0.0f)) {
                         const float bias = G.vs * 1e-3f;
                         const float hx = r.ox + r.dx * bestT, hy = r.oy + r.dy * bestT, hz = r.oz + r.dz * bestT;
                         r.ox = hx + nx * bias; r.oy = hy + ny * bias; r.oz = hz + nz * bias;
