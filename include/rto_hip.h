@@ -158,6 +158,8 @@ int  rto_debug_update_frustum_planes(rto_context* ctx, const float planes[24], f
  * few units across -- every node is visible, the device state that says so is written once and further such updates launch
  * NOTHING (identical results, S/RT:743-802's loop passes every node as well).  enabled = 0 forces the kernel (A/B, tests). */
 int  rto_debug_set_frustum_shortcut(rto_context* ctx, int enabled);
+/* *proven = 1 when the last frustum update was answered by that proof (no kernel), else 0. */
+int  rto_debug_last_frustum_update_proven(const rto_context* ctx, int* proven);
 /* Copies the compacted array (== m_visibleNodes, S/RayTracerBVH.cpp:775-802) to the host for parity
  * checks.  out may be NULL to query the count only. */
 int  rto_download_visible_nodes(rto_context* ctx, rto_node* out, int64_t capacity, int64_t* count);

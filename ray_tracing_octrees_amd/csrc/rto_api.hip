@@ -61,6 +61,7 @@ struct rto_context {
     bool cullAsync = false;          // the flags in force come from k_cull_desc
     bool visAllOnes = false;         // d_vis, the descriptors' visibility bits and d_start say "every node visible" (rto_update_frustum's host-side proof left them so)
     bool cullShortcut = true;        // rto_debug_set_frustum_shortcut
+    bool lastUpdateProven = false;   // the last rto_update_frustum was answered by the host-side proof (rto_debug_last_frustum_update_proven)
     bool cullStateStale = false;     // rootVisible / visibleNodes below are older than d_start
     bool cullCaptured = false;       // an update was stream-captured: replays change d_start behind the host's back
     hipEvent_t evCull = nullptr;     // recorded on c->stream behind the last kernel that rewrote the visibility state (descriptor bits, d_vis,
@@ -1019,7 +1020,9 @@ static int update_frustum_planes(rto_context* c, const float planes[24], float m
     // it -- rto_download_visible_nodes, the generic kernel: ensure_compact().  The packed kernels render from the visibility
     // bits in the descriptors, which is all a frustum update has to refresh for them.
     c->compactValid = false;
+    c->lastUpdateProven = false;
     if (canon && c->cullShortcut && !capturing && !c->cullCaptured && every_node_visible(c, planes, margin)) {
+        c->lastUpdateProven = true;
         // Proven on the host: the update flags every node.  The device state that says so is written once; while it stands, an
         // update launches nothing at all.
         if (!c->visAllOnes) {
@@ -1093,6 +1096,12 @@ int rto_debug_set_frustum_shortcut(rto_context* c, int enabled) {
     if (!c) return RTO_E_INVALID;
     c->cullShortcut = enabled != 0;
     if (!c->cullShortcut) c->visAllOnes = false;
+    return RTO_OK;
+}
+
+int rto_debug_last_frustum_update_proven(const rto_context* c, int* proven) {
+    if (!c || !proven) return RTO_E_INVALID;
+    *proven = c->lastUpdateProven ? 1 : 0;
     return RTO_OK;
 }
 

@@ -26,7 +26,7 @@ NODE_DTYPE = np.dtype(
 SYMBOLS = (
     "rto_create", "rto_destroy", "rto_last_error", "rto_device_name",
     "rto_upload_octree", "rto_build_octree", "rto_download_nodes", "rto_debug_set_build_path", "rto_last_build_ms", "rto_octree_info_get", "rto_set_kernel", "rto_set_launch_order", "rto_forget_stream",
-    "rto_update_frustum", "rto_debug_update_frustum_planes", "rto_debug_set_frustum_shortcut", "rto_download_visible_nodes",
+    "rto_update_frustum", "rto_debug_update_frustum_planes", "rto_debug_set_frustum_shortcut", "rto_debug_last_frustum_update_proven", "rto_download_visible_nodes",
     "rto_render_device", "rto_render_host", "rto_partition_rows", "rto_assemble_device",
     "rto_render_shade_device", "rto_assemble_shade_device", "rto_assemble_batch_device", "rto_render_batch_device", "rto_assemble_batch_all_device", "rto_render_resident", "rto_resident_frame", "rto_download_resident",
     "rto_upload_leaf_triangles", "rto_build_leaf_triangles", "rto_download_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
@@ -122,6 +122,7 @@ def load():
     L.rto_forget_stream.argtypes = [vp, vp]
     L.rto_debug_update_frustum_planes.argtypes = [vp, C.POINTER(C.c_float), C.c_float]
     L.rto_debug_set_frustum_shortcut.argtypes = [vp, C.c_int]
+    L.rto_debug_last_frustum_update_proven.argtypes = [vp, C.POINTER(C.c_int)]
     L.rto_debug_sort_violations.argtypes = [vp, C.POINTER(C.c_int)]
     L.rto_debug_set_tile_mask.argtypes = [vp, C.c_int]
     L.rto_debug_tile_mask_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -299,6 +300,11 @@ class Context:
     def debug_set_frustum_shortcut(self, enabled: bool):
         """False: rto_update_frustum always runs its kernel (the host-side proof that no node can be culled is skipped)."""
         self._check(self._L.rto_debug_set_frustum_shortcut(self._h, 1 if enabled else 0))
+
+    def debug_last_frustum_update_proven(self) -> bool:
+        v = C.c_int()
+        self._check(self._L.rto_debug_last_frustum_update_proven(self._h, C.byref(v)))
+        return bool(v.value)
 
     def forget_stream(self, stream: int):
         """Drop the launch-order tables kept for `stream` (call before destroying the stream)."""

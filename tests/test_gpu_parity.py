@@ -479,6 +479,7 @@ def test_frustum_update_proven_on_the_host_equals_the_kernel(ctx, orc, scenes):
                 ctx.debug_set_frustum_shortcut(shortcut)
                 ctx.update_frustum(view, 45.0, aspect, enable=True)
                 ctx.update_frustum(view, 45.0, aspect, enable=True)          # a second update in the same state
+                assert ctx.debug_last_frustum_update_proven() == shortcut
                 assert ctx.info().culling_active == 1 and ctx.info().visible_nodes == n
                 assert ctx.download_visible_nodes().tobytes() == want_nodes.tobytes()
                 assert_bit_exact(ctx.render_host(f), want, f"camera {i}, host-side proof {'on' if shortcut else 'off'}")
@@ -507,6 +508,53 @@ def test_frustum_update_proven_on_the_host_equals_the_kernel(ctx, orc, scenes):
     finally:
         ctx.debug_set_frustum_shortcut(True)
         ctx.update_frustum(np.eye(4, dtype=np.float32).reshape(16), 45.0, aspect, enable=False)
+
+
+def test_frustum_proof_never_claims_more_than_the_kernel_finds(ctx, orc):
+    """Property: over random plane sets and margins around a small grid -- planes far away, planes grazing the root box, planes
+    cutting it -- the update with the host-side proof and the update with the kernel forced leave the same survivors.  (If the
+    proof ever fired for planes that cull a node, the counts would differ.)  Some sets must be proven, some not."""
+    rng = np.random.default_rng(99)
+    dims = (16, 16, 16)
+    data = (rng.random((16, 16, 16)) < 0.3).astype(np.uint8)
+    gmin = np.array([-3.0, 10.0, 0.5], np.float32)
+    g = orc.Grid(dims, gmin, np.float32(0.25), data)
+    nodes = orc.build_flat_octree(g)
+    ctx.set_kernel(rto.KERNEL_AUTO)
+    ctx.upload_octree(nodes, g.min, g.voxel_size)
+    n = len(nodes)
+    centre = gmin + 2.0
+    all_visible = some_culled = proven = 0
+    try:
+        for trial in range(120):
+            planes = np.zeros((6, 4), np.float32)
+            margin = float(rng.choice([0.0, 0.1, 1.0, 5.0, 150.0]))
+            for i in range(6):
+                nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+                # signed distance of the grid's centre from the plane: from well inside (+8) to cutting the box (0) to outside (-3);
+                # every fifth trial: every plane a hair outside the widened root box (all nodes pass, too close to be proven)
+                reach = 2.0 * float(np.abs(nrm).sum()) + margin * float(np.abs(nrm).sum())
+                dist = reach + 0.003 if trial % 5 == 4 else float(rng.choice([8.0 + 2 * margin, 3.5, 2.0 * 1.7320508 + margin, 1.0, 0.0, -1.0, -3.0 - margin]))
+                planes[i, :3] = nrm
+                planes[i, 3] = dist - float(np.dot(nrm, centre))
+            counts = []
+            for shortcut in (True, False):
+                ctx.debug_set_frustum_shortcut(shortcut)
+                ctx.debug_update_frustum_planes(planes, margin)
+                counts.append(ctx.info().visible_nodes)
+                if shortcut:
+                    was_proven = ctx.debug_last_frustum_update_proven()
+                else:
+                    assert not ctx.debug_last_frustum_update_proven()
+            assert counts[0] == counts[1], f"trial {trial}: {counts} survivors with / without the host-side proof (margin {margin})"
+            assert not was_proven or counts[1] == n
+            proven += was_proven
+            all_visible += counts[1] == n
+            some_culled += counts[1] < n
+        assert proven >= 3 and all_visible > proven and some_culled >= 5, (proven, all_visible, some_culled)
+    finally:
+        ctx.debug_set_frustum_shortcut(True)
+        ctx.update_frustum(np.eye(4, dtype=np.float32).reshape(16), 45.0, 1.0, enable=False)
 
 
 @pytest.mark.parametrize("first_survivor", ["solid leaf", "internal node"])
