@@ -765,9 +765,14 @@ def main(argv=None):
                     rt.finish()
                     ts.append((time.perf_counter() - t_d) / args.dropin_frames)
                 legs[name] = round(median(ts) * 1e3, 5)
+                if name == "update_every_frame":
+                    import ctypes as _C
+                    pv = _C.c_int(0)
+                    _hip.load().rto_debug_last_frustum_update_proven(rt.context_handle, _C.byref(pv))
+                    proven_on_host = bool(pv.value)
                 _trace(f"dropin leg {name}: " + " ".join(f"{t * 1e6:.2f}" for t in ts))
             dropin = {"ms_per_call": legs["update_every_frame"], "ms_per_call_update_kernel_forced": legs["update_kernel_forced"],
-                      "ms_per_call_without_update": legs["no_update"], "calls": args.dropin_frames,
+                      "ms_per_call_without_update": legs["no_update"], "update_proven_on_host": proven_on_host, "calls": args.dropin_frames,
                       "Mrays_per_s": round(rays / legs["update_every_frame"] / 1e3, 1), "frame_equals_timed_frame": bool(dropin_ok),
                       "what": "C++ RayTracerBVH::renderSceneComputeWithCulling(camera, W, H, aspect, 45, updateFrustum=true) per frame, as main.cpp:1357-1363 calls it "
                               "(plain launches, host never waits inside the loop); median of 3 runs after an untimed clock ramp of the same calls.  ms_per_call: the library as shipped -- at this scene "
