@@ -3116,6 +3116,7 @@ __global__ __launch_bounds__(kWave) void k_probe_skip(ProbeParams Q, const uint2
     // the table's 2 KB: 32 bytes per lane, fetched first and stored after the ray set-up (a launch's first loads are its slowest)
     const uint4 lutA = reinterpret_cast<const uint4*>(kSkipPerm.v)[lane * 2], lutB = reinterpret_cast<const uint4*>(kSkipPerm.v)[lane * 2 + 1];
     const uint2 rootDesc = desc[0];                                       // warms the root's line while the rays are set up
+    const float previous = *skip;                                         // the value the blend needs at the very end: asked for now
     float t = 1e30f;
     // the probe's direction as three plain floats: a SkipRay that lives across the barrier below was kept in SCRATCH (24 bytes: two
     // scratch stores at the kernel's head, two before the rank step, the loads in front of the traversal -- in a one-wave latency chain)
@@ -3151,19 +3152,25 @@ __global__ __launch_bounds__(kWave) void k_probe_skip(ProbeParams Q, const uint2
     const bool ok = lane < 49 && t < 1e30f && t > 0.0f;                  // S/VR:1640-1642
     const unsigned long long okMask = __builtin_amdgcn_ballot_w64(ok);
     const int nv = __builtin_popcountll(okMask);
+    // rank of every valid distance: probe j's value comes down through v_readlane (a scalar, 4 cycles) -- as 49 ds_bpermute round
+    // trips this step was 4.3 us of the call's 16.9 (tools/probe_stamp.py)
+    // A valid distance is positive: its bits order like its value, and (bits, probe number) as ONE 64-bit key orders the probes the
+    // way the comparisons of std::sort's result would -- one v_cmp_lt_u64 per probe, no branch; an invalid probe's key is all ones.
     int rank = 0;
+    const int tBits = __float_as_int(t);
+    const unsigned long long myKey = ((unsigned long long)(unsigned)tBits << 32) | (unsigned)lane;
+#pragma unroll
     for (int j = 0; j < 49; j++) {
-        const float tj = __shfl(t, j);
-        const bool okj = (okMask >> j) & 1ull;
-        rank += (okj && (tj < t || (tj == t && j < lane))) ? 1 : 0;
+        const unsigned hi = ((okMask >> j) & 1ull) ? (unsigned)__builtin_amdgcn_readlane(tBits, j) : 0xffffffffu;   // scalar select
+        rank += ((((unsigned long long)hi << 32) | (unsigned)j) < myKey) ? 1 : 0;
     }
     int safeIndex = (int)((float)nv * 0.15f);                            // S/VR:1650
     if (safeIndex < 0) safeIndex = 0;
     const unsigned long long pick = __builtin_amdgcn_ballot_w64(ok && rank == safeIndex);
     float skipDistance = 0.0f;
-    if (nv > 0) skipDistance = __shfl(t, __builtin_ctzll(pick)) * 0.75f; // :1651-1654
+    if (nv > 0) skipDistance = __int_as_float(__builtin_amdgcn_readlane(tBits, (int)__builtin_ctzll(pick))) * 0.75f;   // :1651-1654
     const float blendFactor = 0.4f;                                      // :1659-1661
-    if (lane == 0) *skip = *skip * blendFactor + skipDistance * (1.0f - blendFactor);
+    if (lane == 0) *skip = previous * blendFactor + skipDistance * (1.0f - blendFactor);
 }
 
 // ================================================================ N4: octree construction on the GPU
