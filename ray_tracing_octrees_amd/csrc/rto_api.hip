@@ -2319,8 +2319,9 @@ int rto_octree_ray_skip(rto_context* c, const float ro[3], const float* rd, int6
     const int blocks = (int)((n + kBlock - 1) / kBlock);
     // canonical trees: the descriptor form (latency of a ray = one 8-byte load per visited internal node);
     // anything else, or RTO_KERNEL_GENERIC: the 60-byte node form
-    if (c->canonical && c->numInternal > 0 && c->kernelMode != RTO_KERNEL_GENERIC)
-        hipLaunchKernelGGL(k_octree_ray_skip_packed, dim3(blocks), dim3(kBlock), 0, c->stream, c->d_desc, vis, vis ? 1 : 0, c->rootSize, c->depth,
+    const size_t ldsSkip = (size_t)(kBlock / kWave) * std::max(c->depth, 1) * kWave * sizeof(uint4);      // the rays' frames, [wave][level][lane]
+    if (c->canonical && c->numInternal > 0 && c->kernelMode != RTO_KERNEL_GENERIC && ldsSkip <= 62 * 1024)
+        hipLaunchKernelGGL(k_octree_ray_skip_packed, dim3(blocks), dim3(kBlock), ldsSkip, c->stream, c->d_desc, vis, vis ? 1 : 0, c->rootSize, std::max(c->depth, 1),
                            c->gridMin[0], c->gridMin[1], c->gridMin[2], c->voxelSize, ro[0], ro[1], ro[2], d_rd, n, t_min, t_max, d_out);
     else
         hipLaunchKernelGGL(k_octree_ray_skip, dim3(blocks), dim3(kBlock), 0, c->stream, c->d_nodes, vis,

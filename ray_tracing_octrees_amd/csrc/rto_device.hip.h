@@ -2787,7 +2787,6 @@ __global__ __launch_bounds__(kBlock) void k_octree_ray_skip(const rto_node* __re
 // reference calls this for 49 probe rays per frame (S/VR:1602-1647), so what matters is the latency of one ray.
 // Identical float operations per child as k_octree_ray_skip (box from gridMin + float(c)*voxel, interval clipped by
 // the parent's); `useVis` applies the descriptors' visibility masks (what rto_update_frustum last computed).
-struct SkipFramePacked { unsigned d; int cx, cy, cz; float enterT, exitT; unsigned cand; int pos; };
 
 __device__ __forceinline__ bool skip_interval(float g, float vs, float o, float inv, int c, int size, float& tN, float& tF) {
     const float w0 = g + (float)c * vs;
@@ -2797,85 +2796,8 @@ __device__ __forceinline__ bool skip_interval(float g, float vs, float o, float 
     return true;
 }
 
-__global__ __launch_bounds__(kBlock) void k_octree_ray_skip_packed(const uint2* __restrict__ desc, const uint8_t* __restrict__ vis, int useVis,
-                                                                    int rootSize, int depth,
-                                                                    float gx, float gy, float gz, float vx,
-                                                                    float rox, float roy, float roz,
-                                                                    const float* __restrict__ rd, int64_t n, float tMin0, float tMax0,
-                                                                    float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float dx = rd[3 * i], dy = rd[3 * i + 1], dz = rd[3 * i + 2];
-    float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;                  // S/VR:81-87
-    const float smallValue = 1e-10f;
-    if (__builtin_fabsf(dx) < smallValue) ix = dx >= 0 ? 1e10f : -1e10f;
-    if (__builtin_fabsf(dy) < smallValue) iy = dy >= 0 ? 1e10f : -1e10f;
-    if (__builtin_fabsf(dz) < smallValue) iz = dz >= 0 ? 1e10f : -1e10f;
-    const int dirMask = ((dx > 0) ? 1 : 0) | ((dy > 0) ? 2 : 0) | ((dz > 0) ? 4 : 0);   // S/VR:114-116
-    // the 8 octants by (Hamming distance from dirMask, octant index), 3 bits each
-    unsigned order = 0;
-    {
-        int p = 0;
-        for (int dist = 0; dist <= 3; dist++)
-            for (int o = 0; o < 8; o++)
-                if (__builtin_popcount(o ^ dirMask) == dist) { order |= (unsigned)o << (3 * p); p++; }
-    }
-    // interval of child (bx, by, bz) of edge `size`, clipped by [pe, px]: the operations of S/VR:70-100
-    auto interval = [&](int bx, int by, int bz, int size, float pe, float px, float& enterT, float& exitT) {
-        float tNx, tFx, tNy, tFy, tNz, tFz;
-        skip_interval(gx, vx, rox, ix, bx, size, tNx, tFx);
-        skip_interval(gy, vx, roy, iy, by, size, tNy, tFy);
-        skip_interval(gz, vx, roz, iz, bz, size, tNz, tFz);
-        enterT = gmax(gmax(tNx, tNy), gmax(tNz, pe));
-        exitT = gmin(gmin(tFx, tFy), gmin(tFz, px));
-    };
-
-    float result = 1e30f;
-    SkipFramePacked st[kMaxDepth + 1];
-    int sp = -1;
-    {   // the root (an internal node here: the host only takes this path for canonical trees with descriptors)
-        float e, x;
-        interval(0, 0, 0, rootSize, tMin0, tMax0, e, x);
-        const bool reject = (useVis && vis[0] == 0) || e > x;
-        if (!reject) { sp = 0; st[0].d = 0; st[0].cx = st[0].cy = st[0].cz = 0; st[0].enterT = e; st[0].exitT = x; st[0].pos = -1; st[0].cand = 0; }
-    }
-    while (sp >= 0) {
-        SkipFramePacked& f = st[sp];
-        const int half = rootSize >> (sp + 1);
-        const uint2 d = desc[f.d];
-        const unsigned sm = d.x & 0xffu, im = (d.x >> 8) & 0xffu, vm = useVis ? ((d.x >> 16) & 0xffu) : 0xffu;
-        if (f.pos < 0) {
-            // first visit: which children have a non-empty interval (and are visible, and are not empty leaves)
-            unsigned pass = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                float e, x;
-                interval(f.cx + ((k & 1) ? half : 0), f.cy + ((k & 2) ? half : 0), f.cz + ((k & 4) ? half : 0), half, f.enterT, f.exitT, e, x);
-                pass |= (e > x) ? 0u : (1u << k);
-            }
-            f.cand = pass & vm & (sm | im);
-            f.pos = 0;
-        }
-        int k = -1;
-        while (f.pos < 8) {
-            const int o = (int)((order >> (3 * f.pos)) & 7u);
-            f.pos++;
-            if ((f.cand >> o) & 1u) { k = o; break; }
-        }
-        if (k < 0) { sp--; continue; }                                  // every child returned 1e30
-        const int bx = f.cx + ((k & 1) ? half : 0), by = f.cy + ((k & 2) ? half : 0), bz = f.cz + ((k & 4) ? half : 0);
-        float e, x;
-        interval(bx, by, bz, half, f.enterT, f.exitT, e, x);
-        if ((sm >> k) & 1u) { result = e; break; }                      // solid leaf: finite, every ancestor returns it (S/VR:146-149)
-        const unsigned child = d.y + (unsigned)__builtin_popcount(im & ((1u << k) - 1u));
-        sp++;
-        st[sp].d = child; st[sp].cx = bx; st[sp].cy = by; st[sp].cz = bz; st[sp].enterT = e; st[sp].exitT = x; st[sp].pos = -1; st[sp].cand = 0;
-    }
-    out[i] = result;
-}
-
 // ---------------------------------------------------------------- N1 as a render mode, and N1's consumer
-// skip_traverse: the search of k_octree_ray_skip_packed with the per-ray frames in LDS ([level][lane], 16 bytes each) instead
+// skip_traverse: octreeRaySkip's search on the descriptor tree with the per-ray frames in LDS ([level][lane], 16 bytes each) instead
 // of a private array, and an O(1) return to the deepest level that still has untried children (`pend`), so that a whole
 // frame of rays (rto_render_skip_device: "nearest hit" as SURVEY.md section 8f asks for it) runs at a useful rate.  Same float
 // operations per child, same child order (Hamming distance from the octant of the positive direction bits, ties by octant
@@ -3038,6 +2960,27 @@ __device__ __forceinline__ float skip_traverse(const uint2* __restrict__ desc, c
         cur = en.y + (unsigned)__builtin_popcount((en.x >> 16) & 0xffu & ((1u << k) - 1u));
         cx = bx; cy = by; cz = bz; level = L + 1;
     }
+}
+
+// rto_octree_ray_skip on a canonical tree: one thread per ray (shared origin), the per-ray frames in LDS like every other user of
+// skip_traverse -- until round 4 this kernel kept them in a private array: 688 bytes of scratch per thread.
+__global__ __launch_bounds__(kBlock) void k_octree_ray_skip_packed(const uint2* __restrict__ desc, const uint8_t* __restrict__ vis, int useVis,
+                                                                    int rootSize, int depth,
+                                                                    float gx, float gy, float gz, float vx,
+                                                                    float rox, float roy, float roz,
+                                                                    const float* __restrict__ rd, int64_t n, float tMin0, float tMax0,
+                                                                    float* __restrict__ out) {
+    extern __shared__ uint4 lds_skip[];    // [wave][level][lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint4* stk = lds_skip + (size_t)wave * depth * kWave + lane;
+    __shared__ unsigned char permLut[8 * 256];
+    load_skip_perm(permLut);
+    __syncthreads();                                                     // before any thread leaves
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const SkipRay r = skip_ray(rox, roy, roz, rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+    int lx, ly, lz, ls;
+    out[i] = skip_traverse(desc, vis, useVis != 0, rootSize, gx, gy, gz, vx, r, tMin0, tMax0, stk, lx, ly, lz, ls, nullptr, permLut);
 }
 
 // One thread per pixel (a wave = an 8x8 tile): distance of the ray of generateRay through octreeRaySkip(root, ro, rd, 0, 1e30)
