@@ -732,9 +732,7 @@ __device__ __forceinline__ void order_sort_sample(const int* __restrict__ tileCo
     if ((int)threadIdx.x < kWave) {                 // write cursors: costlier buckets first.  Lane b owns bucket 63 - b.
         const int b = kOrderBuckets - 1 - lane;
         const int total = cnt[b];
-        int incl = total;
-        for (int o = 1; o < kWave; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-        cnt[b] = incl - total;
+        cnt[b] = wave_scan_add(total) - total;      // exclusive prefix sum in registers (DPP), no LDS round trips
     }
     __syncthreads();
     for (int e0 = (int)(threadIdx.x & ~63u); e0 < cw; e0 += bd) {
@@ -747,7 +745,7 @@ __device__ __forceinline__ void order_sort_sample(const int* __restrict__ tileCo
             const int leader = (int)__builtin_ctzll(zeros);
             int base = 0;
             if (lane == leader) base = atomicAdd(&cnt[0], (int)__builtin_popcountll(zeros));
-            base = __shfl(base, leader);
+            base = __builtin_amdgcn_readlane(base, leader);
             if (b == 0) r = base + (int)__builtin_popcountll(zeros & ((1ull << lane) - 1ull));
         }
         if (b < 0) continue;
@@ -3053,6 +3051,9 @@ struct ProbeParams { float invP[16], invV[16]; float eye[3]; float gx, gy, gz, v
 __global__ __launch_bounds__(kWave) void k_probe_skip(ProbeParams Q, const uint2* __restrict__ desc, const uint8_t* __restrict__ vis, int useVis,
                                                        float* __restrict__ skip, float* __restrict__ probeT /* optional: the 49 distances */) {
     extern __shared__ uint4 lds_skip[];
+#if defined(RTO_PROBE_STAMP)       // A/B build (tools/probe_stamp.py): skip[1..3] = us spent in set-up / traversal / rank + blend
+    const unsigned long long st0 = wall_clock64();
+#endif
     const int lane = threadIdx.x;
     uint4* stk = lds_skip + lane;
     __shared__ unsigned char permLut[8 * 256];
@@ -3086,12 +3087,18 @@ __global__ __launch_bounds__(kWave) void k_probe_skip(ProbeParams Q, const uint2
     reinterpret_cast<uint4*>(permLut)[lane * 2] = lutA; reinterpret_cast<uint4*>(permLut)[lane * 2 + 1] = lutB;
     asm volatile("" :: "v"(rootDesc.x), "v"(rootDesc.y));
     __syncthreads();
+#if defined(RTO_PROBE_STAMP)
+    const unsigned long long st1 = wall_clock64();
+#endif
     if (lane < 49) {
         const SkipRay r = skip_ray(Q.eye[0], Q.eye[1], Q.eye[2], pdx, pdy, pdz);
         int a, b, cc, dd;
         t = skip_traverse(desc, vis, useVis != 0, Q.rootSize, Q.gx, Q.gy, Q.gz, Q.vs, r, 0.0f, 1e30f, stk, a, b, cc, dd, nullptr, permLut);
         if (probeT) probeT[lane] = t;
     }
+#if defined(RTO_PROBE_STAMP)
+    const unsigned long long st2 = wall_clock64();
+#endif
     const bool ok = lane < 49 && t < 1e30f && t > 0.0f;                  // S/VR:1640-1642
     const unsigned long long okMask = __builtin_amdgcn_ballot_w64(ok);
     const int nv = __builtin_popcountll(okMask);
@@ -3114,6 +3121,9 @@ __global__ __launch_bounds__(kWave) void k_probe_skip(ProbeParams Q, const uint2
     if (nv > 0) skipDistance = __int_as_float(__builtin_amdgcn_readlane(tBits, (int)__builtin_ctzll(pick))) * 0.75f;   // :1651-1654
     const float blendFactor = 0.4f;                                      // :1659-1661
     if (lane == 0) *skip = previous * blendFactor + skipDistance * (1.0f - blendFactor);
+#if defined(RTO_PROBE_STAMP)
+    if (lane == 0) { const unsigned long long st3 = wall_clock64(); skip[1] = (float)(st1 - st0) * 0.01f; skip[2] = (float)(st2 - st1) * 0.01f; skip[3] = (float)(st3 - st2) * 0.01f; }
+#endif
 }
 
 // ================================================================ N4: octree construction on the GPU

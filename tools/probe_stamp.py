@@ -1,3 +1,6 @@
+"""tools/probe_stamp.py -- where k_probe_skip spends a call: build `tools/build_variants.sh pstamp "-DRTO_PROBE_STAMP"`, then on the GPU box
+    RTO_HIP_LIB=build/variants/librto_hip_pstamp.so python tools/probe_stamp.py
+(the stamped kernel leaves the three durations behind the skip value)."""
 import os, sys
 ROOT="/root/repo" if os.path.isdir("/root/repo/tools") else os.getcwd()
 sys.path.insert(0, ROOT)
