@@ -266,8 +266,14 @@ int  rto_comm_flush(rto_comm* comm);              /* waits until every submitted
  * not wait for streams of a dead communicator's aborted collectives beyond their completion by the abort).  timeout_ms <= 0: no limit
  * (as rto_comm_flush). */
 int  rto_comm_flush_timeout(rto_comm* comm, int timeout_ms);
-/* 1 once the communicator has been aborted (timeout or asynchronous error), else 0. */
+/* 1 once the communicator has been aborted (timeout or asynchronous error), else 0.  The communicators of ONE
+ * rto_comm_create_all group die together: every batch queues a Send / Recv on each of them, so an abort of one member aborts
+ * (and marks dead) all of them, and rto_comm_submit_all checks every member before any of them starts the batch.
+ * rto_comm_destroy never waits on a collective that cannot finish: it polls the streams (10 s) and aborts a live communicator
+ * whose streams stay busy (a peer process that died) before it releases anything. */
 int  rto_comm_is_dead(const rto_comm* comm);
+/* ncclCommCount of the live communicator: the ranks RCCL itself says take part (what an N-GPU bench line reports as ranks_seen). */
+int  rto_comm_ranks_seen(const rto_comm* comm, int* ranks);
 /* Test hook: marks the communicator as timed out exactly as rto_comm_flush_timeout does on expiry (ncclCommAbort, dead). */
 int  rto_comm_debug_abort(rto_comm* comm);
 /* Developer aid: a ONE-rank communicator renders, ships and assembles as rank as_rank of as_world GPUs (every per-rank cost

@@ -986,12 +986,30 @@ static bool every_node_visible(const rto_context* c, const float planes[24], flo
     return true;
 }
 
+// Frames launched on OTHER streams since the last update read the descriptors / d_vis / d_start an update is about to rewrite:
+// the device is waited for (always, once a frame was captured on another stream: its replays are not seen here).  Not while
+// capturing.  Called only where something is going to be written.
+static int wait_for_other_streams(rto_context* c) {
+    if ((c->otherStreams || c->foreignCaptured) && !stream_is_capturing(c->stream)) { RTO_HIP(c, hipDeviceSynchronize()); c->otherStreams = false; }
+    return RTO_OK;
+}
+
 static int update_frustum_planes(rto_context* c, const float planes[24], float margin) {
     const int64_t n = c->numNodes;
     const int nb = (int)((n + kBlock - 1) / kBlock);
     const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
     const bool canon = c->canonical && nbInt > 0 && c->d_descPos;
     const bool capturing = stream_is_capturing(c->stream);
+    // An update the host proves to be a no-op while the "every node visible" state already stands writes nothing: no hazard with
+    // frames in flight on other streams (the multi-GPU path's render stream), so no device-wide wait either.
+    if (c->d_vis && canon && c->cullShortcut && !capturing && !c->cullCaptured && c->visAllOnes && c->culling && every_node_visible(c, planes, margin)) {
+        c->compactValid = false;
+        c->lastUpdateProven = true;
+        c->cullAsync = true; c->cullStateStale = false;
+        c->rootVisible = 1; c->visibleNodes = n;
+        return RTO_OK;
+    }
+    { const int rcW = wait_for_other_streams(c); if (rcW != RTO_OK) return rcW; }
     if (!c->d_vis) {
         if (capturing)
             return fail(c, RTO_E_UNSUPPORTED, "rto_update_frustum: the first update of an octree allocates its buffers; call it once before hipStreamBeginCapture");
@@ -1068,10 +1086,10 @@ int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, floa
     RTO_HIP(c, hipSetDevice(c->device));
     // The visibility masks live in the descriptors every traversal kernel reads.  Frames on the context's own stream
     // (rto_render_resident: what RayTracerBVH uses) are ordered around the update by the stream itself: nothing is waited for.
-    // Frames launched on OTHER streams since the last update must be done before the masks change: the device is waited for
-    // (always, once a frame was captured on another stream: its replays are not seen here).  Not while capturing.
-    if ((c->otherStreams || c->foreignCaptured) && !stream_is_capturing(c->stream)) { RTO_HIP(c, hipDeviceSynchronize()); c->otherStreams = false; }
+    // Frames launched on OTHER streams since the last update must be done before the masks change (wait_for_other_streams) --
+    // but only where the update writes: one the host proves to change nothing returns without touching the device.
     if (!enable) {
+        { const int rcW = wait_for_other_streams(c); if (rcW != RTO_OK) return rcW; }
         const int nbInt = (int)((c->numInternal + kBlock - 1) / kBlock);
         if (c->culling && c->canonical && nbInt > 0) {
             hipLaunchKernelGGL(k_desc_visall, dim3(nbInt), dim3(kBlock), 0, c->stream, c->numInternal, c->d_desc);
@@ -1626,7 +1644,7 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 // frames finds the same state each time
                 RTO_HIP(c, hipMemsetAsync(st->d_queue, 0, sizeof(int), s));
                 // enough workgroups to fill the machine at this kernel's occupancy; the rest of the slots come from the counter
-                const int resident = c->numCUs * RTO_LEAN_WAVES;
+                const int resident = c->numCUs * RTO_PERSIST_WAVES;
                 hipLaunchKernelGGL(k_trace_lean_persistent<MODE>, dim3(std::min(lblocks, resident)), dim3(kBlock), lds, s, Q, c->d_desc, d_out,
                                    c->d_steps, c->d_counters, st->d_queue);
             } else if (c->kernelMode == RTO_KERNEL_PACKED_V3) {
@@ -2123,6 +2141,9 @@ static int launch_triangles(rto_context* c, const rto_frame* f, const rto_partit
             LeanTriScene S{ c->d_triRec, c->d_tris };
 #if defined(RTO_TRI_TIMELINE)
             S.timeline = (!count && !shadeOut && !capturing && ensure_steps(c, (size_t)tiles * 8) == RTO_OK) ? c->d_steps : nullptr;
+#endif
+#if defined(RTO_TRI_STAMP)
+            S.stamp = (!count && !shadeOut && !capturing && ensure_steps(c, (size_t)tiles * 24) == RTO_OK) ? reinterpret_cast<unsigned*>(c->d_steps) : nullptr;
 #endif
             const size_t lds = (size_t)lean_wpb(1) * ((P.depth + 1) * kWave * sizeof(uint2) + kWave * sizeof(unsigned long long));   // stacks + the keys of the triangle rounds
             P.maskLdsBytes = (int)lds;

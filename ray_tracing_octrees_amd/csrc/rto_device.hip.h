@@ -762,7 +762,7 @@ __global__ __launch_bounds__(kOrderBlock) void k_order_build(const int* __restri
                                                               int* __restrict__ order, int* __restrict__ violations) {
     extern __shared__ unsigned char order_stage[];  // one byte per tile of the sample
     __shared__ int cnt[kOrderBuckets];
-    order_sort_sample(tileCost, tilesX, boxX0, boxY0, boxW, boxH, (int)blockIdx.x, kOrderGroups, order, violations, order_stage, cnt);
+    order_sort_sample(tileCost, tilesX, boxX0, boxY0, boxW, boxH, (int)blockIdx.x, (int)gridDim.x, order, violations, order_stage, cnt);   // G = the launch's own group count (kOrderGroups; dev builds: 16 / 32 / 64)
 }
 
 // ================================================================ screen-space occupancy mask
@@ -1667,7 +1667,7 @@ __global__ __launch_bounds__(kBlock) void k_closest_near_first(RenderParams P, c
                 // candidate was a degenerate touch (tNear == tFar) -- one pixel of the Calgary golden frame, found when the launch geometry
                 // changed which rays share a wave (docs/LAB_NOTES.md)
                 const bool nearer = tHit < best;
-                const bool tie = hit && tHit == best;
+                const bool tie = tHit == best;             // only after a hit: best starts at 1e30 and tHit < 1e30 (the cut above); no lane-mask boolean in the update
                 const bool first = pops_before(chx, chy, chz, bx, by, bz);
                 if (tHit <= tFar && (nearer || (tie && first))) {
                     best = tHit; hit = true; bx = chx; by = chy; bz = chz; bs = h;
@@ -1731,8 +1731,13 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_batch(Ren
 // wave renders its first tile and then keeps taking launch slots from a global counter until none is left.  The host
 // zeroes the counter with a memset node in front of every launch, so each launch is self-contained (safe to capture
 // into a HIP graph and to replay any number of times).
+// 5 waves per SIMD, not the 6 of k_trace_lean: the tile function inside a loop keeps the slot bookkeeping live across it
+// and at 6 (80 VGPRs) two of them were spilled to scratch in the hot loop (12 bytes); at 5 (<= 96) nothing is.
+#ifndef RTO_PERSIST_WAVES
+#define RTO_PERSIST_WAVES 5
+#endif
 template <int MODE>
-__global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_persistent(RenderParams P, const uint2* __restrict__ desc,
+__global__ __launch_bounds__(kBlock, RTO_PERSIST_WAVES) void k_trace_lean_persistent(RenderParams P, const uint2* __restrict__ desc,
                                                            float4* __restrict__ out, int* __restrict__ stepsOut,
                                                            Counters* __restrict__ counters, int* __restrict__ queue) {
     extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
@@ -2348,6 +2353,9 @@ struct LeanTriScene {
 #if defined(RTO_TRI_TIMELINE)
     int* timeline;              // A/B build: 8 ints per tile {start lo, hi, end lo, hi (100 MHz), trips, rounds, HW_ID, XCC_ID | slot << 4}
 #endif
+#if defined(RTO_TRI_STAMP)
+    unsigned* stamp;            // A/B build (tools/tri_stamp.py): 24 words per tile = 7 phases x {s_memtime ticks, times entered, lanes with work}
+#endif
 };
 
 // interesting children per descriptor (after k_desc_trimask)
@@ -2394,6 +2402,19 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
                                                           const int lane, const int slot) {
 #if defined(RTO_TRI_TIMELINE)
     const unsigned long long profT0 = wall_clock64();
+#endif
+#if defined(RTO_TRI_STAMP)
+    // phases: 0 prologue, 1 node loop, 2 round set-up (leaf records, prefix sum, keys), 3 pair chunks (dealing + Moeller-Trumbore),
+    // 4 key read-back + pop-next, 5 a ray's end (accounting, shadow ray start), 6 epilogue.  The stamp's s_waitcnt also drains
+    // the wave's LDS queue: the build measures where the time goes, its frame is slower than the product's.
+    unsigned stTicks[7] = { 0, 0, 0, 0, 0, 0, 0 }, stEnter[7] = { 0, 0, 0, 0, 0, 0, 0 }, stLanes[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long stLast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stLast) :: "memory");
+#define RTO_TS(i, lanes) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        __builtin_amdgcn_sched_barrier(0); stTicks[i] += (unsigned)(t_ - stLast); stEnter[i] += 1u; stLanes[i] += (unsigned)(lanes); stLast = t_; } while (0)
+#define RTO_TS_COUNT(mask) __builtin_amdgcn_readfirstlane(__builtin_popcountll(__builtin_amdgcn_ballot_w64(mask)))
+#else
+#define RTO_TS(i, lanes) do { } while (0)
 #endif
     int tile, tx, ty;
     resolve_slot(P, slot, tx, ty, tile);
@@ -2453,6 +2474,10 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     unsigned long long profLaneTrips = 0, profChunks = 0, profPairs = 0, profWaveTrips = 0;
 #endif
     int chunks = 0;                // triangle chunks of this wave (wave-uniform): part of the tile's cost
+#if defined(RTO_TRI_STAMP)
+    unsigned stWaveTrips = 0;      // loop bodies of the node phase this WAVE issued (>= the trips of its busiest lane: every round pays its own longest lane)
+    RTO_TS(0, RTO_TS_COUNT(alive));
+#endif
 
     for (;;) {
         // node loop: until nobody walks, or RTO_TRI_BATCH lanes wait with a leaf (the tests cost by the pair, so a round
@@ -2463,12 +2488,18 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
         // that have just popped a leaf (the ballot sees exactly the lanes walking in this trip).  The earlier form, a loop on
         // the two ballots around `if (alive)`, cost ~20 VALU instructions per trip in register copies at the loop's edges.
         int waiting = __builtin_popcountll(__builtin_amdgcn_ballot_w64(haveLeaf));
+#if defined(RTO_TRI_STAMP)
+        int stT = 0;               // this lane's trips in this round: the wave issued max(stT) loop bodies for sum(stT) lane-trips
+#endif
         if (waiting < RTO_TRI_BATCH)
         while (alive) {
             trips++;
 #if defined(RTO_TRI_PROFILE)
             { const unsigned long long act = (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));     // lanes walking in this trip
               profLaneTrips += __builtin_amdgcn_readfirstlane((int)act); profWaveTrips += 1; }
+#endif
+#if defined(RTO_TRI_STAMP)
+            stT++;
 #endif
             const uint2 d = *reinterpret_cast<const uint2*>(recBytes + (cur << 3));
             const int Lb = __builtin_ctz(lvlPending | sentinel);
@@ -2510,6 +2541,10 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
             if (waiting >= RTO_TRI_BATCH) break;
         }
         rounds++;
+#if defined(RTO_TRI_STAMP)
+        stWaveTrips += (unsigned)__builtin_amdgcn_readlane(wave_scan_max_nonneg(stT), kWave - 1);
+        RTO_TS(1, __builtin_amdgcn_readlane(wave_scan_add(stT), kWave - 1));
+#endif
         // ---- the waiting lanes' triangles, tested by ALL 64 lanes (S/RT semantics of the pop: it happens only below the
         //      cap).  Leaves own 1 to several dozen triangles (big uniform leaves), so "each lane loops over its own leaf"
         //      runs at 21 % lane utilisation behind the longest leaf.  Instead the (leaf, triangle) pairs of the whole wave
@@ -2540,6 +2575,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
             const int first = (int)tr.x - (incl - cnt);             // pair w of this lane's leaf is triangle first + w
             keys[lane] = ~0ull;
             __builtin_amdgcn_wave_barrier();
+            RTO_TS(2, RTO_TS_COUNT(haveLeaf));
             for (int w0 = 0; w0 < total; w0 += kWave) {
 #if defined(RTO_TRI_PROFILE)
                 profChunks++; profPairs += (unsigned long long)min(kWave, total - w0);
@@ -2569,6 +2605,10 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            RTO_TS(3, total);
+#if defined(RTO_TRI_STAMP)
+            const int stWaiting = RTO_TS_COUNT(haveLeaf);
+#endif
             if (haveLeaf) {
                 const unsigned long long key = keys[lane];
                 if (key != ~0ull) { best = (int)(unsigned)key; bestT = __uint_as_float((unsigned)(key >> 32)); }
@@ -2594,8 +2634,12 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
                     if ((e.x >> 8) & bitj) { haveLeaf = false; alive = true; }             // an internal child: back to the node loop
                 }
             }
+            RTO_TS(4, stWaiting);
         }
         // ---- a ray has ended: account for it; a primary hit starts the shadow ray
+#if defined(RTO_TRI_STAMP)
+        const int stEnded = RTO_TS_COUNT(ended);
+#endif
         if (ended) {
             ended = false;
             int steps = 1 + S;
@@ -2627,6 +2671,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
                 }
             } else if (endedHit) shade = 0.0f;                         // something between the hit and the light
         }
+        RTO_TS(5, stEnded);
         if (__builtin_amdgcn_ballot_w64(alive || haveLeaf) == 0ull) break;
     }
 #if defined(RTO_TRI_TIMELINE)
@@ -2662,7 +2707,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
         int cost = trips;
         for (int off = 32; off > 0; off >>= 1) cost = max(cost, __shfl_xor(cost, off));
         cost += 3 * rounds + chunks;
-        if (lane == 0 && ty < P.tilesY && tileLive) P.tileCost[tile] = cost >> 3;
+        if (lane == 0 && ty < P.tilesY && tileLive) P.tileCost[tile] = ((cost >> 3) == 0 && P.tileMask) ? -1 : cost >> 3;   // inside the mask, no work: the rim (as trace_tile_lean)
     }
     if (valid && !(P.skipOutside && outside)) {
         if (SHADE) __builtin_nontemporal_store(shade, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);
@@ -2674,6 +2719,18 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
         for (int off = 32; off > 0; off >>= 1) { pops += __shfl_down(pops, off); hits += __shfl_down(hits, off); }
         if (lane == 0) { atomicAdd(&counters->pops, pops); atomicAdd(&counters->hits, hits); }
     }
+#if defined(RTO_TRI_STAMP)
+    RTO_TS(6, RTO_TS_COUNT(valid));
+    int stTrips = trips;
+    for (int off = 32; off > 0; off >>= 1) stTrips = max(stTrips, __shfl_xor(stTrips, off));
+    if (Sc.stamp && MODE == kModeColor && lane == 0 && ty < P.tilesY) {
+        unsigned* rec = Sc.stamp + (size_t)tile * 24;
+#pragma unroll
+        for (int i = 0; i < 7; i++) { rec[i * 3] = stTicks[i]; rec[i * 3 + 1] = stEnter[i]; rec[i * 3 + 2] = stLanes[i]; }
+        rec[21] = (unsigned)stTrips | (stWaveTrips << 16); rec[22] = (unsigned)chunks; rec[23] = (unsigned)rounds | 0x80000000u;
+    }
+#endif
+#undef RTO_TS
 }
 
 template <int MODE, bool SHADE>
@@ -3009,7 +3066,8 @@ __global__ __launch_bounds__(kBlock) void k_skip_render(RenderParams P, const ui
     int lx = 0, lyy = 0, lz = 0, ls = 0, visits = 0;
     Ray g;
     g.ox = g.oy = g.oz = g.dx = g.dy = g.dz = 0.0f;
-    if (inImage && !outside && tile_may_hit(P, tx, ty, slot)) {
+    const bool tileLive = tile_may_hit(P, tx, ty, slot, lane, tile);     // wave-uniform; a tile outside the mask records its cost there (0, or -1 on the rim)
+    if (inImage && !outside && tileLive) {
         g = generate_ray_tab(P, px, py);
         const SkipRay r = skip_ray(g.ox, g.oy, g.oz, g.dx, g.dy, g.dz);
         t = skip_traverse(desc, vis, useVis != 0, P.rootSize, G.gx, G.gy, G.gz, G.vs, r, 0.0f, 1e30f, stk, lx, lyy, lz, ls, &visits, permLut);
@@ -3017,7 +3075,7 @@ __global__ __launch_bounds__(kBlock) void k_skip_render(RenderParams P, const ui
     if (P.tileCost) {                                                    // this tile's cost for the launch order: the visits of its busiest ray
         int cst = visits;
         for (int off = 32; off > 0; off >>= 1) cst = max(cst, __shfl_xor(cst, off));
-        if (lane == 0 && ty < P.tilesY) P.tileCost[tile] = cst;
+        if (lane == 0 && ty < P.tilesY && tileLive) P.tileCost[tile] = (cst == 0 && P.tileMask) ? -1 : cst;
     }
     if (inImage && !(P.skipOutside && outside)) {
         const size_t pix = (size_t)ly * P.W + px;

@@ -32,7 +32,7 @@ SYMBOLS = (
     "rto_upload_leaf_triangles", "rto_build_leaf_triangles", "rto_download_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_debug_sort_violations", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
     "rto_comm_unique_id", "rto_comm_create", "rto_comm_create_all", "rto_comm_destroy", "rto_comm_last_error", "rto_comm_submit",
-    "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_flush_timeout", "rto_comm_is_dead", "rto_comm_debug_abort", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_comm_debug_last_payload", "rto_comm_debug_set_rehearsal_clear", "rto_debug_fault_alloc", "rto_render_triangles_batch_device",
+    "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_flush_timeout", "rto_comm_is_dead", "rto_comm_ranks_seen", "rto_comm_debug_abort", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_comm_debug_last_payload", "rto_comm_debug_set_rehearsal_clear", "rto_debug_fault_alloc", "rto_render_triangles_batch_device",
     "rto_debug_set_tile_mask", "rto_debug_tile_mask_info", "rto_render_closest_device", "rto_render_closest_host", "rto_render_skip_device", "rto_render_skip_host", "rto_probe_skip_device", "rto_probe_skip_host",
     "rto_scene_bounds_get", "rto_scene_bounds_of_nodes", "rto_split_plan_make", "rto_split_part_of_rank", "rto_split_rows_of_part", "rto_split_row_source",
 )
@@ -177,6 +177,7 @@ def load():
     L.rto_comm_flush.argtypes = [vp]
     L.rto_comm_flush_timeout.argtypes = [vp, C.c_int]
     L.rto_comm_is_dead.argtypes = [vp]
+    L.rto_comm_ranks_seen.argtypes = [vp, C.POINTER(C.c_int)]
     L.rto_comm_debug_abort.argtypes = [vp]
     L.rto_comm_debug_rehearse.argtypes = [vp, C.c_int, C.c_int]
     L.rto_comm_debug_set_rehearsal_clear.argtypes = [vp, C.c_int]
@@ -604,6 +605,12 @@ class Comm:
     def is_dead(self) -> bool:
         return bool(self._L.rto_comm_is_dead(self._h))
 
+    def ranks_seen(self) -> int:
+        """ncclCommCount: the ranks RCCL says take part in this communicator."""
+        n = C.c_int(0)
+        self._check(self._L.rto_comm_ranks_seen(self._h, C.byref(n)))
+        return int(n.value)
+
     def debug_abort(self):
         """Test hook: what a flush timeout does (ncclCommAbort, the communicator is dead)."""
         self._check(self._L.rto_comm_debug_abort(self._h))
@@ -668,3 +675,16 @@ class CommGroup:
     def flush(self):
         for h in self._handles:
             self._check(self._L.rto_comm_flush(h))
+
+    def ranks_seen(self) -> int:
+        n = C.c_int(0)
+        self._check(self._L.rto_comm_ranks_seen(self._handles[0], C.byref(n)))
+        return int(n.value)
+
+    def is_dead(self):
+        """one flag per member"""
+        return [bool(self._L.rto_comm_is_dead(h)) for h in self._handles]
+
+    def debug_abort(self, member: int = 0):
+        """Test hook: abort ONE member as a flush timeout would; the whole group is dead afterwards."""
+        self._check(self._L.rto_comm_debug_abort(self._handles[member]))

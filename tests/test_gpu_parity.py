@@ -2228,6 +2228,45 @@ def test_comm_group_of_one_gpu_renders_into_the_resident_frame(ctx, orc, scenes,
         other.close()
 
 
+def test_comm_group_abort_with_a_batch_in_flight_then_destroy(ctx, orc, scenes, camera):
+    """a rto_comm_create_all group shares its fate.  A batch is submitted, a member is aborted as a flush timeout would
+    (ncclCommAbort), and then: every member reports dead, rto_comm_submit_all refuses BEFORE any member starts the batch (the
+    group's slots stay in step), rto_comm_destroy of every member returns (it polls, never sits in hipStreamSynchronize behind
+    a collective that cannot finish), and the context renders on with a fresh group.  ranks_seen is ncclCommCount's answer."""
+    import torch
+    s = scenes("sphere32")
+    view, pos = camera("sphere")
+    upload(ctx, s)
+    W, H = 320, 200
+    f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+    want, _ = oracle_frame(orc, s, view, pos, W, H)
+    arr = hip.Context.frame_array([f, f])
+    out = torch.full((2, H, W, 4), 7.0, dtype=torch.float32, device="cuda")
+    grp = hip.CommGroup([ctx], band_rows=8)
+    try:
+        assert grp.ranks_seen() == 1
+        grp.submit(arr, out.data_ptr(), H * W * 16)
+        grp.flush()
+        assert_bit_exact(out[1].cpu().numpy(), want, "group of one, batched submit")
+        grp.submit(arr, out.data_ptr(), H * W * 16)                    # in flight
+        grp.debug_abort(0)
+        assert grp.is_dead() == [True]
+        with pytest.raises(rto.RtoError) as e:
+            grp.submit(arr, out.data_ptr(), H * W * 16)
+        assert e.value.code == hip.RTO_E_INVALID and "dead" in str(e.value)
+        with pytest.raises(rto.RtoError):
+            grp.ranks_seen()
+    finally:
+        grp.close()                                                    # must return
+    assert_bit_exact(ctx.render_host(f), want, "the context renders on after its group died")
+    again = hip.CommGroup([ctx], band_rows=8)
+    try:
+        again.render_resident(f)
+        assert_bit_exact(ctx.download_resident(), want, "a fresh group on the same context")
+    finally:
+        again.close()
+
+
 def test_cpp_class_set_devices(orc, scenes):
     """RayTracerBVH::setDevices: with one device the reference call sequence is unchanged; asking for more GPUs than the
     box has fails loudly (no silent single-GPU fallback)."""
