@@ -16,7 +16,11 @@ N = 1    : `value` is ONE KERNEL LAUNCH PER FRAME (rto_render_device: what the r
            line, all outside the timed region: `frames_per_launch` (several frames per kernel launch, identical and
            distinct cameras -- the throughput form for callers that know the next cameras), `dropin_call` (the C++ class
            exactly as main.cpp:1357-1363 calls it: renderSceneComputeWithCulling with a frustum update every frame),
-           `orbit` (a moving camera, plain launches), `pcie_inclusive` (host-buffer entry point).
+           `orbit` (a moving camera, plain launches), `pcie_inclusive` (host-buffer entry point).  The default run (config 2) also
+           carries, each measured after the headline and checked bitwise against the oracle on one frame: `configs` (BASELINE
+           configs 4 and 5 as 20 plain launches each), `cold` (the first 20 frames of a fresh context after 0.5 s of idle: no
+           clock ramp, no launch-order history), `random_cameras` (64 seeded camera jumps, one launch each: mean and max),
+           `split_rehearsal` (this GPU playing ranks 0 and 1 of a 2 / 4 / 8-GPU split).  --no-extras skips them.
 N > 1    : `python3 bench.py --gpus N` starts N fresh ranks itself (python -m torch.distributed.run, one per GPU; the
            parent process never touches a GPU) and relays rank 0's line; launched under torch.distributed.run it is a
            rank.  Every rank holds the octree and renders its round-robin bands; ONE grouped RCCL send/recv per batch of
@@ -107,6 +111,9 @@ def parse_args(argv=None):
                     help="N>1: seconds the parent waits for its ranks before it kills their process group and exits 124 (0 = no limit)")
     ap.add_argument("--launcher-test-command", default="", help=argparse.SUPPRESS)     # tests: python source run in place of the ranks
     ap.add_argument("--no-tile-mask", action="store_true", help="A/B: switch the occupancy mask of the default kernels off (rto_debug_set_tile_mask)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N=1, config 2: skip the legs behind the headline (configs 4 and 5, cold context, random cameras, split rehearsal)")
+    ap.add_argument("--extras-steps", type=int, default=20, help="timed launches of each `configs` leg and of the `cold` leg")
     ap.add_argument("--launcher-dry-run", action="store_true", help="--gpus N without WORLD_SIZE: print the child command line and exit")
     return ap.parse_args(argv)
 
@@ -290,6 +297,250 @@ def pmc_entry(config: str, kernel_name: str, order: str, fpl: int):
         if e.get("config") == config and e.get("kernel") == kernel_name and e.get("order") == order and int(e.get("frames_per_launch") or 1) == fpl:
             return e
     return None
+
+
+def seeded_camera(rto, np, seed, grid):
+    """The camera generator of tests/test_gpu_parity.py::test_random_cameras_at_full_size (same seeds, same draws): far, near, inside
+    the volume, looking past it; fov 30 / 45 / 70."""
+    dims = np.array(grid.dims, np.float32)
+    ext = float(dims.max() * np.float32(grid.voxelSize))
+    centre = np.asarray(grid.min, np.float32) + 0.5 * dims * np.float32(grid.voxelSize)
+    rng = np.random.default_rng(77000 + seed)
+    kind = ("far", "near", "inside", "past")[seed % 4]
+    radius = ext * {"far": rng.uniform(1.5, 5.0), "near": rng.uniform(0.55, 1.0), "inside": rng.uniform(0.05, 0.45), "past": rng.uniform(0.8, 2.0)}[kind]
+    cam = rto.Camera(float(rng.uniform(0, 6.28)), float(rng.uniform(-1.4, 1.4)), float(radius))
+    aim = rng.uniform(-0.15, 0.15, 3) if kind != "past" else rng.uniform(0.6, 1.2, 3) * rng.choice([-1.0, 1.0], 3)
+    cam.setTarget(centre + aim.astype(np.float32) * ext)
+    fov = float(rng.choice([30.0, 45.0, 70.0]))
+    return cam, fov, kind
+
+
+def valu_frac(config, kernel_name, ms):
+    """roofline.frac of a leg from the committed PMC entry of (config, kernel): SQ_INSTS_VALU per launch / ms / the 2-cycle VALU peak."""
+    pmc = pmc_entry(config, kernel_name, "temporal", 1)
+    if pmc is None or not ms:
+        return None
+    insts = float(pmc["SQ_INSTS_VALU"])
+    return {"bound": "valu_issue", "frac": round(insts / (ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4), "valu_insts_per_launch": int(insts),
+            "lane_utilisation": round(float(pmc["SQ_THREAD_CYCLES_VALU"]) / (64.0 * insts), 3) if pmc.get("SQ_THREAD_CYCLES_VALU") else None,
+            "traffic": pmc.get("hbm_bytes_per_launch"), "pmc_matches_this_build": pmc.get("device_source_hash") == device_source_hash()}
+
+
+def extras(args, local_rank, stream, main_ctx, main_grid, main_frame, main_img, small=False):
+    """The legs behind the headline of the default run: every figure one plain launch per frame on `stream`,
+    every leg checked bitwise against the oracle on one frame, outside every timed region.  small: the contract test's sizes
+    (a reduced headline scene brings reduced legs: config 5 at 64^3 / 640x360, config 4 at 480x270, 8 cameras, N = 2 only)."""
+    import argparse as _ap
+
+    import numpy as np
+    import torch
+
+    import ray_tracing_octrees_amd as rto
+    from oracle import orc   # the checker, outside every timed region
+    from ray_tracing_octrees_amd import hip as _hip
+
+    cores = host_cores()
+    out = {}
+    K = max(1, args.extras_steps)
+
+    def timed_block(fn, n):
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record(stream); eb.record(stream); torch.cuda.synchronize()
+        t = time.perf_counter()
+        ea.record(stream)
+        for _ in range(n):
+            fn()
+        eb.record(stream)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3, ea.elapsed_time(eb) / n
+
+    # ---- configs 4 and 5: scene built by rto_build_octree in a context of its own, short disclosed ramp, K plain launches
+    configs = {}
+    for name in ("4", "5"):
+        t_leg = time.perf_counter()
+        cfg = CONFIGS[name]
+        W, H = cfg["width"], cfg["height"]
+        if small:
+            W, H = (640, 360) if name == "5" else (480, 270)
+        tri = cfg["mode"] == "triangles"
+        grid, cam, short, what, camtxt = build_scene(_ap.Namespace(config=name, dim=64 if (small and name == "5") else None))
+        c = rto.Context(local_rank)
+        t_b = time.perf_counter()
+        c.build_octree(grid.data, grid.min, grid.voxelSize)
+        if tri:
+            c.build_leaf_triangles(None)
+        c.synchronize()
+        build_ms = (time.perf_counter() - t_b) * 1e3
+        fr = rto.make_frame(cam.getView(), cam.getPos(), W / H, 45.0, W, H)
+        fb = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+        render = (lambda: c.render_triangles_device(fr, fb.data_ptr(), True, None, stream.cuda_stream)) if tri else \
+                 (lambda: c.render_device(fr, fb.data_ptr(), None, stream.cuda_stream))
+        c.timing_begin(-1)
+        ramp = 0
+        t_end = time.perf_counter() + 0.1
+        while time.perf_counter() < t_end:
+            for _ in range(5):
+                render()
+            torch.cuda.synchronize(); ramp += 5
+        wall_ms, gpu_ms = timed_block(render, K)
+        c.timing_begin(K)
+        for _ in range(K):
+            render()
+        kms = sorted(float(x) for x in c.timing_read())
+        c.timing_begin(-1)
+        got = fb.cpu().numpy()
+        nodes = c.download_nodes()
+        if tri:
+            og = orc.Grid(grid.dims, grid.min, grid.voxelSize, grid.data)
+            tris, off = orc.build_leaf_triangles(og, nodes)
+            want, ost = orc.render_triangles(nodes, tris, off, grid.min, grid.voxelSize, cam.getView(), cam.getPos(), W / H, 45.0, W, H, shadow=True, nthreads=cores)
+            kname = "k_trace_lean_triangles"
+        else:
+            want, ost = orc.render(nodes, grid.min, grid.voxelSize, cam.getView(), cam.getPos(), W / H, 45.0, W, H, nthreads=cores)
+            kname = "k_trace_lean"
+        ok = got.tobytes() == np.ascontiguousarray(want, np.float32).tobytes()
+        if not ok:
+            sys.exit(f"bench: config {name}'s frame differs from the oracle's -- result void")
+        configs[name] = {
+            "workload": f"cfg{name}: {short}, {c.info().num_nodes} nodes, {W}x{H}{', MC triangles+shadow' if tri else ''}, {camtxt} fov45",
+            "steps": K, "ms_per_frame": round(wall_ms, 5), "gpu_ms_per_frame": round(gpu_ms, 5), "Mrays_per_s": round(W * H / wall_ms / 1e3, 1),
+            "kernel_ms_event_pair_median": round(kms[len(kms) // 2], 5),
+            "roofline": None if small else valu_frac(name, kname, gpu_ms), "kernel": kname,
+            "hit_rays": int(ost["hits"]), "verified_against_oracle": True,
+            "octree_build_ms": round(build_ms, 2), "built_by": "rto_build_octree" + (" + rto_build_leaf_triangles" if tri else "") + " (GPU; includes the H2D copy of the voxels)",
+            "clock_ramp": f"{ramp} untimed frames (100 ms) in a fresh context", "launches": "plain stream launches, one per frame, no per-launch events",
+            "leg_seconds": None}
+        c.close()
+        del fb
+        configs[name]["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+    out["configs"] = configs
+
+    # ---- cold: a fresh context of the headline's scene, 0.5 s of idle, then its first K frames with a per-launch event pair
+    W, H = main_frame.width, main_frame.height
+    c = rto.Context(local_rank)
+    c.build_octree(main_grid.data, main_grid.min, main_grid.voxelSize)
+    c.synchronize()
+    fb = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    c.timing_begin(K)
+    t = time.perf_counter()
+    for _ in range(K):
+        c.render_device(main_frame, fb.data_ptr(), None, stream.cuda_stream)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t) / K * 1e3
+    kms = [float(x) for x in c.timing_read()]
+    c.timing_begin(-1)
+    same = bool(torch.equal(fb, main_img))
+    if not same:
+        sys.exit("bench: the cold context's frame differs from the timed frame -- result void")
+    out["cold"] = {"frames": K, "ms_per_frame": round(wall, 5), "Mrays_per_s": round(W * H / wall / 1e3, 1),
+                   "first_frame_kernel_ms": round(kms[0], 5), "kernel_ms_mean": round(sum(kms) / len(kms), 5), "kernel_ms_max": round(max(kms), 5),
+                   "kernel_ms_each": [round(x, 4) for x in kms], "frame_equals_timed_frame": same,
+                   "what": "a FRESH context of the headline's scene (no launch-order table, no tile costs, no mask history), the GPU idle for 0.5 s, "
+                           f"then its first {K} frames as plain launches with a HIP event pair around each kernel: no clock ramp, no warm-up"}
+    c.close()
+
+    # ---- random cameras: 64 seeded jumps (tests' generator), ONE launch each on the headline's context
+    n_cam = 8 if small else 64
+    frames, kinds = [], []
+    for seed in range(n_cam):
+        cam, fov, kind = seeded_camera(rto, np, seed, main_grid)
+        frames.append((rto.make_frame(cam.getView(), cam.getPos(), W / H, fov, W, H), cam, fov))
+        kinds.append(kind)
+    # pass 1: the GPU at its working clock (100 ms of the headline's frame), then the 64 jumps back to back: kernel time per camera
+    main_ctx.timing_begin(-1)
+    t_end = time.perf_counter() + (0.0 if small else 0.1)
+    while True:
+        for _ in range(10):
+            main_ctx.render_device(main_frame, fb.data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize()
+        if time.perf_counter() >= t_end:
+            break
+    main_ctx.timing_begin(n_cam)
+    for fr, cam, fov in frames:
+        main_ctx.render_device(fr, fb.data_ptr(), None, stream.cuda_stream)
+    torch.cuda.synchronize()
+    kms = [float(x) for x in main_ctx.timing_read()]
+    main_ctx.timing_begin(-1)
+    # pass 2: the same jumps one call at a time, the host waiting for each frame (what an interactive caller sees; the GPU idles
+    # between calls and drops its clock); the first four frames go to the checker
+    for _ in range(10):
+        main_ctx.render_device(main_frame, fb.data_ptr(), None, stream.cuda_stream)
+    torch.cuda.synchronize()
+    walls = []
+    check = {}
+    for i, (fr, cam, fov) in enumerate(frames):
+        t = time.perf_counter()
+        main_ctx.render_device(fr, fb.data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize()
+        walls.append((time.perf_counter() - t) * 1e3)
+        if i < 4:
+            check[i] = fb.cpu().numpy()
+    nodes = main_ctx.download_nodes()
+    for i, got in check.items():
+        fr, cam, fov = frames[i]
+        want, _ = orc.render(nodes, main_grid.min, main_grid.voxelSize, cam.getView(), cam.getPos(), W / H, fov, W, H, nthreads=cores)
+        if got.tobytes() != np.ascontiguousarray(want, np.float32).tobytes():
+            sys.exit(f"bench: random camera {i} differs from the oracle's frame -- result void")
+    worst = max(range(n_cam), key=lambda i: kms[i])
+    out["random_cameras"] = {"cameras": n_cam, "kernel_ms_mean": round(sum(kms) / n_cam, 5), "kernel_ms_max": round(kms[worst], 5),
+                             "kernel_ms_median": round(median(kms), 5), "max_at_seed": worst, "max_kind": kinds[worst],
+                             "call_ms_mean": round(sum(walls) / n_cam, 5), "call_ms_max": round(max(walls), 5),
+                             "kernel_ms_mean_by_kind": {k: round(sum(kms[i] for i in range(n_cam) if kinds[i] == k) / max(1, kinds.count(k)), 5) for k in ("far", "near", "inside", "past")},
+                             "frames_verified_against_oracle": sorted(check),
+                             "what": f"{n_cam} seeded cameras of the headline's scene (the generator of tests' test_random_cameras_at_full_size: far / near / inside the "
+                                     "volume / looking past it, fov 30 / 45 / 70), each a JUMP from the one before: one launch per camera, its launch order and "
+                                     "rim learned from another camera; kernel_ms = the traversal kernel (event pair) with the jumps launched back to back on a GPU at its working clock, "
+                                     "call_ms = a second pass, launch + wait on the host per camera (the GPU idles between calls)"}
+    del fb
+
+    # ---- split rehearsal: this GPU playing ranks 0 and 1 of a 2 / 4 / 8-GPU split (rto_comm_debug_rehearse), 8 frames per gather
+    try:
+        import ctypes
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)                                   # RCCL's banner must not reach this process's one-line stdout
+        try:
+            comm = _hip.Comm(main_ctx, 1, 0, _hip.comm_unique_id(), band_rows=args.band_rows)
+        finally:
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
+        fpg = 8
+        arr = rto.Context.frame_array([main_frame] * fpg)
+        cf = torch.empty((fpg, H, W, 4), dtype=torch.float32, device="cuda")
+        comm.debug_set_rehearsal_clear(False)
+        comm.debug_set_timing(True)
+        reh = {}
+        for n in ((2,) if small else (2, 4, 8)):
+            for r in (0, 1):
+                comm.debug_rehearse(n, r)
+                t_end = time.perf_counter() + (0.0 if small else 0.08)          # untimed: back to the working clock, buffers of this split
+                while True:
+                    for _ in range(6):
+                        comm.submit(arr, cf.data_ptr(), H * W * 16, _hip.RESIDENT_OCTREE)
+                    comm.flush(COMM_TIMEOUT_MS)
+                    if time.perf_counter() >= t_end:
+                        break
+                t = time.perf_counter()
+                nb = 40
+                for _ in range(nb):
+                    comm.submit(arr, cf.data_ptr(), H * W * 16, _hip.RESIDENT_OCTREE)
+                comm.flush(COMM_TIMEOUT_MS)
+                ms = (time.perf_counter() - t) / (nb * fpg) * 1e3
+                rm, gm = comm.debug_last_timing()
+                sent, _whole = comm.debug_last_payload()
+                reh[f"N{n}_rank{r}"] = {"ms_per_frame": round(ms, 5), "render_ms_per_frame": round(rm / fpg, 5), "gather_assemble_ms_per_frame": round(gm / fpg, 5),
+                                        "payload_bytes_per_frame": sent * 4 // fpg}
+        comm.debug_rehearse(0)
+        comm.close()
+        reh["what"] = ("ONE GPU doing what rank r of N does per frame (render its bands, grouped send/recv with itself, assembly), 8 frames per gather, pipelined: "
+                       "per-rank cost of the split, no peer traffic; from 4 GPUs on rank 0 only gathers and assembles")
+        out["split_rehearsal"] = reh
+    except Exception as e:                                # no RCCL in this process: say so, keep the line
+        out["split_rehearsal"] = {"skipped": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def _trace(msg):
@@ -527,6 +778,52 @@ def main(argv=None):
         latency = {"payload_bytes_per_frame_and_rank": sent * 4, "payload_bytes_whole_rows": whole * 4,
                    "ms_per_frame": round(lat * 1e3, 5), "frames": n_lat,
                    "what": "rto_comm_submit of ONE frame + rto_comm_flush per frame: render part -> grouped send/recv -> assemble, host waits for each frame"}
+        # per-rank GPU time of a full batch: timed events around every rank's render and around its gather
+        # (+ rank 0's assembly), 5 batches each waited for; the line carries every rank's figure and the slowest
+        comm.debug_set_timing(True)
+        ptr = comm_frames.data_ptr() if rank == 0 else 0
+        rts, gts = [], []
+        for _ in range(5):
+            comm.submit(comm_arr, ptr, H * W * 16, comm_mode); comm.flush(COMM_TIMEOUT_MS)
+            rm, gm = comm.debug_last_timing()
+            rts.append(rm / fpg); gts.append(gm / fpg)
+        comm.debug_set_timing(False)
+        mine = {"rank": rank, "render_ms_per_frame": round(median(rts), 5), "gather_ms_per_frame": round(median(gts), 5)}
+        per_rank = [mine]
+        if dist is not None:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        ranks_seen = comm.ranks_seen()
+        if dist is not None:
+            seen = torch.tensor([float(ranks_seen)], dtype=torch.float64)
+            dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+            ranks_seen = int(seen.item())
+        rank_timing = {"ranks_seen": ranks_seen, "ranks_seen_how": "ncclCommCount of every rank's communicator (minimum over ranks)",
+                       "per_rank": per_rank,
+                       "render_ms_per_frame_max": max(p["render_ms_per_frame"] for p in per_rank),
+                       "gather_ms_per_frame_max": max(p["gather_ms_per_frame"] for p in per_rank),
+                       "what": f"GPU ms per frame of a batch of {fpg}, one batch at a time (no overlap between batches): render = this rank's bands (+ pack), "
+                               "gather = its grouped send / recv from the moment its parts were rendered (+ rank 0's assembly)"}
+        # like for like at N = 1: ONE GPU rendering the same batches whole (fpg frames per launch, the form every rank of the split uses)
+        n1 = None
+        if rank == 0 and not triangles and args.rehearse_world <= 1:
+            nb = min(8, fpg)
+            bb = torch.empty((nb, H, W, 4), dtype=torch.float32, device="cuda")
+            ba = rto.Context.frame_array([frame] * nb)
+            for _ in range(4):
+                ctx.render_batch_device(ba, bb.data_ptr(), H * W * 16, None, False, stream.cuda_stream)
+            torch.cuda.synchronize()
+            t_n = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                ctx.render_batch_device(ba, bb.data_ptr(), H * W * 16, None, False, stream.cuda_stream)
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - t_n) / (reps * nb) * 1e3
+            n1 = {"frames_per_launch": nb, "ms_per_frame": round(ms1, 5), "Mrays_per_s": round(rays / ms1 / 1e3, 1),
+                  "what": "rank 0's GPU alone, whole frames, the same number of frames per kernel launch as a batch of the split (rto_render_batch_device), "
+                          "measured behind the timed region while the other ranks wait: the 1-GPU figure `value` should be compared with"}
+            del bb
+        sync_all()
     _trace(f'latency leg done, rank {rank}')
     if rank == 0:
         kernel_name = KERNEL_NAMES[args.kernel] if info.canonical else "k_trace_generic"
@@ -856,11 +1153,23 @@ def main(argv=None):
             result["orbit"] = orbit
         if latency is not None:
             result["single_frame_latency"] = latency
+            result["batched_throughput"] = {"Mrays_per_s": result["value"], "ms_per_frame": result["ms_per_step"], "frames_per_gather": fpg,
+                                            "what": "`value`: batches of frames, gather k overlapping render k+1"}
+            result["rank_timing"] = rank_timing
+            result["ranks_seen"] = rank_timing["ranks_seen"]
+            if n1 is not None:
+                result["n1_comparator"] = n1
         if pcie is not None:
             result["pcie_inclusive"] = pcie
         if cpu is not None:
             result["cpu_baseline"] = cpu
             result["speedup_vs_cpu_all_cores"] = round(result["value"] / cpu["value"], 1)
+        if world == 1 and not use_comm and args.config == "2" and not args.no_extras and img is not None and args.kernel == "auto":
+            t_x = time.perf_counter()
+            small = bool(args.dim or args.width or args.height)
+            for k, v in extras(args, local_rank, stream, ctx, grid, frame, img, small).items():
+                result[k] = v
+            result["extras_seconds"] = round(time.perf_counter() - t_x, 1)
         _trace('printing the line')
         print(json.dumps(result), flush=True)
 

@@ -283,6 +283,10 @@ int  rto_comm_debug_rehearse(rto_comm* comm, int as_world, int as_rank);
  * travel, rank 0 paints the background itself -- and what whole rows would have been. */
 int  rto_comm_debug_set_rehearsal_clear(rto_comm* comm, int enabled);   /* rehearsals: per-batch clear of the absent ranks' rows (default on; timing runs switch it off) */
 int  rto_comm_debug_last_payload(const rto_comm* comm, int64_t* packed_floats, int64_t* full_floats);
+/* Bench aid: with timing on, every batch records four timed events; after its flush rto_comm_debug_last_timing gives the GPU
+ * milliseconds of the batch submitted last: ms[0] this rank's render (+ pack), ms[1] its grouped send / recv (+ rank 0's assembly). */
+int  rto_comm_debug_set_timing(rto_comm* comm, int enabled);
+int  rto_comm_debug_last_timing(rto_comm* comm, float ms[2]);
 void* rto_comm_stream(rto_comm* comm);            /* hipStream_t the gathers and (rank 0) the assembled frames are ordered on */
 
 /* ---- multi-GPU: the split plan (pure host arithmetic, no GPU needed) -----------------------------------------

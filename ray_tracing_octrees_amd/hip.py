@@ -32,7 +32,7 @@ SYMBOLS = (
     "rto_upload_leaf_triangles", "rto_build_leaf_triangles", "rto_download_leaf_triangles", "rto_render_triangles_device", "rto_render_triangles_host", "rto_render_triangles_shade_device",
     "rto_octree_ray_skip", "rto_frame_stats", "rto_render_steps_host", "rto_debug_timeline", "rto_debug_tile_cost", "rto_debug_set_tile_order", "rto_debug_sort_violations", "rto_last_kernel_ms", "rto_timing_begin", "rto_timing_read", "rto_stream", "rto_synchronize",
     "rto_comm_unique_id", "rto_comm_create", "rto_comm_create_all", "rto_comm_destroy", "rto_comm_last_error", "rto_comm_submit",
-    "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_flush_timeout", "rto_comm_is_dead", "rto_comm_ranks_seen", "rto_comm_debug_abort", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_comm_debug_last_payload", "rto_comm_debug_set_rehearsal_clear", "rto_debug_fault_alloc", "rto_render_triangles_batch_device",
+    "rto_comm_submit_all", "rto_comm_render_resident_all", "rto_comm_flush", "rto_comm_flush_timeout", "rto_comm_is_dead", "rto_comm_ranks_seen", "rto_comm_debug_abort", "rto_comm_stream", "rto_comm_debug_rehearse", "rto_comm_debug_last_payload", "rto_comm_debug_set_timing", "rto_comm_debug_last_timing", "rto_comm_debug_set_rehearsal_clear", "rto_debug_fault_alloc", "rto_render_triangles_batch_device",
     "rto_debug_set_tile_mask", "rto_debug_tile_mask_info", "rto_render_closest_device", "rto_render_closest_host", "rto_render_skip_device", "rto_render_skip_host", "rto_probe_skip_device", "rto_probe_skip_host",
     "rto_scene_bounds_get", "rto_scene_bounds_of_nodes", "rto_split_plan_make", "rto_split_part_of_rank", "rto_split_rows_of_part", "rto_split_row_source",
 )
@@ -181,6 +181,8 @@ def load():
     L.rto_comm_debug_abort.argtypes = [vp]
     L.rto_comm_debug_rehearse.argtypes = [vp, C.c_int, C.c_int]
     L.rto_comm_debug_set_rehearsal_clear.argtypes = [vp, C.c_int]
+    L.rto_comm_debug_set_timing.argtypes = [vp, C.c_int]
+    L.rto_comm_debug_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
     L.rto_debug_fault_alloc.argtypes = [C.c_long]
     L.rto_comm_debug_last_payload.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.rto_render_triangles_batch_device.argtypes = [vp, C.POINTER(Frame), C.c_int, C.POINTER(Partition), C.c_int, C.c_int, vp, C.c_size_t, vp]
@@ -623,6 +625,15 @@ class Comm:
 
     def debug_set_rehearsal_clear(self, enabled: bool):
         self._check(self._L.rto_comm_debug_set_rehearsal_clear(self._h, 1 if enabled else 0))
+
+    def debug_set_timing(self, enabled: bool):
+        self._check(self._L.rto_comm_debug_set_timing(self._h, 1 if enabled else 0))
+
+    def debug_last_timing(self):
+        """(render ms, gather (+ assembly on rank 0) ms) of the batch submitted last; call after flush()."""
+        ms = (C.c_float * 2)()
+        self._check(self._L.rto_comm_debug_last_timing(self._h, ms))
+        return float(ms[0]), float(ms[1])
 
     def debug_rehearse(self, as_world: int, as_rank: int = 0):
         """One-rank communicator only: split frames as rank `as_rank` of `as_world` GPUs (0 switches it off)."""

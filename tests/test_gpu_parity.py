@@ -2319,6 +2319,20 @@ def test_bench_line_contract_small_run():
     assert d["dropin_call"]["ms_per_call"] > 0 and d["dropin_call"]["frame_equals_timed_frame"] is True
     assert len(d["config"]["workload"]) <= 120 and d["config"]["workload"].startswith("cfg2:") and len(d["config"]["clock_ramp"]) <= 120
     assert "one kernel launch per frame" in d["config"]["parallelism"] and d["roofline"]["kernel_ms_event_pair_median"] > 0
+    # the legs behind the headline (round 5): configs 4 and 5, a cold context, camera jumps, the split rehearsed -- reduced sizes here
+    for name in ("4", "5"):
+        c = d["configs"][name]
+        assert c["verified_against_oracle"] is True and c["ms_per_frame"] > 0 and c["Mrays_per_s"] > 0 and c["steps"] == 20 and c["hit_rays"] > 0
+        assert c["workload"].startswith(f"cfg{name}:") and "roofline" in c
+    assert d["configs"]["5"]["kernel"] == "k_trace_lean_triangles"
+    assert d["cold"]["frames"] == 20 and len(d["cold"]["kernel_ms_each"]) == 20 and d["cold"]["frame_equals_timed_frame"] is True
+    assert d["cold"]["first_frame_kernel_ms"] > 0 and d["cold"]["ms_per_frame"] > 0
+    rc = d["random_cameras"]
+    assert rc["cameras"] == 8 and rc["kernel_ms_max"] >= rc["kernel_ms_mean"] > 0 and rc["frames_verified_against_oracle"] == [0, 1, 2, 3]
+    sr = d["split_rehearsal"]
+    assert "skipped" not in sr, sr
+    for k in ("N2_rank0", "N2_rank1"):
+        assert sr[k]["ms_per_frame"] > 0 and sr[k]["render_ms_per_frame"] > 0 and sr[k]["gather_assemble_ms_per_frame"] > 0
 
 
 def test_camera_a_hair_outside_the_root_box(ctx, orc):
