@@ -196,6 +196,131 @@ def policy_speculate(rays, batch=16, K=2, heads_only=True, full_chunks=False):
     return dict(bodies=bodies, rounds=rounds, chunks=chunks, pairs=pairs, lane_trips=lane_trips, wasted=wasted)
 
 
+def policy_carry(rays, batch=16, pair_threshold=0, full_only=True):
+    """The present policy, but a round tests only FULL chunks of 64 pairs (the remainder's leaves keep waiting, with their progress kept)
+    unless nobody can walk; pair_threshold > 0: the round starts when that many pairs wait (instead of `batch` lanes)."""
+    lanes = [Lane(r) for r in rays]
+    left = [0] * 64         # pairs of the waiting leaf not tested yet
+    bodies = rounds = chunks = pairs = lane_trips = 0
+
+    def is_leaf(c):
+        return isinstance(c, int) and c != 0
+
+    while True:
+        for i, l in enumerate(lanes):
+            if is_leaf(l.cur()) and left[i] == 0:
+                left[i] = abs(l.cur())
+        waiting = sum(1 for l in lanes if is_leaf(l.cur()))
+        wpairs = sum(left)
+        trig = (lambda: wpairs >= pair_threshold) if pair_threshold else (lambda: waiting >= batch)
+        if not trig():
+            while True:
+                alive = [(i, l) for i, l in enumerate(lanes) if l.cur() == 0]
+                if not alive:
+                    break
+                bodies += 1
+                lane_trips += len(alive)
+                for i, l in alive:
+                    l.pos += 1
+                    c = l.cur()
+                    if is_leaf(c):
+                        waiting += 1
+                        left[i] = abs(c)
+                        wpairs += abs(c)
+                if trig():
+                    break
+        rounds += 1
+        anyone_walks = any(l.cur() == 0 for l in lanes)
+        tot = sum(left)
+        budget = (tot // 64) * 64 if (full_only and anyone_walks and tot >= 64) else tot
+        if full_only and anyone_walks and tot < 64:
+            budget = tot                      # a round was asked for with less than a chunk: test it (the trigger decides how often)
+        used = 0
+        for i, l in enumerate(lanes):
+            if left[i] == 0:
+                continue
+            take = min(left[i], budget - used)
+            used += take
+            left[i] -= take
+            if left[i] == 0:
+                c = l.cur()
+                l.pos += 1
+                if c < 0:
+                    l.next_ray()
+            if used >= budget:
+                break
+        chunks += (used + 63) // 64
+        pairs += used
+        for l in lanes:
+            if l.cur() == "end":
+                l.next_ray()
+        if all(l.cur() is None for l in lanes):
+            break
+    return dict(bodies=bodies, rounds=rounds, chunks=chunks, pairs=pairs, lane_trips=lane_trips)
+
+
+def policy_dual(raysA, raysB, batch=16, switch_in_round=True):
+    """Two tiles per wave: lane l owns a ray context of each; a body serves the first of its contexts that can walk.  A round tests the
+    waiting leaves of both sets."""
+    A = [Lane(r) for r in raysA]
+    B = [Lane(r) for r in raysB]
+    bodies = rounds = chunks = pairs = lane_trips = 0
+    is_leaf = lambda c: isinstance(c, int) and c != 0
+    while True:
+        waiting = sum(1 for l in A + B if is_leaf(l.cur()))
+        chosen = [a if a.cur() == 0 else b for a, b in zip(A, B)]       # switch_in_round = False: a lane's context is fixed for the round
+        if waiting < batch:
+            while True:
+                act = []
+                if switch_in_round:
+                    for a, b in zip(A, B):
+                        if a.cur() == 0:
+                            act.append(a)
+                        elif b.cur() == 0:
+                            act.append(b)
+                else:
+                    act = [c for c in chosen if c.cur() == 0]
+                if not act:
+                    break
+                bodies += 1
+                lane_trips += len(act)
+                for l in act:
+                    l.pos += 1
+                    if is_leaf(l.cur()):
+                        waiting += 1
+                if waiting >= batch:
+                    break
+        rounds += 1
+        tot = 0
+        for l in A + B:
+            c = l.cur()
+            if is_leaf(c):
+                tot += abs(c)
+                l.pos += 1
+                if c < 0:
+                    l.next_ray()
+        chunks += (tot + 63) // 64
+        pairs += tot
+        for l in A + B:
+            if l.cur() == "end":
+                l.next_ray()
+        if all(l.cur() is None for l in A + B):
+            break
+    return dict(bodies=bodies, rounds=rounds, chunks=chunks, pairs=pairs, lane_trips=lane_trips)
+
+
+def run_dual(name, **kw):
+    tot = {}
+    n = len(ev) // 2
+    for t in range(n):
+        r = policy_dual(rays_of_tile(2 * t), rays_of_tile(2 * t + 1), **kw)
+        for k, v in r.items():
+            tot[k] = tot.get(k, 0) + v
+    est = tot["bodies"] * 137 + tot["rounds"] * 110 + tot["chunks"] * 87
+    print(f"{name:44s} PER TILE: bodies {tot['bodies'] / n / 2:6.1f} (util {tot['lane_trips'] / tot['bodies'] / 64:.2f})  rounds {tot['rounds'] / n / 2:5.1f}  chunks {tot['chunks'] / n / 2:5.1f} "
+          f"(fill {tot['pairs'] / max(1, tot['chunks']) / 64:.2f})  est. instr/tile {est / n / 2:7.0f}")
+
+
 def run(name, fn, **kw):
     tot = {}
     for t in range(len(ev)):
@@ -215,5 +340,21 @@ for b in (8, 12, 24):
 for K in (1, 2, 3):
     for b in (16, 24, 32):
         run(f"speculate K={K}, round at {b} filed, heads", policy_speculate, batch=b, K=K)
+for b in (12, 16, 24, 32, 48):
+    run_dual(f"two tiles per wave, round at {b} waiting", batch=b)
+for b in (12, 16, 24, 32):
+    run_dual(f"two tiles, context switch at round ends only, {b}", batch=b, switch_in_round=False)
+for b in (12, 16, 20):
+    run(f"full chunks only, round at {b} lanes", policy_carry, batch=b)
+for pt in (48, 64, 96, 128):
+    run(f"round at {pt} waiting pairs, every pair tested", policy_carry, pair_threshold=pt, full_only=False)
+    run(f"round at {pt} waiting pairs, full chunks only", policy_carry, pair_threshold=pt, full_only=True)
 run("speculate K=2, round at 16, all filed tests", policy_speculate, batch=16, K=2, heads_only=False)
 run("speculate K=3, round at 24, all filed tests", policy_speculate, batch=24, K=3, heads_only=False)
+
+# ---- where the idle lanes of the node loop come from
+mx = tot = n = 0
+for t in range(len(ev)):
+    per_lane = [sum(1 for r in rs for e in r if e == 0) for rs in rays_of_tile(t)]
+    mx += max(per_lane); tot += sum(per_lane); n += 1
+print(f"per wave: lane-trips / 64 = {tot / n / 64:.1f} bodies (perfect packing); busiest lane's trips = {mx / n:.1f} (no waiting at all); the present policy issues more than either (first line)")
