@@ -463,6 +463,14 @@ def extras(args, local_rank, stream, main_ctx, main_grid, main_frame, main_img, 
     torch.cuda.synchronize()
     kms = [float(x) for x in main_ctx.timing_read()]
     main_ctx.timing_begin(-1)
+    # pass 1b: every camera once more, 5 frames each: the time of the 5th is what the jump costs once the launch order has settled
+    main_ctx.timing_begin(n_cam * 5)
+    for fr, cam, fov in frames:
+        for _ in range(5):
+            main_ctx.render_device(fr, fb.data_ptr(), None, stream.cuda_stream)
+    torch.cuda.synchronize()
+    settled = [float(x) for x in main_ctx.timing_read()][4::5]
+    main_ctx.timing_begin(-1)
     # pass 2: the same jumps one call at a time, the host waiting for each frame (what an interactive caller sees; the GPU idles
     # between calls and drops its clock); the first four frames go to the checker
     for _ in range(10):
@@ -486,12 +494,15 @@ def extras(args, local_rank, stream, main_ctx, main_grid, main_frame, main_img, 
     worst = max(range(n_cam), key=lambda i: kms[i])
     out["random_cameras"] = {"cameras": n_cam, "kernel_ms_mean": round(sum(kms) / n_cam, 5), "kernel_ms_max": round(kms[worst], 5),
                              "kernel_ms_median": round(median(kms), 5), "max_at_seed": worst, "max_kind": kinds[worst],
+                             "kernel_ms_mean_settled": round(sum(settled) / n_cam, 5), "kernel_ms_max_settled": round(max(settled), 5),
+                             "jump_penalty_mean": round(sum(kms) / sum(settled), 3),
                              "call_ms_mean": round(sum(walls) / n_cam, 5), "call_ms_max": round(max(walls), 5),
                              "kernel_ms_mean_by_kind": {k: round(sum(kms[i] for i in range(n_cam) if kinds[i] == k) / max(1, kinds.count(k)), 5) for k in ("far", "near", "inside", "past")},
                              "frames_verified_against_oracle": sorted(check),
                              "what": f"{n_cam} seeded cameras of the headline's scene (the generator of tests' test_random_cameras_at_full_size: far / near / inside the "
                                      "volume / looking past it, fov 30 / 45 / 70), each a JUMP from the one before: one launch per camera, its launch order and "
-                                     "rim learned from another camera; kernel_ms = the traversal kernel (event pair) with the jumps launched back to back on a GPU at its working clock, "
+                                     "rim learned from another camera; *_settled: the 5th consecutive frame of the same camera (its own order and rim), so jump_penalty_mean = what the stale "
+                                     "schedule costs; kernel_ms = the traversal kernel (event pair) with the jumps launched back to back on a GPU at its working clock, "
                                      "call_ms = a second pass, launch + wait on the host per camera (the GPU idles between calls)"}
     del fb
 
@@ -806,21 +817,27 @@ def main(argv=None):
                                "gather = its grouped send / recv from the moment its parts were rendered (+ rank 0's assembly)"}
         # like for like at N = 1: ONE GPU rendering the same batches whole (fpg frames per launch, the form every rank of the split uses)
         n1 = None
-        if rank == 0 and not triangles and args.rehearse_world <= 1:
-            nb = min(8, fpg)
+        if rank == 0 and args.rehearse_world <= 1:
+            nb = min(4 if triangles else 8, fpg)          # config 5: 4 x 133 MB of frames
             bb = torch.empty((nb, H, W, 4), dtype=torch.float32, device="cuda")
             ba = rto.Context.frame_array([frame] * nb)
+
+            def whole_batch():
+                if triangles:
+                    ctx.render_triangles_batch_device(ba, bb.data_ptr(), H * W * 16, True, None, False, stream.cuda_stream)
+                else:
+                    ctx.render_batch_device(ba, bb.data_ptr(), H * W * 16, None, False, stream.cuda_stream)
             for _ in range(4):
-                ctx.render_batch_device(ba, bb.data_ptr(), H * W * 16, None, False, stream.cuda_stream)
+                whole_batch()
             torch.cuda.synchronize()
             t_n = time.perf_counter()
             reps = 10
             for _ in range(reps):
-                ctx.render_batch_device(ba, bb.data_ptr(), H * W * 16, None, False, stream.cuda_stream)
+                whole_batch()
             torch.cuda.synchronize()
             ms1 = (time.perf_counter() - t_n) / (reps * nb) * 1e3
             n1 = {"frames_per_launch": nb, "ms_per_frame": round(ms1, 5), "Mrays_per_s": round(rays / ms1 / 1e3, 1),
-                  "what": "rank 0's GPU alone, whole frames, the same number of frames per kernel launch as a batch of the split (rto_render_batch_device), "
+                  "what": "rank 0's GPU alone, whole frames, several frames per kernel launch as every rank of the split renders them (rto_render_[triangles_]batch_device), "
                           "measured behind the timed region while the other ranks wait: the 1-GPU figure `value` should be compared with"}
             del bb
         sync_all()

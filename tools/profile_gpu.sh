@@ -9,7 +9,7 @@
 set -u
 TAG=${1:-r03}; shift || true
 CONFIG=${1:-2}; shift || true
-ARGS="--config $CONFIG --cpu-frames 0 --no-verify --orbit-frames 0 --dropin-frames 0 $*"
+ARGS="--config $CONFIG --cpu-frames 0 --no-verify --orbit-frames 0 --dropin-frames 0 --no-extras $*"
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

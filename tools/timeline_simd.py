@@ -7,11 +7,19 @@ import numpy as np
 import ray_tracing_octrees_amd as rto
 
 dim, W, H = 256, 1920, 1080
-g = rto.VoxelGrid.test_sphere(dim)
+config = next((a.split("=")[1] for a in sys.argv if a.startswith("config=")), "2")      # config=4: Calgary as shipped, oblique camera
 ctx = rto.Context(0)
-ctx.build_octree(g.data, g.min, g.voxelSize)
 theta = float(next((a.split("=")[1] for a in sys.argv if a.startswith("theta=")), 0.5))
-cam = rto.Camera(theta, 0.7, 1.8)
+if config == "4":
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_scene_cache.npz"))
+    dims = tuple(int(x) for x in z["dims"])
+    data = np.unpackbits(z["packed"])[: dims[0] * dims[1] * dims[2]].reshape(dims[2], dims[1], dims[0])
+    g = rto.VoxelGrid.from_array(data, z["min"].astype(np.float32), np.float32(z["voxel"]))
+    cam = rto.Camera(0.6, 0.5, 3500.0)
+else:
+    g = rto.VoxelGrid.test_sphere(dim)
+    cam = rto.Camera(theta, 0.7, 1.8)
+ctx.build_octree(g.data, g.min, g.voxelSize)
 f = rto.make_frame(cam.getView(), cam.getPos(), W / H, 45.0, W, H)
 if "nomask" in sys.argv:
     ctx.debug_set_tile_mask(False)
@@ -43,6 +51,20 @@ tx = (W + 7) // 8
 us, inv = np.unique(skey, return_inverse=True)
 tot_it = np.bincount(inv, weights=it); cnt = np.bincount(inv); last = np.zeros(len(us)); np.maximum.at(last, inv, e)
 print("per SIMD: waves mean %.1f max %d | iterations mean %.0f max %d | last end mean %.1f p90 %.1f max %.1f" % (cnt.mean(), cnt.max(), tot_it.mean(), tot_it.max(), last.mean(), np.percentile(last, 90), last.max()))
+jout = next((a.split("=")[1] for a in sys.argv if a.startswith("json=")), None)
+if jout:
+    import json
+    livew = it > 0
+    busy = np.zeros(len(us)); np.add.at(busy, inv, (e - s) * (it > 0))
+    json.dump({"config": config, "waves": int(len(rec)), "live_waves": int(livew.sum()), "kernel_span_us": float(e.max()), "simds": int(len(us)),
+               "per_simd": {"waves_mean": float(cnt.mean()), "waves_max": int(cnt.max()), "trips_mean": float(tot_it.mean()), "trips_max": int(tot_it.max()),
+                            "trips_p10": float(np.percentile(tot_it, 10)), "trips_p90": float(np.percentile(tot_it, 90)),
+                            "last_end_us_mean": float(last.mean()), "last_end_us_p10": float(np.percentile(last, 10)), "last_end_us_max": float(last.max())},
+               "longest_wave": {"trips": int(it.max()), "duration_us": float((e - s)[np.argmax(it)]), "end_us": float(e[np.argmax(it)])},
+               "trips_total": int(it.sum()),
+               "issue_floor_us": {"loop": float(tot_it.mean() * 120 * 3.35 / 2.4e3), "loop_of_the_busiest_simd": float(tot_it.max() * 120 * 3.35 / 2.4e3),
+                                  "how": "trips per SIMD x 120 VALU instructions x 3.35 cycles (measured issue cost of the loop's mix) / 2.4 GHz; prologues and epilogues (~330 instructions per live wave) come on top"},
+               "live_waves_ended_by_us": {str(q): float(np.percentile(e[livew], q)) for q in (50, 90, 99, 100)}}, open(jout, "w"), indent=1)
 order = np.argsort(-last)[:3]
 for k in order:
     m = np.nonzero(inv == k)[0]
