@@ -309,11 +309,60 @@ def policy_dual(raysA, raysB, batch=16, switch_in_round=True):
     return dict(bodies=bodies, rounds=rounds, chunks=chunks, pairs=pairs, lane_trips=lane_trips)
 
 
+def policy_dual_parked(raysA, raysB, batch=16):
+    """Two tiles per wave, the simple form: a lane's second context is PARKED (registers swapped at a round's end when the active one
+    cannot walk and the parked one can); a round tests the ACTIVE contexts' leaves only."""
+    act = [Lane(r) for r in raysA]
+    par = [Lane(r) for r in raysB]
+    bodies = rounds = chunks = pairs = lane_trips = swaps = 0
+    is_leaf = lambda c: isinstance(c, int) and c != 0
+    while True:
+        waiting = sum(1 for l in act if is_leaf(l.cur()))
+        if waiting < batch:
+            while True:
+                alive = [l for l in act if l.cur() == 0]
+                if not alive:
+                    break
+                bodies += 1
+                lane_trips += len(alive)
+                for l in alive:
+                    l.pos += 1
+                    if is_leaf(l.cur()):
+                        waiting += 1
+                if waiting >= batch:
+                    break
+        rounds += 1
+        tot = 0
+        for l in act:
+            c = l.cur()
+            if is_leaf(c):
+                tot += abs(c)
+                l.pos += 1
+                if c < 0:
+                    l.next_ray()
+        chunks += (tot + 63) // 64
+        pairs += tot
+        for l in act:
+            if l.cur() == "end":
+                l.next_ray()
+        sw = False
+        for i in range(64):
+            a, b = act[i], par[i]
+            if a.cur() != 0 and (b.cur() == 0 or (a.cur() is None and b.cur() is not None)):
+                act[i], par[i] = b, a
+                sw = True
+        swaps += 1 if sw else 0
+        if all(l.cur() is None for l in act + par):
+            break
+    return dict(bodies=bodies, rounds=rounds, chunks=chunks, pairs=pairs, lane_trips=lane_trips, swaps=swaps)
+
+
 def run_dual(name, **kw):
     tot = {}
     n = len(ev) // 2
+    fn = kw.pop("fn", policy_dual)
     for t in range(n):
-        r = policy_dual(rays_of_tile(2 * t), rays_of_tile(2 * t + 1), **kw)
+        r = fn(rays_of_tile(2 * t), rays_of_tile(2 * t + 1), **kw)
         for k, v in r.items():
             tot[k] = tot.get(k, 0) + v
     est = tot["bodies"] * 137 + tot["rounds"] * 110 + tot["chunks"] * 87
@@ -344,6 +393,8 @@ for b in (12, 16, 24, 32, 48):
     run_dual(f"two tiles per wave, round at {b} waiting", batch=b)
 for b in (12, 16, 24, 32):
     run_dual(f"two tiles, context switch at round ends only, {b}", batch=b, switch_in_round=False)
+for b in (8, 12, 16, 24):
+    run_dual(f"two tiles, second context parked, round at {b}", batch=b, fn=policy_dual_parked)
 for b in (12, 16, 20):
     run(f"full chunks only, round at {b} lanes", policy_carry, batch=b)
 for pt in (48, 64, 96, 128):
