@@ -62,3 +62,35 @@ def test_the_watchdog_lets_a_finished_job_through():
                        capture_output=True, text=True, env=env, timeout=120)
     assert p.returncode == 0, p.stderr
     assert p.stdout.strip() == '{"metric": "stub", "value": 1}'
+
+
+def test_bench_camera_jumps_are_the_test_suites_cameras():
+    """bench.py's `random_cameras` leg says it uses the generator of test_random_cameras_at_full_size: the same seeds must give the
+    same view matrices, positions and fields of view (the product's Camera against the oracle's, both pinned to the reference's)."""
+    import importlib.util
+
+    import numpy as np
+
+    import ray_tracing_octrees_amd as rto
+    from oracle import orc
+
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    grid = rto.VoxelGrid.test_sphere(32)
+    og = orc.test_sphere_grid(32)
+    dims = np.array(og.dims, np.float32)
+    ext = float(dims.max() * og.voxel_size)
+    centre = np.asarray(og.min, np.float32) + 0.5 * dims * np.float32(og.voxel_size)
+    for seed in range(12):
+        cam, fov, kind = bench.seeded_camera(rto, np, seed, grid)
+        rng = np.random.default_rng(77000 + seed)                       # tests/test_gpu_parity.py, verbatim
+        k2 = ("far", "near", "inside", "past")[seed % 4]
+        radius = ext * {"far": rng.uniform(1.5, 5.0), "near": rng.uniform(0.55, 1.0), "inside": rng.uniform(0.05, 0.45), "past": rng.uniform(0.8, 2.0)}[k2]
+        oc = orc.Camera(float(rng.uniform(0, 6.28)), float(rng.uniform(-1.4, 1.4)), float(radius))
+        aim = rng.uniform(-0.15, 0.15, 3) if k2 != "past" else rng.uniform(0.6, 1.2, 3) * rng.choice([-1.0, 1.0], 3)
+        oc.set_target(*[float(x) for x in centre + aim.astype(np.float32) * ext])
+        fov2 = float(rng.choice([30.0, 45.0, 70.0]))
+        assert (kind, fov) == (k2, fov2)
+        assert np.asarray(cam.getView(), np.float32).tobytes() == np.asarray(oc.get_view(), np.float32).tobytes(), seed
+        assert np.asarray(cam.getPos(), np.float32).tobytes() == np.asarray(oc.get_pos(), np.float32).tobytes(), seed
