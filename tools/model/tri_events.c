@@ -36,7 +36,21 @@ static int trace_events(const orc_node* nodes, const float* tris, const int32_t*
                 float t;
                 if (ray_triangle(ro, rd, tris + (size_t)k * 12, &t) && t < bestT) { bestT = t; best = k; }
             }
-            if (n < cap) ev[n++] = (int16_t)(best >= 0 ? -cnt : cnt);
+            int code = best >= 0 ? -cnt : cnt;
+            if (best < 0) {
+                /* would a box around the leaf's triangles, widened by 1e-3 voxel, have rejected the ray?  (study only: +1000 marks it) */
+                v3 lo = v3_(1e30f, 1e30f, 1e30f), hi = v3_(-1e30f, -1e30f, -1e30f);
+                for (int k = triOffset[nodeIdx]; k < triOffset[nodeIdx + 1]; k++)
+                    for (int vtx = 0; vtx < 3; vtx++) {
+                        const float* P3 = tris + (size_t)k * 12 + vtx * 3;
+                        lo = v3_(gmin(lo.x, P3[0]), gmin(lo.y, P3[1]), gmin(lo.z, P3[2]));
+                        hi = v3_(gmax(hi.x, P3[0]), gmax(hi.y, P3[1]), gmax(hi.z, P3[2]));
+                    }
+                float m = vs * 1e-3f, tn, tf;
+                lo = v3_(lo.x - m, lo.y - m, lo.z - m); hi = v3_(hi.x + m, hi.y + m, hi.z + m);
+                if (!intersect_aabb(ro, rd, lo, hi, &tn, &tf)) code += 1000;
+            }
+            if (n < cap) ev[n++] = (int16_t)code;
             if (best >= 0) {
                 r.hit = 1; r.t = bestT;
                 r.normal = v3_(tris[(size_t)best * 12 + 9], tris[(size_t)best * 12 + 10], tris[(size_t)best * 12 + 11]);
