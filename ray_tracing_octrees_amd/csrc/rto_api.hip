@@ -33,6 +33,8 @@ struct rto_context {
     int64_t numInternal = 0;
     int rootSize = 0, depth = 0;
     bool canonical = false;
+    bool exactGridAllowed = true;   // rto_debug_set_exact_grid(0): the general 12-plane child test whatever the grid (tests, A/B)
+    bool exactGrid = false;         // every node plane gridMin + k * voxelSize (k = 0 .. rootSize) is computed without rounding: see grid_is_exact
     float gridMin[3] = { 0, 0, 0 };
     float voxelSize = 1.f;
     int kernelMode = RTO_KERNEL_AUTO;
@@ -427,8 +429,29 @@ struct BuildScratch {
 // occupancy mask -- the deepest level whose cells (internal nodes at that depth + solid leaves at or above it) number at most
 // kMaskMaxCells.
 constexpr int kMaskMaxCells = 8192;      // config 2: 5,624 cells (depth 5) serve as well as 20,504 (depth 6): 38.7 us either way; projecting them costs a quarter
+// Does the reference's node-box arithmetic (S/RT:265-266: nodeMin = gridMin + vec3(x, y, z) * voxelSize, nodeMax = nodeMin + vec3(size) *
+// voxelSize, in float) round anywhere on this grid?  If for every k = 0 .. rootSize the product k * voxelSize and the sum gridMin + that
+// product are exact, every plane of every node is the real number gridMin + k * voxelSize, and a child's max plane (min + size *
+// voxelSize) IS its upper sibling's min plane, bit for bit: the lean kernels then compute 9 plane parameters per trip instead of 12
+// (child_axis_terms_exact) -- the same floats by construction.  True for power-of-two voxel sizes on "round" origins (the test spheres:
+// -0.5, 2^-8) and for integer grids (sceneCache.bin: origin (-2125, -1215, -150), voxel 10); any other grid takes the general form.
+static bool grid_is_exact(const float gridMin[3], float voxelSize, int rootSize) {
+    if (!(voxelSize > 0.0f) || !std::isfinite(voxelSize) || rootSize <= 0 || rootSize > (1 << 20)) return false;
+    for (int a = 0; a < 3; a++) {
+        if (!std::isfinite(gridMin[a])) return false;
+        for (int k = 0; k <= rootSize; k++) {
+            const volatile float prod = (float)k * voxelSize;               // the kernels' own operations, one rounding each
+            const volatile float sum = gridMin[a] + prod;
+            if ((double)prod != (double)k * (double)voxelSize) return false;
+            if ((double)sum != (double)gridMin[a] + (double)k * (double)voxelSize) return false;
+        }
+    }
+    return true;
+}
+
 static int build_cells_impl(rto_context* c);
 static int build_cells(rto_context* c) {
+    c->exactGrid = c->exactGridAllowed && grid_is_exact(c->gridMin, c->voxelSize, c->rootSize);
     static const bool trace = dev_env("RTO_BUILD_TRACE", 0) != 0;            // developer aid (dev builds): host time of this step, on stderr
     if (!trace) return build_cells_impl(c);
     const auto t0 = std::chrono::steady_clock::now();
@@ -1110,6 +1133,17 @@ int rto_update_frustum(rto_context* c, const float view[16], float fov_deg, floa
     return update_frustum_planes(c, planes, 150.0f);
 }
 
+// Test / A-B hook (not in rto_hip.h): 0 = the general child test even on a grid whose planes are exact; 1 = automatic (default).
+// Takes effect at once (the flag travels with every frame's parameters); info[0] = the grid is exact, info[1] = the 9-plane form is in use.
+int rto_debug_set_exact_grid(rto_context* c, int enabled, int info[2]) {
+    if (!c) return RTO_E_INVALID;
+    c->exactGridAllowed = enabled != 0;
+    const bool exact = c->numNodes > 0 && grid_is_exact(c->gridMin, c->voxelSize, c->rootSize);
+    c->exactGrid = c->exactGridAllowed && exact;
+    if (info) { info[0] = exact ? 1 : 0; info[1] = c->exactGrid ? 1 : 0; }
+    return RTO_OK;
+}
+
 int rto_debug_set_frustum_shortcut(rto_context* c, int enabled) {
     if (!c) return RTO_E_INVALID;
     c->cullShortcut = enabled != 0;
@@ -1311,6 +1345,7 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     P.lightNeg[0] = -l.x; P.lightNeg[1] = -l.y; P.lightNeg[2] = -l.z;
     P.W = f->width; P.H = f->height;
     P.rootSize = c->rootSize; P.depth = c->depth > 0 ? c->depth : 1;
+    P.exactGrid = c->exactGrid ? 1 : 0;
     P.numParts = (p && p->num_parts > 1) ? p->num_parts : 1;
     P.part = P.numParts > 1 ? p->part : 0;
     P.bandRows = P.numParts > 1 ? p->band_rows : f->height;

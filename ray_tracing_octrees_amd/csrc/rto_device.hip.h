@@ -79,6 +79,7 @@ struct RenderParams {
     float lightNeg[3];     // -normalize(vec3(-1)), S/RT:333-334
     int W, H;
     int rootSize, depth;
+    int exactGrid;                  // host-proven (grid_is_exact): every node plane is computed without rounding -> child_axis_terms_exact
     int numParts, part, bandRows;   // rto_partition
     int localRows;                  // rows this part owns
     int tilesX, tilesY;             // 8x8 tiles over W x localRows
@@ -1249,10 +1250,34 @@ __device__ __forceinline__ void child_axis_terms(float g, float o, float inv, un
     n1 = __uint_as_float(bop3<kSelC>(a1y, a2y, sgn)); f1 = __uint_as_float(bop3<kSelC>(a2y, a1y, sgn));
 }
 
+// The same on a grid whose planes the host has proven EXACT (rto_api.hip, grid_is_exact): for every k = 0 .. rootSize the product
+// k * voxelSize and the sum gridMin + k * voxelSize are computed without rounding, i.e. every plane the reference's arithmetic
+// (S/RT:265-266) produces for any node IS the real number gridMin + k * vs.  Then any expression whose real value is that number and
+// whose last operation is a single correctly rounded one yields the very same float: the node's three planes per axis are
+//   p0 = fma(c, vs, g)            (= g + c * vs: one rounding of an exactly representable value)
+//   p1 = p0 + fh * vs             (the low child's nodeMax AND the high child's nodeMin: the same real number, hence the same float)
+//   p2 = p1 + fh * vs             (the high child's nodeMax)
+// and the entry / exit parameters follow from them by the reference's own two operations, (p - o) * inv: bit for bit the values
+// child_axis_terms computes from 4 planes, with 3 planes and without the packed multiply / add pairs.
+template <bool BIASED>
+__device__ __forceinline__ void child_axis_terms_exact(float g, float o, float inv, unsigned sgn, int c, float fh, float vs, float sv,
+                                                       float& n0, float& n1, float& f0, float& f1) {
+    (void)fh;
+    const float fc = BIASED ? __uint_as_float((unsigned)c) - 8388608.0f : (float)c;
+    const float p0 = __builtin_fmaf(fc, vs, g);
+    const float p1 = p0 + sv;
+    const float p2 = p1 + sv;
+    const f32x2 t01 = ((f32x2){ p0, p1 } - o) * inv;
+    const float t2 = (p2 - o) * inv;
+    const unsigned a0 = __float_as_uint(t01.x), a1 = __float_as_uint(t01.y), a2 = __float_as_uint(t2);
+    n0 = __uint_as_float(bop3<kSelC>(a0, a1, sgn)); f0 = __uint_as_float(bop3<kSelC>(a1, a0, sgn));
+    n1 = __uint_as_float(bop3<kSelC>(a1, a2, sgn)); f1 = __uint_as_float(bop3<kSelC>(a2, a1, sgn));
+}
+
 // clampLo / clampHi (FOLD only): what the entry / exit parameters are clipped with before they are compared.  Defaults: the
 // smallest positive float and the largest float below 1e30 (S/RT:235, :273); the octreeRaySkip traversal passes its parent
 // interval [enterT, exitT] instead (S/VR:97-100: a child passes when max(tNear, enterT) <= min(tFar, exitT)).
-template <bool FOLD = true, bool BIASED = false>
+template <bool FOLD = true, bool BIASED = false, bool EXACT = false>
 __device__ __forceinline__ unsigned child_fail_mask_fast(float gx, float gy, float gz, float vs, float ox, float oy, float oz,
                                                          float ix, float iy, float iz, unsigned sx, unsigned sy, unsigned sz,
                                                          int cx, int cy, int cz, float fh,
@@ -1261,9 +1286,15 @@ __device__ __forceinline__ unsigned child_fail_mask_fast(float gx, float gy, flo
     const float kEps = clampLo;                               // default: smallest positive float: tFar > 0  <=>  tFar >= kEps
     const float kBelow1e30 = clampHi;                         // default: largest float < 1e30f:  tNear < 1e30 <=> tNear <= this
     float nx0, nx1, fx0, fx1, ny0, ny1, fy0, fy1, nz0, nz1, fz0, fz1;
-    child_axis_terms<BIASED>(gx, ox, ix, sx, cx, fh, vs, sv, nx0, nx1, fx0, fx1);
-    child_axis_terms<BIASED>(gy, oy, iy, sy, cy, fh, vs, sv, ny0, ny1, fy0, fy1);
-    child_axis_terms<BIASED>(gz, oz, iz, sz, cz, fh, vs, sv, nz0, nz1, fz0, fz1);
+    if (EXACT) {
+        child_axis_terms_exact<BIASED>(gx, ox, ix, sx, cx, fh, vs, sv, nx0, nx1, fx0, fx1);
+        child_axis_terms_exact<BIASED>(gy, oy, iy, sy, cy, fh, vs, sv, ny0, ny1, fy0, fy1);
+        child_axis_terms_exact<BIASED>(gz, oz, iz, sz, cz, fh, vs, sv, nz0, nz1, fz0, fz1);
+    } else {
+        child_axis_terms<BIASED>(gx, ox, ix, sx, cx, fh, vs, sv, nx0, nx1, fx0, fx1);
+        child_axis_terms<BIASED>(gy, oy, iy, sy, cy, fh, vs, sv, ny0, ny1, fy0, fy1);
+        child_axis_terms<BIASED>(gz, oz, iz, sz, cz, fh, vs, sv, nz0, nz1, fz0, fz1);
+    }
     // fold "tFar > 0" and "tNear < 1e30" into the x terms (spelled as instructions: behind a bitwise select the compiler
     // would first canonicalise the operand with an extra v_max_f32 x, x)
     // FOLD = false (see `plainWave` in trace_tile_lean): every ray of the wave starts outside the root box, more than a few ulps
@@ -1362,6 +1393,11 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
                                   __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
     const bool anyRisky = __builtin_amdgcn_ballot_w64(risky) != 0ull;   // wave-uniform, fixed for the whole traversal
     const bool plainWave = __builtin_amdgcn_ballot_w64(guarded) == 0ull;   // wave-uniform: no ray of this wave needs the folds
+    const bool exactGrid = P.exactGrid != 0;
+    // the exact form's v_fma_f32 takes the voxel size from a scalar register and so needs the origin in a vector one: kept there across
+    // the loop (three registers) instead of being copied in front of every fma
+    float gxv = G.gx, gyv = G.gy, gzv = G.gz;
+    asm volatile("" : "+v"(gxv), "+v"(gyv), "+v"(gzv));
 
     // The loop is written for gfx950's VALU issue costs (tools/ubench/valu_rate2.hip, valu_rate3.hip: add / sub / mul f32,
     // add / sub u32, and / or / xor, shifts by an immediate and v_bitop3 issue every 2 cycles per SIMD; min / max, cvt,
@@ -1391,6 +1427,12 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
         unsigned fail8;
         if (anyRisky) fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz,
                                                     r.ix, r.iy, r.iz, cx & 0x7fffff, cy & 0x7fffff, cz & 0x7fffff, 1 << bpos);
+        else if (exactGrid) {           // wave-uniform (a kernel argument): the host has proven the grid's planes exact
+            if (plainWave) fail8 = child_fail_mask_fast<false, true, true>(gxv, gyv, gzv, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                                           sgnX, sgnY, sgnZ, cx, cy, cz, fh);
+            else fail8 = child_fail_mask_fast<true, true, true>(gxv, gyv, gzv, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                                sgnX, sgnY, sgnZ, cx, cy, cz, fh);
+        }
         else if (plainWave) fail8 = child_fail_mask_fast<false, true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
                                                                       sgnX, sgnY, sgnZ, cx, cy, cz, fh);
         else fail8 = child_fail_mask_fast<true, true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
@@ -2451,6 +2493,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     const bool risky = alive && !(__builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
                                   __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
     const bool anyRisky = __builtin_amdgcn_ballot_w64(risky) != 0ull;   // wave-uniform; shadow rays are never risky themselves
+    const bool exactGrid = P.exactGrid != 0;
                                                                          // (finite light direction), the exact form serves them too
     unsigned cur = 0;
     int cx = (int)kCoordBias, cy = (int)kCoordBias, cz = (int)kCoordBias;      // node position, biased (child_axis_terms): the bit operations below never touch the bias
@@ -2508,6 +2551,8 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
             unsigned fail8;
             if (anyRisky) fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz,
                                                         r.ix, r.iy, r.iz, cx & 0x7fffff, cy & 0x7fffff, cz & 0x7fffff, 1 << (bpos & 31));
+            else if (exactGrid) fail8 = child_fail_mask_fast<true, true, true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                                               sgnX, sgnY, sgnZ, cx, cy, cz, fh);      // grid planes proven exact: 9 plane parameters
             else fail8 = child_fail_mask_fast<true, true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
                                                           sgnX, sgnY, sgnZ, cx, cy, cz, fh);
             const unsigned vm0 = (d.x >> 16) & 0xffu;

@@ -313,6 +313,15 @@ class Context:
         """Drop the launch-order tables kept for `stream` (call before destroying the stream)."""
         self._check(self._L.rto_forget_stream(self._h, C.c_void_p(stream) if stream else None))
 
+    def debug_set_exact_grid(self, enabled: bool = True):
+        """Test / A-B hook (not part of rto_hip.h): False = the general 12-plane child test even on a grid whose node planes are computed
+        without rounding; True = automatic (default).  Returns (the resident grid is exact, the 9-plane form is in use).  Pixels never depend on it."""
+        fn = self._L.rto_debug_set_exact_grid
+        fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        info = (C.c_int * 2)()
+        self._check(fn(self._h, 1 if enabled else 0, info))
+        return bool(info[0]), bool(info[1])
+
     def debug_set_tile_mask(self, mode):
         """0 / False: occupancy mask off; 1 / True: on (default); 2: on, built by a launch of its own in front of the frame and
         consulted by every wave (tests).  Pixels never depend on it."""

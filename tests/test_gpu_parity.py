@@ -71,6 +71,8 @@ def _random_grid(orc, rng):
     data ^= noise.astype(np.uint8)                                      # salt and pepper -> depth to min-leaf 1
     gmin = rng.uniform(-50, 50, 3).astype(np.float32)
     voxel = np.float32(rng.choice([0.03125, 0.7, 1.0, 3.3]))
+    if rng.random() < 0.5:                                              # a "round" origin: with 0.03125 / 1.0 every node plane is then exact in float
+        gmin = (np.round(gmin / voxel) * voxel).astype(np.float32)      # (the lean kernels' 9-plane child test, rto_api.hip grid_is_exact)
     return orc.Grid(dims, gmin, voxel, data)
 
 
@@ -107,8 +109,16 @@ def test_fuzz_random_scenes_and_cameras(ctx, orc, seed):
             np.testing.assert_array_equal(ctx.render_steps(f), steps, err_msg=what)
             gs = ctx.frame_stats(f)
             assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"]), what
-        # the nearest-hit render mode (octreeRaySkip per pixel) on the same frame
+        # a grid whose planes are exact runs the 9-plane child test: the general form must give the same frame and the same step counts
         ctx.set_kernel(rto.KERNEL_AUTO)
+        if ctx.debug_set_exact_grid(True)[1]:
+            ctx.debug_set_exact_grid(False)
+            try:
+                assert_bit_exact(ctx.render_host(f), want, f"seed {seed} {kind}: general child test on an exact grid")
+                np.testing.assert_array_equal(ctx.render_steps(f), steps)
+            finally:
+                ctx.debug_set_exact_grid(True)
+        # the nearest-hit render mode (octreeRaySkip per pixel) on the same frame
         nrgba, nt = orc.render_skip(s.nodes, s.min, s.voxel, view, pos, aspect, fov, W, H)
         for _ in range(2):
             grgba, gt_ = ctx.render_skip_host(f)
@@ -2333,6 +2343,56 @@ def test_bench_line_contract_small_run():
     assert "skipped" not in sr, sr
     for k in ("N2_rank0", "N2_rank1"):
         assert sr[k]["ms_per_frame"] > 0 and sr[k]["render_ms_per_frame"] > 0 and sr[k]["gather_assemble_ms_per_frame"] > 0
+
+
+@pytest.mark.parametrize("scene", ["sphere64", "calgary", "odd"])
+def test_exact_grid_child_test_equals_the_general_one(ctx, orc, scenes, camera, scene):
+    """Round 5: where the host proves that every node plane gridMin + k * voxelSize is computed without rounding (the test spheres,
+    sceneCache.bin) the lean kernels compute 9 plane parameters per trip (fma, two adds) instead of 12 -- the same floats by
+    construction.  Both forms against the oracle: pixels, per-pixel step counts, counters, the triangle path with shadow rays, inside
+    and outside cameras; and a grid that is NOT exact (voxel 0.7) must be refused by the proof."""
+    s = scenes(scene)
+    upload(ctx, s)
+    exact, used = ctx.debug_set_exact_grid(True)
+    assert exact == used
+    if scene in ("sphere64", "calgary"):
+        assert exact, "the benchmark scenes' grids are exact: origin -0.5 / voxel 2^-k, origin (-2125, -1215, -150) / voxel 10"
+    W, H = 320, 200
+    cams = [camera("calgary_oblique" if scene == "calgary" else "sphere")]
+    dims = np.array(s.grid.dims, np.float32)
+    centre = np.asarray(s.min, np.float32) + 0.5 * dims * np.float32(s.voxel)
+    inside = orc.Camera(1.1, 0.4, float(0.2 * dims.max() * s.voxel))
+    inside.set_target(*[float(x) for x in centre])
+    cams.append((inside.get_view(), inside.get_pos()))
+    tris, off = orc.build_leaf_triangles(s.grid, s.nodes)
+    ctx.upload_leaf_triangles(tris, off)
+    try:
+        for view, pos in cams:
+            f = rto.make_frame(view, pos, W / H, 45.0, W, H)
+            want, st = oracle_frame(orc, s, view, pos, W, H)
+            steps = orc.render_steps(s.nodes, s.min, s.voxel, view, pos, W / H, 45.0, W, H)
+            wt, _ = orc.render_triangles(s.nodes, tris, off, s.min, s.voxel, view, pos, W / H, 45.0, W, H, shadow=True)
+            for on in (True, False):
+                ctx.debug_set_exact_grid(on)
+                what = f"{scene}, exact-grid form {'on' if on else 'off'}"
+                for _ in range(2):
+                    assert_bit_exact(ctx.render_host(f), want, what)
+                np.testing.assert_array_equal(ctx.render_steps(f), steps, err_msg=what)
+                gs = ctx.frame_stats(f)
+                assert (gs["pops"], gs["hits"], gs["capped"]) == (st["pops"], st["hits"], st["capped"]), what
+                if len(tris):
+                    for _ in range(2):
+                        assert_bit_exact(ctx.render_triangles_host(f, shadow=True), wt, what + ", triangles + shadow")
+    finally:
+        ctx.debug_set_exact_grid(True)
+    # the proof refuses a grid whose products k * voxel round
+    rng = np.random.default_rng(5)
+    data = (rng.random((8, 8, 8)) < 0.4).astype(np.uint8)
+    for gmin, voxel, expect in (((0.0, 0.0, 0.0), 0.7, False), ((-0.5, -0.5, -0.5), 0.125, True), ((0.1, 0.0, 0.0), 0.125, False),
+                                ((-2125.0, -1215.0, -150.0), 10.0, True), ((1e8, 0.0, 0.0), 1.0, False)):
+        g = orc.Grid((8, 8, 8), np.array(gmin, np.float32), np.float32(voxel), data)
+        upload(ctx, Scene(g, orc.build_flat_octree(g)))
+        assert ctx.debug_set_exact_grid(True) == (expect, expect), (gmin, voxel)
 
 
 def test_camera_a_hair_outside_the_root_box(ctx, orc):
