@@ -1319,6 +1319,110 @@ __device__ __forceinline__ unsigned child_fail_mask_fast(float gx, float gy, flo
     return (fa << 4) | fb;
 }
 
+// ---- the 8 verdicts on an EXACT grid, without a single per-child min / max ---------------------------------------------------
+// On a grid whose planes are exact (grid_is_exact) a node has three planes per axis, p0 < p1 < p2, and -- subtraction and the
+// multiplication by a finite non-zero factor being monotonic -- their parameters come out ordered: with the axis' entry parameter
+// e = t(first plane the ray meets), m = t(p1) and exit parameter x, e <= m <= x holds in float.  A child is a choice, per axis, of the
+// ENTRY half [e, m] or the EXIT half [m, x]; write S for the axes on which it takes the exit half.  Its verdict in the reference,
+// max3(near) <= min3(far) (S/RT:226-236 on the child's box), compares a maximum with a minimum, i.e. asks that EVERY near value be
+// <= EVERY far value.  Same-axis pairs hold by the ordering; the others are, with Tn = max(e_x, e_y, e_z) and Tf = min(x_x, x_y, x_z)
+// (the node's own interval; the folds tFar > 0, tNear < 1e30 join them as one more lower / upper bound):
+//      A_a: m_a <= Tf   for every a in S         B_a: Tn <= m_a   for every a not in S         C_ab: m_a <= m_b   for a in S, b not in S
+// -- twelve comparisons of nine numbers per node instead of 8 x (max3, min3, compare), each one float subtraction whose sign IS the
+// comparison (no NaN on this path), spread to a lane mask by one arithmetic shift.  (Tn <= Tf itself needs no test: it is the verdict
+// that made the walk enter this node, computed from the same floats in its parent's trip -- or by the root test.)  Which CHILD
+// INDICES a failed comparison strikes follows from the ray's direction signs alone: ka_a = the children whose a-half is the exit
+// half (0xAA / 0xCC / 0xF0, complemented where the ray runs down the axis), x_ab = ka_a ^ ka_b -- six words per ray, made once.
+// The result's bits above 7 are not cleared: every caller masks it with a descriptor's 8-bit visibility mask.
+struct ExactPat { unsigned kaX, kaY, kaZ, xXY, xXZ, xYZ; };
+__device__ __forceinline__ ExactPat exact_patterns(unsigned sgnX, unsigned sgnY, unsigned sgnZ) {
+    ExactPat p;
+    p.kaX = 0xAAu ^ (sgnX & 0xFFu); p.kaY = 0xCCu ^ (sgnY & 0xFFu); p.kaZ = 0xF0u ^ (sgnZ & 0xFFu);
+    p.xXY = p.kaX ^ p.kaY; p.xXZ = p.kaX ^ p.kaZ; p.xYZ = p.kaY ^ p.kaZ;
+    return p;
+}
+constexpr int kOr3 = 0xFE;        // a | b | c
+// entry, mid and exit parameter of one axis (child_axis_terms_exact's planes)
+template <bool BIASED>
+__device__ __forceinline__ void axis_emx_exact(float g, float o, float inv, unsigned sgn, int c, float vs, float sv, float& e, float& m, float& x) {
+    const float fc = BIASED ? __uint_as_float((unsigned)c) - 8388608.0f : (float)c;
+    const float p0 = __builtin_fmaf(fc, vs, g);
+    const float p1 = p0 + sv;
+    const float p2 = p1 + sv;
+    const f32x2 t02 = ((f32x2){ p0, p2 } - o) * inv;                  // the two outer planes as a pair (one packed subtract, one packed multiply)
+    m = (p1 - o) * inv;                                               // the mid plane on its own: it goes into six single subtractions
+    const unsigned a0 = __float_as_uint(t02.x), a2 = __float_as_uint(t02.y);
+    e = __uint_as_float(bop3<kSelC>(a0, a2, sgn)); x = __uint_as_float(bop3<kSelC>(a2, a0, sgn));
+}
+// all ones where u <= v FAILS
+__device__ __forceinline__ unsigned fails_le(float u, float v) { return (unsigned)((int)__float_as_uint(v - u) >> 31); }
+
+template <bool FOLD, bool BIASED>
+__device__ __forceinline__ unsigned child_fail_mask_exactgrid(float gx, float gy, float gz, float vs, float ox, float oy, float oz,
+                                                              float ix, float iy, float iz, unsigned sx, unsigned sy, unsigned sz, const ExactPat& K,
+                                                              int cx, int cy, int cz, float fh,
+                                                              float clampLo = __uint_as_float(1u), float clampHi = __uint_as_float(0x7149f2c9u)) {
+    const float sv = fh * vs;
+    float ex, mx, xx, ey, my, xy, ez, mz, xz;
+    axis_emx_exact<BIASED>(gx, ox, ix, sx, cx, vs, sv, ex, mx, xx);
+    axis_emx_exact<BIASED>(gy, oy, iy, sy, cy, vs, sv, ey, my, xy);
+    axis_emx_exact<BIASED>(gz, oz, iz, sz, cz, vs, sv, ez, mz, xz);
+    float Tn = max3f(ex, ey, ez), Tf = min3f(xx, xy, xz);
+    if (FOLD) {
+        asm("v_max_f32 %0, %1, %2" : "=v"(Tn) : "v"(Tn), "v"(clampLo));      // tFar > 0: the smallest positive float is one more lower bound
+        asm("v_min_f32 %0, %1, %2" : "=v"(Tf) : "v"(Tf), "v"(clampHi));      // tNear < 1e30: the largest float below it one more upper bound
+    }
+    const unsigned selX = bop3<kSelC>(fails_le(Tn, mx), fails_le(mx, Tf), K.kaX);    // children with x in S: A_x; the others: B_x
+    const unsigned selY = bop3<kSelC>(fails_le(Tn, my), fails_le(my, Tf), K.kaY);
+    const unsigned selZ = bop3<kSelC>(fails_le(Tn, mz), fails_le(mz, Tf), K.kaZ);
+    unsigned fail = bop3<kOr3>(selX, selY, selZ);
+    const unsigned pXY = bop3<kSelC>(fails_le(my, mx), fails_le(mx, my), K.kaX);     // x in S, y not: C_xy; y in S, x not: C_yx
+    const unsigned pXZ = bop3<kSelC>(fails_le(mz, mx), fails_le(mx, mz), K.kaX);
+    const unsigned pYZ = bop3<kSelC>(fails_le(mz, my), fails_le(my, mz), K.kaY);
+    fail = bop3<kOrAnd>(fail, pXY, K.xXY);
+    fail = bop3<kOrAnd>(fail, pXZ, K.xXZ);
+    fail = bop3<kOrAnd>(fail, pYZ, K.xYZ);
+    return fail;
+}
+
+// The same for a kernel without registers to spare (the triangle kernel, 96 VGPRs at 5 waves per SIMD): three pattern words per ray
+// instead of six (x_ab is formed inside the operation that uses it) and the direction signs taken from the reciprocals in every trip
+// (three arithmetic shifts) instead of living in three more registers: 5 more instructions per trip, 6 fewer registers.
+// the three patterns in ONE word, ka_x | ka_y << 8 | ka_z << 16: nothing above a pattern's own 8 bits is ever looked at, so a shift
+// by a constant (full rate) unpacks one
+struct ExactPat3 { unsigned pack; };
+__device__ __forceinline__ ExactPat3 exact_patterns3(unsigned sgnX, unsigned sgnY, unsigned sgnZ) {
+    ExactPat3 p;
+    p.pack = (0xAAu ^ (sgnX & 0xFFu)) | ((0xCCu ^ (sgnY & 0xFFu)) << 8) | ((0xF0u ^ (sgnZ & 0xFFu)) << 16);
+    return p;
+}
+constexpr int kAndXor = 0x60;     // a & (b ^ c)
+template <bool FOLD, bool BIASED>
+__device__ __forceinline__ unsigned child_fail_mask_exactgrid3(float gx, float gy, float gz, float vs, float ox, float oy, float oz,
+                                                               float ix, float iy, float iz, const ExactPat3& K,
+                                                               int cx, int cy, int cz, float fh,
+                                                               float clampLo = __uint_as_float(1u), float clampHi = __uint_as_float(0x7149f2c9u)) {
+    const float sv = fh * vs;
+    const unsigned sx = (unsigned)((int)__float_as_uint(ix) >> 31), sy = (unsigned)((int)__float_as_uint(iy) >> 31), sz = (unsigned)((int)__float_as_uint(iz) >> 31);
+    float ex, mx, xx, ey, my, xy, ez, mz, xz;
+    axis_emx_exact<BIASED>(gx, ox, ix, sx, cx, vs, sv, ex, mx, xx);
+    axis_emx_exact<BIASED>(gy, oy, iy, sy, cy, vs, sv, ey, my, xy);
+    axis_emx_exact<BIASED>(gz, oz, iz, sz, cz, vs, sv, ez, mz, xz);
+    float Tn = max3f(ex, ey, ez), Tf = min3f(xx, xy, xz);
+    if (FOLD) {
+        asm("v_max_f32 %0, %1, %2" : "=v"(Tn) : "v"(Tn), "v"(clampLo));
+        asm("v_min_f32 %0, %1, %2" : "=v"(Tf) : "v"(Tf), "v"(clampHi));
+    }
+    const unsigned kaX = K.pack, kaY = K.pack >> 8, kaZ = K.pack >> 16;          // bits above 7: don't care
+    const unsigned selX = bop3<kSelC>(fails_le(Tn, mx), fails_le(mx, Tf), kaX);
+    const unsigned selY = bop3<kSelC>(fails_le(Tn, my), fails_le(my, Tf), kaY);
+    const unsigned selZ = bop3<kSelC>(fails_le(Tn, mz), fails_le(mz, Tf), kaZ);
+    const unsigned pXY = bop3<kAndXor>(bop3<kSelC>(fails_le(my, mx), fails_le(mx, my), kaX), kaX, kaY);
+    const unsigned pXZ = bop3<kAndXor>(bop3<kSelC>(fails_le(mz, mx), fails_le(mx, mz), kaX), kaX, kaZ);
+    const unsigned pYZ = bop3<kAndXor>(bop3<kSelC>(fails_le(mz, my), fails_le(my, mz), kaY), kaY, kaZ);
+    return bop3<kOr3>(selX, selY, selZ) | bop3<kOr3>(pXY, pXZ, pYZ);
+}
+
 // The same 8 verdicts with glm's NaN-faithful (y<x)?y:x min/max, one child at a time (waves that hold a ray with a
 // non-finite reciprocal direction -- axis-parallel rays -- are rare: small code and few registers matter here, not
 // speed).  Same float expressions as slab_exact on the child's box (S/RT:265-269).
@@ -1414,6 +1518,7 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
     const int capBound = kMaxTraversalSteps + 7 * P.depth;              // S >= capBound: every later hit lies beyond the cap
     const unsigned sgnX = (unsigned)((int)__float_as_uint(r.ix) >> 31), sgnY = (unsigned)((int)__float_as_uint(r.iy) >> 31),
                    sgnZ = (unsigned)((int)__float_as_uint(r.iz) >> 31);          // all ones: the reciprocal direction is negative
+    const ExactPat K = exact_patterns(sgnX, sgnY, sgnZ);                // exact grids: which children a failed comparison strikes (child_fail_mask_exactgrid)
     const char* descBytes = reinterpret_cast<const char*>(desc);
     int trips = 0;                                                      // wave-uniform trip count = this tile's cost
     if (startLeaf) { hit = alive && startSolid; alive = false; }        // a terminal start node (culled-root edge only): one pop, S/RT:277-288
@@ -1428,10 +1533,10 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
         if (anyRisky) fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz,
                                                     r.ix, r.iy, r.iz, cx & 0x7fffff, cy & 0x7fffff, cz & 0x7fffff, 1 << bpos);
         else if (exactGrid) {           // wave-uniform (a kernel argument): the host has proven the grid's planes exact
-            if (plainWave) fail8 = child_fail_mask_fast<false, true, true>(gxv, gyv, gzv, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                                           sgnX, sgnY, sgnZ, cx, cy, cz, fh);
-            else fail8 = child_fail_mask_fast<true, true, true>(gxv, gyv, gzv, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                                sgnX, sgnY, sgnZ, cx, cy, cz, fh);
+            if (plainWave) fail8 = child_fail_mask_exactgrid<false, true>(gxv, gyv, gzv, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                                          sgnX, sgnY, sgnZ, K, cx, cy, cz, fh);
+            else fail8 = child_fail_mask_exactgrid<true, true>(gxv, gyv, gzv, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                               sgnX, sgnY, sgnZ, K, cx, cy, cz, fh);
         }
         else if (plainWave) fail8 = child_fail_mask_fast<false, true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
                                                                       sgnX, sgnY, sgnZ, cx, cy, cz, fh);
@@ -2502,8 +2607,9 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     const unsigned sentinel = 1u << P.depth;
     int S = 0;                                                          // identity (1), for the ray in flight
     const int capBound = kMaxTraversalSteps + 7 * P.depth;
-    unsigned sgnX = (unsigned)((int)__float_as_uint(r.ix) >> 31), sgnY = (unsigned)((int)__float_as_uint(r.iy) >> 31),
-             sgnZ = (unsigned)((int)__float_as_uint(r.iz) >> 31);
+    // exact grids (child_fail_mask_exactgrid3): which children a failed comparison strikes; remade when the shadow ray starts.  The
+    // direction signs themselves are taken from the reciprocals in every trip (three registers fewer across the loop)
+    ExactPat3 K = exact_patterns3((unsigned)((int)__float_as_uint(r.ix) >> 31), (unsigned)((int)__float_as_uint(r.iy) >> 31), (unsigned)((int)__float_as_uint(r.iz) >> 31));
     bool haveLeaf = false;         // a popped triangle leaf (record `cur`) waits for its test
     bool ended = false;            // the ray in flight ran out of nodes (or into the cap) in the node loop
     bool shadowRay = false;        // the ray in flight is the pixel's shadow ray
@@ -2551,10 +2657,11 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
             unsigned fail8;
             if (anyRisky) fail8 = child_fail_mask_exact(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz,
                                                         r.ix, r.iy, r.iz, cx & 0x7fffff, cy & 0x7fffff, cz & 0x7fffff, 1 << (bpos & 31));
-            else if (exactGrid) fail8 = child_fail_mask_fast<true, true, true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                                               sgnX, sgnY, sgnZ, cx, cy, cz, fh);      // grid planes proven exact: 9 plane parameters
+            else if (exactGrid) fail8 = child_fail_mask_exactgrid3<true, true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                                               K, cx, cy, cz, fh);                    // grid planes proven exact: 9 plane parameters, 12 comparisons
             else fail8 = child_fail_mask_fast<true, true>(G.gx, G.gy, G.gz, G.vs, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                          sgnX, sgnY, sgnZ, cx, cy, cz, fh);
+                                                          (unsigned)((int)__float_as_uint(r.ix) >> 31), (unsigned)((int)__float_as_uint(r.iy) >> 31),
+                                                          (unsigned)((int)__float_as_uint(r.iz) >> 31), cx, cy, cz, fh);
             const unsigned vm0 = (d.x >> 16) & 0xffu;
             S += __builtin_popcount(vm0);
             // children that do more than count a pop: visible internal ones and visible triangle leaves that pass the slab test
@@ -2706,7 +2813,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
                         r.ox = hx + nx * bias; r.oy = hy + ny * bias; r.oz = hz + nz * bias;
                         r.dx = lnx; r.dy = lny; r.dz = lnz;
                         r.ix = lix; r.iy = liy; r.iz = liz;
-                        sgnX = lsx; sgnY = lsy; sgnZ = lsz;
+                        K = exact_patterns3(lsx, lsy, lsz);
                         shadowRay = true;
                         float tNear, tFar, a0, a1, a2, a3, a4, a5;
                         alive = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
@@ -2755,8 +2862,13 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
         if (lane == 0 && ty < P.tilesY && tileLive) P.tileCost[tile] = ((cost >> 3) == 0 && P.tileMask) ? -1 : cost >> 3;   // inside the mask, no work: the rim (as trace_tile_lean)
     }
     if (valid && !(P.skipOutside && outside)) {
-        if (SHADE) __builtin_nontemporal_store(shade, reinterpret_cast<float*>(out) + (size_t)ly * P.W + px);
-        else store_pixel(out + (size_t)ly * P.W + px, shade_color(shade));
+        // the pixel's place is worked out again from the lane number (behind a barrier the compiler cannot see through): two registers
+        // that would otherwise live across the whole walk -- the kernel sits at its budget of 96 (5 waves per SIMD)
+        int lane2 = lane;
+        asm volatile("" : "+v"(lane2));
+        const size_t pix = (size_t)(ty * 8 + (lane2 >> 3)) * P.W + (size_t)(tx * 8 + (lane2 & 7));
+        if (SHADE) __builtin_nontemporal_store(shade, reinterpret_cast<float*>(out) + pix);
+        else store_pixel(out + pix, shade_color(shade));
     }
     if (MODE == kModeColor) fill_outside<SHADE ? kModeShade : kModeColor>(P, out, lane, slot);
     if (MODE == kModeSteps) {
