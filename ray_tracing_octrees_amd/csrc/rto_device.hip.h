@@ -1554,7 +1554,7 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
         const int bpos2 = (int)bop3<kSelC>((unsigned)bpos, (unsigned)Lb, noWork);
         // pop its next candidate: the highest one (children pop 7..0)
         const int j = 31 - __builtin_clz(W & 0xffu);                     // W & 0xff != 0 unless the lane is dead
-        const unsigned bitj = 1u << j;
+        const unsigned bitj = 0x80000000u >> (31 - j);                   // = 1u << j as a RIGHT shift: variable right shifts issue at full rate on gfx950, left shifts at half (tools/ubench/valu_rate4.hip)
         const unsigned imv = W >> 8;                                     // bits 0..7: internal mask (unmasked); above: visible mask
         const bool solid = (imv & bitj) == 0;
         hit = !dead && solid;                                            // S/RT:278-288 (cap applied after the loop)
@@ -2672,7 +2672,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
             const unsigned base = bop3<kSelC>(d.y, e.y, noWork);
             const int bpos2 = (int)bop3<kSelC>((unsigned)bpos, (unsigned)Lb, noWork);
             const int j = 31 - __builtin_clz(W & 0xffu);
-            const unsigned bitj = 1u << j;
+            const unsigned bitj = 0x80000000u >> (31 - j);                   // = 1u << j as a RIGHT shift: variable right shifts issue at full rate on gfx950, left shifts at half (tools/ubench/valu_rate4.hip)
             const bool leaf = ((W >> 8) & bitj) == 0;
             const unsigned Wn = W ^ bitj;
             stk[bpos2 * kWave] = make_uint2(Wn, base);
