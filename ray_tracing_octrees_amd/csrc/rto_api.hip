@@ -1343,6 +1343,7 @@ static int fill_params(rto_context* c, const rto_frame* f, const rto_partition* 
     P.voxelSize = c->voxelSize;
     rtmath::vec3 l = rtmath::normalize(rtmath::vec3(-1.0f, -1.0f, -1.0f));     // S/RT:333
     P.lightNeg[0] = -l.x; P.lightNeg[1] = -l.y; P.lightNeg[2] = -l.z;
+    for (int a = 0; a < 3; a++) { const volatile float q = 1.0f / P.lightNeg[a]; P.lightInv[a] = q; }     // IEEE single division (volatile: never a reciprocal approximation)
     P.W = f->width; P.H = f->height;
     P.rootSize = c->rootSize; P.depth = c->depth > 0 ? c->depth : 1;
     P.exactGrid = c->exactGrid ? 1 : 0;

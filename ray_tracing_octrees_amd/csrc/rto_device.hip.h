@@ -77,6 +77,7 @@ struct RenderParams {
     float gridMin[3];
     float voxelSize;
     float lightNeg[3];     // -normalize(vec3(-1)), S/RT:333-334
+    float lightInv[3];     // 1.0f / lightNeg (IEEE division on the host: the same float the device's correctly rounded division gives): every shadow ray's reciprocal direction
     int W, H;
     int rootSize, depth;
     int exactGrid;                  // host-proven (grid_is_exact): every node plane is computed without rounding -> child_axis_terms_exact
@@ -1354,7 +1355,13 @@ __device__ __forceinline__ void axis_emx_exact(float g, float o, float inv, unsi
     const unsigned a0 = __float_as_uint(t02.x), a2 = __float_as_uint(t02.y);
     e = __uint_as_float(bop3<kSelC>(a0, a2, sgn)); x = __uint_as_float(bop3<kSelC>(a2, a0, sgn));
 }
-// all ones where u <= v FAILS
+// all ones where u <= v FAILS: the sign of v - u (a float difference has the exact sign of the comparison; x - x is +0).
+// Two corner cases give "fails" where the comparison holds, and neither can change a child's verdict:
+//   * u = +0, v = -0 (v - u = -0): v then is some child's UPPER bound -- a mid parameter m_b with b in the entry half, or Tf -- and
+//     equals zero, while that child's lower bound Tn is > 0 (the fold's smallest positive float; in fold-free waves every ray meets the
+//     root box at tNear > 0): Tn <= m_b fails for it in any case (B_b), and Tf = -0 < Tn means the node was never entered;
+//   * inf - inf = NaN of either sign (parameters that overflowed): the children concerned have m_a = +inf as a lower bound (m_a <= Tf
+//     fails, Tf < 1e30) or m_b = -inf as an upper one (Tn <= m_b fails).
 __device__ __forceinline__ unsigned fails_le(float u, float v) { return (unsigned)((int)__float_as_uint(v - u) >> 31); }
 
 template <bool FOLD, bool BIASED>
@@ -2577,7 +2584,7 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
     float lnx = P.lightNeg[0], lny = P.lightNeg[1], lnz = P.lightNeg[2];
     asm volatile("" : "+s"(lnx), "+s"(lny), "+s"(lnz));                    // see geo_of
     // every shadow ray has this direction: its reciprocal and signs are computed once per wave, not once per hit
-    const float lix = 1.0f / lnx, liy = 1.0f / lny, liz = 1.0f / lnz;
+    const float lix = P.lightInv[0], liy = P.lightInv[1], liz = P.lightInv[2];     // from the host: three divisions per wave less
     const unsigned lsx = (unsigned)((int)__float_as_uint(lix) >> 31), lsy = (unsigned)((int)__float_as_uint(liy) >> 31),
                    lsz = (unsigned)((int)__float_as_uint(liz) >> 31);
 
