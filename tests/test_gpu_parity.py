@@ -2364,6 +2364,14 @@ def test_exact_grid_child_test_equals_the_general_one(ctx, orc, scenes, camera, 
     inside = orc.Camera(1.1, 0.4, float(0.2 * dims.max() * s.voxel))
     inside.set_target(*[float(x) for x in centre])
     cams.append((inside.get_view(), inside.get_pos()))
+    # eyes exactly ON a plane of the grid (phi = 0 puts the eye at x = target.x, theta = 0 at y = target.y; the target on a node plane):
+    # plane parameters that are +0 / -0, the corner the sign-of-a-difference comparisons have to survive (fails_le)
+    ext = float(dims.max() * s.voxel)
+    plane = np.asarray(s.min, np.float32) + np.float32(s.voxel) * np.floor(dims / 2)          # a node plane on every axis
+    for th, ph in ((0.4, 0.0), (0.0, 0.8), (0.0, 0.0)):
+        c = orc.Camera(th, ph, 1.6 * ext)
+        c.set_target(*[float(x) for x in plane])
+        cams.append((c.get_view(), c.get_pos()))
     tris, off = orc.build_leaf_triangles(s.grid, s.nodes)
     ctx.upload_leaf_triangles(tris, off)
     try:
