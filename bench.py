@@ -53,7 +53,7 @@ NODE_BYTES = 60                # struct GPUNodes, the reference's node record (S
 PIXEL_BYTES = 16               # RGBA32F
 SIMDS, CLOCK_GHZ, VALU_CYCLES_PER_WAVE_INST = 1024, 2.4, 2   # 256 CUs x 4 SIMD-32: a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
 VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INST   # 1228.8 G wave-instructions/s
-MEASURED_CYCLES_PER_WAVE_INST = 3.35   # the traversal loop's mix at the issue costs measured on a saturated SIMD (profiles/r02_valu_issue_rates.txt): 401.5 cycles / 120 instructions
+MEASURED_CYCLES_PER_WAVE_INST = 2.95   # the traversal loop's mix at the issue costs measured on a saturated SIMD (profiles/r02_valu_issue_rates.txt, tools/ubench/valu_rate4.hip): round 5's exact-grid loop, ~326 cycles / ~111 instructions (rounds 2-4: 401.5 / 120 = 3.35)
 R02_VALU_INSTS = {"2": 24.12e6, "4": 55.13e6, "5": 328.1e6}   # SQ_INSTS_VALU per single-frame launch of round 2's kernels (profiles/r02_config*_summary.json)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_counters.json")
 
