@@ -1148,6 +1148,9 @@ def main(argv=None):
                                    f"{', Marching-Cubes leaf triangles + 1 shadow ray per hit' if triangles else ''}, {camtxt}, fov 45",
                 "parallelism": parallelism,
                 "kernel": args.kernel, "tile_mask": (not args.no_tile_mask),
+                # the host proved at upload that every node plane gridMin + k * voxelSize is computed without rounding: the lean kernels use
+                # the 9-plane / 12-comparison child test (bit-identical to the general one: DESIGN section 3)
+                "exact_grid_child_test": bool(ctx.debug_set_exact_grid(True)[1]),
                 "clock_ramp": (f"{ramp_frames} untimed frames ({args.ramp_ms:.0f} ms) before the {args.warmup} warm-up frames" if ramp_frames else
                                (f"{primed} untimed frames in full batches before the {args.warmup} warm-up frames" if primed else "none")),
             },
