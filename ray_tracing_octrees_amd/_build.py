@@ -20,7 +20,10 @@ LIB_HOST = os.path.join(PKG, "librto_host.so")
 
 # -ffp-contract=off: one IEEE operation per source operator (the exactness contract).
 # HIP's default -fhip-fp32-correctly-rounded-divide-sqrt stays on; no fast-math anywhere.
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+# -fno-slp-vectorize (round 5): the packed operations these kernels want are written as 2-vectors in the source; what the SLP
+# vectoriser adds on top (pairs of unrelated scalars packed through v_mov shuffles into v_pk_* at 4.4 cycles against 2 x 2.4) costs
+# config 5 5 %, configs 2 and 4 2 % (A/B, same box).  No effect on results: it only groups identical IEEE operations.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17"]
 HOST_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wextra"]
 
 

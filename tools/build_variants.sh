@@ -7,7 +7,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$R/build/variants"
 while [ $# -ge 2 ]; do
   N=$1; F=$2; shift 2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -DRTO_DEV_KNOBS $F "$R/ray_tracing_octrees_amd/csrc/rto_api.hip" -o "$R/build/variants/librto_hip_$N.so" &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -std=c++17 -DRTO_DEV_KNOBS $F "$R/ray_tracing_octrees_amd/csrc/rto_api.hip" -o "$R/build/variants/librto_hip_$N.so" &
 done
 wait
 ls -la "$R/build/variants"
