@@ -2545,7 +2545,7 @@ __global__ __launch_bounds__(kBlock) void k_unified_fill(const uint2* __restrict
 }
 
 #ifndef RTO_TRI_WAVES
-#define RTO_TRI_WAVES 5
+#define RTO_TRI_WAVES 6         // round 5: without the SLP vectoriser the kernel fits 80 VGPRs: 6 waves per SIMD (LDS: 24 x 5.6 KB of 160)
 #endif
 #ifndef RTO_TRI_BATCH
 #define RTO_TRI_BATCH 16
@@ -2718,8 +2718,10 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
         int best = -1;
         if (__builtin_amdgcn_ballot_w64(haveLeaf) != 0ull) {
             if (haveLeaf && (1 + S > kMaxTraversalSteps || MODE == kModeSteps)) {
+                const uint2* stkR = stk;
+                asm volatile("" : "+v"(stkR));       // this rare walk takes its base from `stk` HERE: a pre-offset copy hoisted to the kernel's head was a register held (and at 6 waves per SIMD spilled) for the whole walk
                 for (int b = P.depth - 1; b > bpos; b--) {
-                    const unsigned w = stk[b * kWave].x;
+                    const unsigned w = stkR[b * kWave].x;
                     const unsigned jl = ((cx >> b) & 1) | (((cy >> b) & 1) << 1) | (((cz >> b) & 1) << 2);
                     Rrest += __builtin_popcount(__builtin_amdgcn_ubfe(w, 16, 8) & ((1u << jl) - 1u));
                 }
@@ -2823,7 +2825,12 @@ __device__ __forceinline__ void trace_tile_lean_triangles(const RenderParams& P,
                         K = exact_patterns3(lsx, lsy, lsz);
                         shadowRay = true;
                         float tNear, tFar, a0, a1, a2, a3, a4, a5;
-                        alive = slab_exact(G, r, 0, 0, 0, P.rootSize, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
+                        int rootEdge = P.rootSize;
+                        asm volatile("" : "+s"(rootEdge));          // the root box is worked out HERE, once per pixel: hoisted out of the walk its three max planes are
+                                                                     // wave-uniform values in vector registers for the whole kernel (the first to be spilled at 6 waves per SIMD)
+                        int rootAt = 0;
+                        asm volatile("" : "+s"(rootAt));            // ... and so are its three min planes
+                        alive = slab_exact(G, r, rootAt, rootAt, rootAt, rootEdge, tNear, tFar, a0, a1, a2, a3, a4, a5) && !(tNear >= 1e30f);
                         if (!alive) stepsTotal += 1;                  // the shadow ray pops the root and misses it
                         cur = 0; cx = cy = cz = (int)kCoordBias; bpos = P.depth - 1; lvlPending = 0; S = 0;
                     }

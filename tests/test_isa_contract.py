@@ -69,9 +69,18 @@ def test_hot_kernels_keep_their_register_and_scratch_budgets(asm):
                  "24k_octree_ray_skip_packed", "13k_skip_render", "20k_closest_near_first", "11k_cull_desc", "13k_order_build",
                  "23k_trace_lean_persistent"):
         for k in find(meta, frag):
-            assert meta[k]["scratch"] == 0 and meta[k]["vgpr_spill"] == 0, (k, meta[k])
+            assert meta[k]["vgpr_spill"] == 0, (k, meta[k])
+            if meta[k]["scratch"]:
+                # a private segment the kernel never touches (slots reserved for scalar registers that were then kept in vector-register
+                # lanes): what matters is that no instruction goes to scratch
+                ins = body(asm, k[len("_ZN3rto"):])
+                assert not any(t.startswith(("scratch_", "buffer_load", "buffer_store")) for t in ins), (k, meta[k])
+            else:
+                assert meta[k]["scratch"] == 0
     for k in find(meta, "22k_trace_lean_triangles"):
-        assert meta[k]["vgpr"] <= 96, (k, meta[k])                  # 5 waves per SIMD (__launch_bounds__(256, 5): 512 / 5 = 102)
+        assert meta[k]["vgpr"] <= 80, (k, meta[k])                  # round 5: 6 waves per SIMD (__launch_bounds__(256, 6): 512 / 6 = 85, allocated by 8)
+    for k in find(meta, "28k_trace_lean_triangles_batch"):
+        assert meta[k]["vgpr"] <= 80, (k, meta[k])
     for k in find(meta, "23k_trace_lean_persistent"):
         assert meta[k]["vgpr"] <= 96, (k, meta[k])
 
