@@ -1603,7 +1603,8 @@ static int lean_wpb(int path) { return lean_block(path) / kWave; }
 // At 4 per SIMD the last third of the waves is handed out as slots free up -- to whichever SIMD is done first: config 2, one
 // frame per launch: 44.9 -> 38.9 us.  (Measured: a request of 32 KB and one of 40 KB give the same occupancy and time -- the
 // CU hands its LDS out in two halves --, 53 KB gives 2 per SIMD: 46.7 us.)  Launches of several frames have waves to spare and
-// keep 6.  RTO_WAVES_PER_SIMD=<n> overrides (A/B runs); 0 = never pad.
+// keep 6.  (Round 5: with the cheaper loop the padding for 6 -- 27 KB per workgroup -- beats 4: see launch_trace.)
+// RTO_WAVES_PER_SIMD=<n> overrides (A/B runs); 0 = never pad.
 static size_t lds_for_occupancy(size_t lds, int wavesDefault) {
     static const int forced = (int)dev_env("RTO_WAVES_PER_SIMD", -1);
     const int waves = forced >= 0 ? forced : wavesDefault;
@@ -1663,8 +1664,10 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             // 4 resident waves per SIMD when the frame's waves with work would all be resident at once at 6 (see lds_for_occupancy): about
             // 40 % of the box's tiles have work behind the mask, so up to 3 x the machine's slots at 6 per SIMD.  Config 2 (14,280 tiles)
             // 32.8 us at 4 against 36.5 at 6; config 4 (28,652 tiles) 71.6 at 4 against 69.3 at 6.
+            // Round 5 (the loop a third cheaper than when 4 was chosen): 4 / 5 / 6 / no padding = config 2 28.2 / 28.2 / 27.6 / 29.0 us (orbit
+            // 29.8 / - / 28.9 / 29.9), config 4 59.0 / 59.0 / 56.6 / 55.5 (tools/wps_sweep.sh): few waves now take the padding for 6.
             const bool fewWaves = Q.traceWaves <= 3 * 6 * 4 * c->numCUs;
-            const size_t lds = Q.tileMask ? lds_for_occupancy(ldsLean, fewWaves ? 4 : 0) : (leanKernel && !(c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT) ? lds_for_occupancy(ldsLean, 0) : ldsStacks);
+            const size_t lds = Q.tileMask ? lds_for_occupancy(ldsLean, fewWaves ? 6 : 0) : (leanKernel && !(c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT) ? lds_for_occupancy(ldsLean, 0) : ldsStacks);
             Q.maskLdsBytes = (int)lds;
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
             startRecorded = true;
