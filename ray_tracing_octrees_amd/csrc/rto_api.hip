@@ -1599,19 +1599,20 @@ static int lean_wpb(int path) { return lean_block(path) / kWave; }
 // Resident waves per SIMD of a lean octree launch, set through its dynamic LDS request (4-wave workgroups: workgroups per CU ==
 // waves per SIMD).  With the occupancy mask a frame has fewer waves with work than the machine has wave slots at 6 per SIMD
 // (config 2: ~5,800 against 6,144): all of them would be resident from the first microsecond, statically spread, and the
-// frame would end when the unluckiest SIMD ends (timeline: SIMD totals of 91 +- 30 loop trips, last SIMD at 42 us, mean 29).
-// At 4 per SIMD the last third of the waves is handed out as slots free up -- to whichever SIMD is done first: config 2, one
-// frame per launch: 44.9 -> 38.9 us.  (Measured: a request of 32 KB and one of 40 KB give the same occupancy and time -- the
-// CU hands its LDS out in two halves --, 53 KB gives 2 per SIMD: 46.7 us.)  Launches of several frames have waves to spare and
-// keep 6.  (Round 5: with the cheaper loop the padding for 6 -- 27 KB per workgroup -- beats 4: see launch_trace.)
-// RTO_WAVES_PER_SIMD=<n> overrides (A/B runs); 0 = never pad.
+// frame would end when the unluckiest SIMD ends (round 3's timeline: SIMD totals of 91 +- 30 loop trips, last SIMD at 42 us, mean
+// 29).  With fewer the last part of the waves is handed out as slots free up -- to whichever SIMD is done first.  The request
+// for n: more than a (n + 1)-th of the CU's 160 KB, so that n + 1 workgroups cannot share it and n can (measured through the
+// timeline's wave ids: 40 and 32 KB give 4 per SIMD -- five 32-KB requests do not fit --, 27 KB gives 5, 23 KB and less 6, the
+// kernel's register limit).  Round 3 chose 4 (44.9 -> 38.9 us); round 5, the loop a third cheaper: 4 / 5 / 6 = config 2 28.2 /
+// 27.6 / 29.0 us (orbit 29.8 / 28.9 / 29.9), config 4 59.0 / 56.6 / 55.5 (tools/wps_sweep.sh).  Launches of several frames have
+// waves to spare and take no padding.  RTO_WAVES_PER_SIMD=<n> overrides (A/B runs); 0 = never pad.
 static size_t lds_for_occupancy(size_t lds, int wavesDefault) {
     static const int forced = (int)dev_env("RTO_WAVES_PER_SIMD", -1);
     const int waves = forced >= 0 ? forced : wavesDefault;
     if (waves <= 0) return lds;
     const size_t groupsPerCU = (size_t)waves * 4 / (size_t)lean_wpb(0);     // 4 SIMDs per CU
-    const size_t perGroup = (size_t)(160 * 1024) / groupsPerCU;
-    return std::max(lds, std::min<size_t>(perGroup, 64 * 1024) & ~(size_t)255);
+    const size_t perGroup = (((size_t)(160 * 1024) / (groupsPerCU + 1)) + 1024) & ~(size_t)1023;
+    return std::max(lds, std::min<size_t>(perGroup, 64 * 1024));
 }
 
 template <int MODE>
@@ -1661,13 +1662,10 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
             const int lblocks = (Q.launchWaves + (kBlock / kWave) - 1) / (kBlock / kWave);
             const int lblocksLean = (Q.launchWaves + lean_wpb(0) - 1) / lean_wpb(0);
             const size_t ldsLean = (size_t)lean_wpb(0) * (P.depth + 1) * kWave * sizeof(uint2);
-            // 4 resident waves per SIMD when the frame's waves with work would all be resident at once at 6 (see lds_for_occupancy): about
-            // 40 % of the box's tiles have work behind the mask, so up to 3 x the machine's slots at 6 per SIMD.  Config 2 (14,280 tiles)
-            // 32.8 us at 4 against 36.5 at 6; config 4 (28,652 tiles) 71.6 at 4 against 69.3 at 6.
-            // Round 5 (the loop a third cheaper than when 4 was chosen): 4 / 5 / 6 / no padding = config 2 28.2 / 28.2 / 27.6 / 29.0 us (orbit
-            // 29.8 / - / 28.9 / 29.9), config 4 59.0 / 59.0 / 56.6 / 55.5 (tools/wps_sweep.sh): few waves now take the padding for 6.
+            // 5 resident waves per SIMD when the frame's waves with work would all be resident at once at 6 (see lds_for_occupancy): about
+            // 40 % of the box's tiles have work behind the mask, so up to 3 x the machine's slots at 6 per SIMD.
             const bool fewWaves = Q.traceWaves <= 3 * 6 * 4 * c->numCUs;
-            const size_t lds = Q.tileMask ? lds_for_occupancy(ldsLean, fewWaves ? 6 : 0) : (leanKernel && !(c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT) ? lds_for_occupancy(ldsLean, 0) : ldsStacks);
+            const size_t lds = Q.tileMask ? lds_for_occupancy(ldsLean, fewWaves ? 5 : 0) : (leanKernel && !(c->kernelMode == RTO_KERNEL_PACKED_PERSISTENT) ? lds_for_occupancy(ldsLean, 0) : ldsStacks);
             Q.maskLdsBytes = (int)lds;
             if (!noEvents) RTO_HIP(c, hipEventRecord(evA, s));        // after the order kernel: the pair brackets the traversal kernel alone
             startRecorded = true;

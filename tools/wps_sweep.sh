@@ -3,7 +3,7 @@
 # tools/build_variants.sh knobs ""), static frame + orbit leg, configs 2 and 4.  On the GPU box.
 cd "$(dirname "$0")/.."
 for rep in 1 2; do
-for w in 4 6 0; do
+for w in ${WPS:-4 6 0}; do
   for cfg in 2 4; do
     out=$(RTO_WAVES_PER_SIMD=$w RTO_HIP_LIB=$PWD/build/variants/librto_hip_knobs.so python3 bench.py --config $cfg --no-extras --cpu-frames 0 --orbit-frames 120 --steps 200 --warmup 20 2>&1 | tail -1)
     case "$out" in *"GPU core dump"*|*"Memory access fault"*) echo "FAULT $out"; exit 1;; esac
