@@ -6,15 +6,26 @@ import os
 import sys
 
 
+def newest(pattern):
+    """One file per pass directory, the newest: gpurun MERGES a call's files into an existing gpurun_out/prof_TAG/, so after a second
+    run with the same TAG the directories hold the CSVs of older builds as well."""
+    best = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
 def main(out):
     summary = {"kernels": {}, "counters_per_launch": {}}
-    for f in glob.glob(os.path.join(out, "trace", "**", "*_kernel_stats.csv"), recursive=True):
+    for f in newest(os.path.join(out, "trace", "**", "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
             name = r["Name"].split("(")[0].replace("void ", "")
             summary["kernels"][name] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                         "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
                                         "pct": float(r["Percentage"])}
-    for f in glob.glob(os.path.join(out, "trace", "**", "*_kernel_trace.csv"), recursive=True):
+    for f in newest(os.path.join(out, "trace", "**", "*_kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
             k = summary["kernels"].setdefault(name, {})
@@ -22,14 +33,20 @@ def main(out):
                       "lds_bytes": int(r["LDS_Block_Size"]), "scratch": int(r["Scratch_Size"]),
                       "workgroup": int(r["Workgroup_Size_X"]), "grid": int(r["Grid_Size_X"])})
     acc = {}
-    for f in glob.glob(os.path.join(out, "pmc*", "**", "*_counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(out, "pmc*", "**", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
             if "k_trace" not in name or "<1>" in name or "<1," in name:
                 continue
             acc.setdefault((name, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    # The MEDIAN over the pass's dispatches: a pass renders 14 + a few frames from a fresh context, and the first ~9 (no cost table, no
+    # rim yet) execute ~12 % more instructions than the settled frame whose kernel time the counters are divided by (config 2, round 5:
+    # 20.3 M against 17.98 M; the mean -- what rounds 2-4 stored -- was 18.7-19.0 M).  The mean is kept beside it.
+    summary["counters_per_launch_mean"] = {}
     for (name, ctr), v in sorted(acc.items()):
-        summary["counters_per_launch"].setdefault(name, {})[ctr] = sum(v) / len(v)
+        w = sorted(v)
+        summary["counters_per_launch"].setdefault(name, {})[ctr] = w[len(w) // 2] if len(w) % 2 else 0.5 * (w[len(w) // 2 - 1] + w[len(w) // 2])
+        summary["counters_per_launch_mean"].setdefault(name, {})[ctr] = sum(v) / len(v)
     for name, c in summary["counters_per_launch"].items():
         d = {}
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
