@@ -1586,7 +1586,7 @@ static int prepare_schedule(rto_context* c, hipStream_t s, bool capturing, bool 
 // fit, and with 4-wave workgroups a CU's wave slots stand empty until four are free at once (config 5's timeline: ~4,300 of
 // 5,120 slots taken in mid-frame).  Measured (us per frame, 256 / 128 / 64 threads): config 5 453 / 445 / 439; config 2 36.5 /
 // 43.2 / 43.3, config 4 75.1 / 81.2 / 78.5 -- the octree frames, whose launch geometry was tuned around 4-wave workgroups (four
-// consecutive launch slots per CU, 4 resident waves per SIMD through the LDS request), keep 256.
+// consecutive launch slots per CU, 4 -- since round 5: 5 -- resident waves per SIMD through the LDS request), keep 256.
 // RTO_LEAN_BLOCK / RTO_TRI_BLOCK = <64|128|256> override (A/B runs).
 static int lean_block(int path) {
     static const int b[2] = {

@@ -810,7 +810,7 @@ __device__ __forceinline__ void mask_block(const RenderParams& P, int blockInFra
     const int i = blockInFrame * (int)blockDim.x + (int)threadIdx.x;
     int kind = 0, tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;          // 0: stamps nothing, 1: the tile rectangle, 2: the "whole frame" word
     // The first 8 words of the dynamic LDS hold the workgroup's tile bounding box and its "whole frame" flag (a static __shared__
-    // array would add to every workgroup's LDS request, which the launchers size to the byte for a residency of 4 or 6 waves per
+    // array would add to every workgroup's LDS request, which the launchers size for a residency of 5 or 6 waves per
     // SIMD); the bitmap follows.  When a bitmap of the WHOLE frame fits (1080p: 4 KB) there is no bounding box to agree on: the
     // bitmap is cleared before the projection and two barriers do (with the box: four) -- the mask is complete ~1 us earlier,
     // and every wave that starts before that sets up rays for nothing.
