@@ -2085,6 +2085,30 @@ def test_comm_one_rank_through_the_c_abi(ctx, orc, scenes):
         comm.close()
 
 
+def test_comm_ranks_exchange_through_a_loopback_transport(tmp_path):
+    """Row (e) above one rank: every rank of a 2 / 3 / 4 / 5 / 8-GPU split as its own rto_context + rto_comm (rto_comm_create, the
+    multi-process entry point, NOT the rehearsal hook) in one child process on the one GPU, the product's submit / pack / comm_exchange
+    / assemble unchanged -- rank 0's receive loop over the peers, the self-send of a rendering rank 0 at world 2 and 3, cropped and
+    uncropped plans, octree and triangle + shadow modes, both buffer sets -- with tests/rccl_shim (a device-to-device copy per matched
+    ncclSend / ncclRecv pair) in the place of librccl, which refuses two ranks on one device.  What stays unexercised is RCCL's own
+    transport; every byte rank 0 assembles here was packed by ANOTHER rank's context.  The child never imports torch (it maps the real
+    librccl under the same SONAME)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc to build the loopback transport with")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = tmp_path / "librccl.so.1"
+    subprocess.run([hipcc, "-O1", "-shared", "-fPIC", "-std=c++17", os.path.join(root, "tests", "rccl_shim", "rccl_shim.cpp"), "-o", str(so)],
+                   check=True, capture_output=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "_comm_loopback_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "assembled frames equal the oracle's" in p.stdout, p.stdout[-2000:]
+
+
 def test_comm_timeout_and_dead_communicator(ctx, orc, scenes):
     """The failure path of the collective (nothing upstream to mirror: the reference is single-GPU).  A flush with a limit returns in
     time on a healthy communicator; an aborted one -- what a flush timeout or an asynchronous RCCL error leaves behind -- is DEAD: it
