@@ -165,3 +165,20 @@ def test_no_short_circuit_updates_with_calls_inside_divergent_loops():
         src = re.sub(r"//[^\n]*", "", src)
         bad = re.findall(r"if\s*\([^;{}]*\|\|\s*\([^;{}()]*&&[^;{}()]*&&[^;{}]*\w+\([^;{}]*\)\s*\)\s*\)\s*\{?[^;]*=", src)
         assert not bad, bad[:3]
+
+
+def test_rccl_loopback_stand_in_builds_and_exports_what_rto_comm_binds(tmp_path):
+    """tests/rccl_shim (test infrastructure of test_gpu_parity.py::test_comm_ranks_exchange_through_a_loopback_transport) must offer
+    every symbol rto_comm.inc looks up in librccl -- read from the RTO_SYM(...) / dlsym lines themselves, so a new binding there turns
+    this red here instead of the GPU test failing in its child process."""
+    hipcc = _hipcc()
+    if not hipcc:
+        pytest.skip("no hipcc in this environment")
+    so = tmp_path / "librccl.so.1"
+    subprocess.run([hipcc, "-O1", "-shared", "-fPIC", "-std=c++17", os.path.join(ROOT, "tests", "rccl_shim", "rccl_shim.cpp"), "-o", str(so)],
+                   check=True, stderr=subprocess.DEVNULL)
+    exported = set(re.findall(r" T (nccl\w+)", subprocess.run(["nm", "-D", str(so)], check=True, capture_output=True, text=True).stdout))
+    src = open(os.path.join(CSRC, "rto_comm.inc")).read()
+    wanted = set(re.findall(r'"(nccl[A-Z]\w+)"', src))
+    assert len(wanted) >= 12, wanted
+    assert wanted <= exported, wanted - exported
