@@ -1,5 +1,7 @@
 """Child process of test_gpu_parity.py::test_comm_ranks_exchange_through_a_loopback_transport (run with the directory of the built
 tests/rccl_shim in front of LD_LIBRARY_PATH; never imports torch, which would map the real librccl under the same SONAME).
+argv[1] = "serial" (one host thread drives all ranks, a flush after every batch) or "threads" (one host thread per rank, six batches
+in flight before the flush, RTO_RCCL_SHIM_RENDEZVOUS=1: a send / receive returns when it has met its counterpart).
 
 Every rank of a 2 / 3 / 4 / 5 / 8-GPU split as its OWN rto_context + rto_comm (rto_comm_create: the multi-process entry point) in this
 one process on the one GPU; the product's submit / pack / comm_exchange / assemble run unchanged, only the transport under ncclSend /
@@ -7,6 +9,7 @@ ncclRecv is the shim's device-to-device copy.  Rank 0's assembled frames must be
 import ctypes as C
 import os
 import sys
+import threading
 
 import numpy as np
 
@@ -47,6 +50,9 @@ def main():
     want_tri = [orc.render_triangles(nodes, tris, off, g.min, g.voxel_size, c.get_view(), c.get_pos(), W / H, 45.0, W, H, shadow=True)[0] for c in cams]
 
     nf = len(frames)
+    if len(sys.argv) > 1 and sys.argv[1] == "threads":
+        assert os.environ.get("RTO_RCCL_SHIM_RENDEZVOUS") == "1"
+        return threaded(shim, hipl, g, nodes, tris, off, frames, want_oct, want_tri, W, H)
     d_out = C.c_void_p()
     assert hipl.hipMalloc(C.byref(d_out), nf * H * W * 16) == 0
     host = np.empty((nf, H, W, 4), np.float32)
@@ -84,6 +90,64 @@ def main():
                 c.close()
     hipl.hipFree(d_out)
     print(f"loopback transport: {checked} assembled frames equal the oracle's, worlds 2 3 4 5 8")
+
+
+def threaded(shim, hipl, g, nodes, tris, off, frames, want_oct, want_tri, W, H):
+    """One host thread per rank (what N processes do, as far as one process can): every rank submits six batches of four frames back to
+    back -- the two buffer sets of every rank alternate, batch k's gather overlaps batch k + 1's render -- and flushes once."""
+    nb, nf = 6, len(frames)
+    d_out = C.c_void_p()
+    assert hipl.hipMalloc(C.byref(d_out), nb * nf * H * W * 16) == 0
+    host = np.empty((nb, nf, H, W, 4), np.float32)
+    arr = hip.Context.frame_array(frames)
+    checked = 0
+    for world in (2, 3, 5, 8):
+        uid = hip.comm_unique_id()
+        ready = threading.Barrier(world)
+        errors = []
+
+        def rank_main(r, mode):
+            ctx = comm = None
+            try:
+                ctx = rto.Context(0)
+                ctx.upload_octree(nodes, g.min, g.voxel_size)
+                ctx.upload_leaf_triangles(tris, off)
+                comm = hip.Comm(ctx, world, r, uid, band_rows=16)
+                ready.wait(60)
+                for k in range(nb):
+                    comm.submit(arr, d_out.value + k * nf * H * W * 16 if r == 0 else 0, H * W * 16, mode)
+                comm.flush(60000)
+            except BaseException as e:      # noqa: BLE001 -- reported by the main thread
+                errors.append(f"rank {r}: {type(e).__name__}: {e}")
+                try:
+                    ready.abort()
+                except Exception:
+                    pass
+            finally:
+                if comm is not None:
+                    comm.close()
+                if ctx is not None:
+                    ctx.close()
+
+        for mode, wants, what in ((hip.RESIDENT_OCTREE, want_oct, "octree"), (hip.RESIDENT_TRIANGLES_SHADOW, want_tri, "triangles + shadow")):
+            assert hipl.hipMemset(d_out, 0x55, nb * nf * H * W * 16) == 0
+            ready.reset()
+            ts = [threading.Thread(target=rank_main, args=(r, mode)) for r in range(world)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join(300)
+            assert not errors, errors
+            assert not any(t.is_alive() for t in ts), "a rank's thread did not come back"
+            assert shim.rccl_shim_pending() == 0 and shim.rccl_shim_size_mismatches() == 0
+            assert hipl.hipMemcpy(host.ctypes.data_as(C.c_void_p), d_out, nb * nf * H * W * 16, 2) == 0
+            for k in range(nb):
+                for i in range(nf):
+                    bad = bits_differ(host[k, i], wants[i])
+                    assert bad == 0, f"threads: world {world}, {what}, batch {k} frame {i}: {bad} pixels differ from the oracle's whole frame"
+                    checked += 1
+    hipl.hipFree(d_out)
+    print(f"loopback transport, one thread per rank, pipelined: {checked} assembled frames equal the oracle's, worlds 2 3 5 8")
 
 
 if __name__ == "__main__":

@@ -8,12 +8,20 @@
 // What it implements: point-to-point ncclSend / ncclRecv between the communicators of one "clique" (one ncclUniqueId), matched in
 // posting order per (source, destination) pair like NCCL's, element counts checked to agree, the copy a hipMemcpyAsync on the
 // RECEIVER's stream behind an event the sender's stream recorded when the send was posted; the sender's stream then waits for the
-// copy.  A send whose receive has not been posted yet waits in a list (the test drives all ranks from one thread: ranks N-1..1
-// submit first, rank 0 last, every rank flushes before the next batch -- a sender's buffers are not reused while a copy is pending).
+// copy.  Two modes:
+//  * default (one host thread drives all ranks: ranks N-1..1 submit first, rank 0 last, every rank flushes before the next batch): a
+//    send whose receive has not been posted yet waits in a list, no call blocks;
+//  * RTO_RCCL_SHIM_RENDEZVOUS=1 (one host thread PER rank, batches pipelined without flushes): ncclGroupEnd returns only when each
+//    of its operations has met its counterpart (30 s at most: then ncclSystemError, never a hang) -- the copy is then queued on the
+//    receiver's stream in front of whatever the receiver's thread queues next (its assembly), and the sender's stream waits for it in
+//    front of whatever the sender queues next (the event that frees its buffers): the ordering NCCL's kernels give.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -35,9 +43,12 @@ struct Op {
     ncclComm* comm;
     hipStream_t stream;
     hipEvent_t posted;      // recorded on `stream` when the operation was posted
+    int* met = nullptr;     // rendezvous mode: set to 1 (2: failed) by the thread that completes the pair
 };
 
 std::mutex g_mu;
+std::condition_variable g_cv;
+bool rendezvous() { static const bool on = [] { const char* e = std::getenv("RTO_RCCL_SHIM_RENDEZVOUS"); return e && *e == '1'; }(); return on; }
 std::deque<Op> g_waiting;           // posted, counterpart not yet seen
 thread_local int t_depth = 0;
 thread_local std::vector<Op> t_group;
@@ -71,18 +82,29 @@ bool matches(const Op& a, const Op& b) {    // a: send, b: recv
 ncclResult_t post(Op op) {
     if (hipEventCreateWithFlags(&op.posted, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
     if (hipEventRecord(op.posted, op.stream) != hipSuccess) return ncclUnhandledCudaError;
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::unique_lock<std::mutex> lock(g_mu);
     for (auto it = g_waiting.begin(); it != g_waiting.end(); ++it) {
         if (it->send == op.send) continue;
         const Op& s = op.send ? op : *it;
         const Op& r = op.send ? *it : op;
         if (!matches(s, r)) continue;
         const ncclResult_t rc = copy_now(s, r);
+        if (it->met) *it->met = rc == ncclSuccess ? 1 : 2;
         g_waiting.erase(it);
+        g_cv.notify_all();
         return rc;
     }
+    if (!rendezvous()) { g_waiting.push_back(op); return ncclSuccess; }
+    int met = 0;
+    op.met = &met;
     g_waiting.push_back(op);
-    return ncclSuccess;
+    const bool ok = g_cv.wait_for(lock, std::chrono::seconds(30), [&] { return met != 0; });
+    if (!ok) {      // the counterpart never came: take the operation back, fail loudly
+        for (auto it = g_waiting.begin(); it != g_waiting.end(); ++it)
+            if (it->met == &met) { g_waiting.erase(it); break; }
+        return ncclSystemError;
+    }
+    return met == 1 ? ncclSuccess : ncclInvalidArgument;
 }
 
 ncclResult_t enqueue(const Op& op) {
@@ -132,7 +154,26 @@ ncclResult_t ncclGroupEnd() {
     std::vector<Op> ops;
     ops.swap(t_group);
     ncclResult_t rc = ncclSuccess;
-    for (const Op& op : ops) { const ncclResult_t r = post(op); if (r != ncclSuccess) rc = r; }
+    // a rank's send to itself meets its own receive inside the group (in rendezvous mode it would otherwise wait for itself)
+    std::vector<char> done(ops.size(), 0);
+    for (size_t i = 0; i < ops.size(); i++) {
+        if (done[i] || !ops[i].send || ops[i].peer != ops[i].comm->rank) continue;
+        for (size_t j = 0; j < ops.size(); j++) {
+            if (done[j] || ops[j].send || ops[j].comm != ops[i].comm || ops[j].peer != ops[i].comm->rank) continue;
+            Op s = ops[i], r = ops[j];
+            if (hipEventCreateWithFlags(&s.posted, hipEventDisableTiming) != hipSuccess || hipEventRecord(s.posted, s.stream) != hipSuccess ||
+                hipEventCreateWithFlags(&r.posted, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.posted, r.stream) != hipSuccess) return ncclUnhandledCudaError;
+            const ncclResult_t q = copy_now(s, r);
+            if (q != ncclSuccess) rc = q;
+            done[i] = done[j] = 1;
+            break;
+        }
+    }
+    for (size_t i = 0; i < ops.size(); i++) {
+        if (done[i]) continue;
+        const ncclResult_t r = post(ops[i]);
+        if (r != ncclSuccess) rc = r;
+    }
     return rc;
 }
 
@@ -151,6 +192,7 @@ const char* ncclGetErrorString(ncclResult_t r) {
         case ncclInvalidArgument: return "shim: invalid argument (or: the two sides of a send / receive disagree on the element count)";
         case ncclInvalidUsage: return "shim: invalid usage";
         case ncclUnhandledCudaError: return "shim: HIP error";
+        case ncclSystemError: return "shim: the counterpart of a send / receive never came (30 s)";
         default: return "shim: error";
     }
 }

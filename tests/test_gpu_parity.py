@@ -2104,9 +2104,15 @@ def test_comm_ranks_exchange_through_a_loopback_transport(tmp_path):
     subprocess.run([hipcc, "-O1", "-shared", "-fPIC", "-std=c++17", os.path.join(root, "tests", "rccl_shim", "rccl_shim.cpp"), "-o", str(so)],
                    check=True, capture_output=True)
     env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
-    p = subprocess.run([sys.executable, os.path.join(root, "tests", "_comm_loopback_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "_comm_loopback_worker.py"), "serial"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "assembled frames equal the oracle's" in p.stdout, p.stdout[-2000:]
+    # one host thread per rank, six batches in flight before the flush (the pipelined form bench.py times at N > 1): a send / receive of
+    # the stand-in returns when it has met its counterpart, as NCCL's kernels complete
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "_comm_loopback_worker.py"), "threads"], env=dict(env, RTO_RCCL_SHIM_RENDEZVOUS="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "one thread per rank, pipelined" in p.stdout, p.stdout[-2000:]
 
 
 def test_comm_timeout_and_dead_communicator(ctx, orc, scenes):
