@@ -26,7 +26,9 @@ N > 1    : `python3 bench.py --gpus N` starts N fresh ranks itself (python -m to
            rank.  Every rank holds the octree and renders its round-robin bands; ONE grouped RCCL send/recv per batch of
            frames lands the parts on rank 0, which re-interleaves them -- all of it below the C boundary (rto_comm_* in
            include/rto_hip.h; torch.distributed (gloo) only carries the 128-byte communicator id, the barriers and the max
-           over ranks).  Strong scaling: one frame split N ways.
+           over ranks).  Strong scaling: one frame split N ways.  If the communicator cannot be made, or its first (probe)
+           batch fails, on any rank: every rank renders whole frames on its own GPU and the line says so (`split_error`,
+           `split_fallback`, "scaling": "weak") -- independent replicas with their caveat instead of no line.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the traversal kernel against the bound that holds -- VALU issue
 (wave-level VALU instructions from the committed PMC pass x 2 cycles on 1,024 SIMD-32 at 2.4 GHz) -- and keeps SURVEY
@@ -105,6 +107,7 @@ def parse_args(argv=None):
                          "the line then reports the per-rank cost of the split, NOT a frame rate (only 1/N of every frame is rendered)")
     ap.add_argument("--rehearse-rank", type=int, default=0, help="with --rehearse-world: the rank to play (from 4 GPUs on rank 0 only gathers "
                                                                   "and assembles, ranks 1..N-1 render)")
+    ap.add_argument("--inject-split-failure", action="store_true", help=argparse.SUPPRESS)     # tests: the communicator's first batch "fails" (exercises the replicas fallback)
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1: drive the frames through rto_comm_* with a one-rank RCCL communicator (rehearses the N>1 code path on one GPU)")
     ap.add_argument("--launch-timeout", type=float, default=300.0,
@@ -622,6 +625,7 @@ def main(argv=None):
     use_comm = world > 1 or args.force_comm
     pipelined = use_comm and not args.no_pipeline
     comm = None
+    split_error = None
     if use_comm:
         ids = [_hip.comm_unique_id() if rank == 0 else None]
         if dist is not None:
@@ -632,13 +636,37 @@ def main(argv=None):
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
+        # If the communicator cannot be made, or its first batch does not come back, on ANY rank, every rank falls back to rendering whole
+        # frames on its own GPU (independent replicas: frames are the path's independent units) and the line says so (`split_error`,
+        # "scaling": "weak"): a number with its caveat instead of no line.  A hang inside RCCL is ended by the flush limit / the launcher.
         try:
             comm = _hip.Comm(ctx, world, rank, ids[0], band_rows=args.band_rows)
+            probe = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+            comm.submit(rto.Context.frame_array([frame]), probe.data_ptr() if rank == 0 else 0, H * W * 16,
+                        _hip.RESIDENT_TRIANGLES_SHADOW if triangles else _hip.RESIDENT_OCTREE)
+            comm.flush(COMM_TIMEOUT_MS)
+            if args.inject_split_failure:
+                raise RuntimeError("injected by --inject-split-failure")
+            del probe
+        except Exception as e:
+            split_error = f"rank {rank}: {type(e).__name__}: {e}"
+            print(f"bench: the screen split cannot run here ({split_error})", file=sys.stderr, flush=True)
         finally:
             ctypes.CDLL(None).fflush(None)
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-        if args.rehearse_world > 1:
+        if dist is not None:
+            errs = [None] * world
+            dist.all_gather_object(errs, split_error)
+            split_error = next((e for e in errs if e), None)
+        if split_error is not None:
+            if comm is not None:
+                try:
+                    comm.close()
+                except Exception:
+                    pass
+            comm, use_comm, pipelined = None, False, False
+        if args.rehearse_world > 1 and comm is not None:
             if world != 1:
                 raise SystemExit("--rehearse-world needs --gpus 1 --force-comm")
             comm.debug_rehearse(args.rehearse_world, args.rehearse_rank)   # this GPU plays that rank: per-rank cost of the split, no peer traffic
@@ -1130,14 +1158,17 @@ def main(argv=None):
                            f"{', gather k overlaps render k+1' if pipelined else ''}")
         else:
             parallelism = "1 GPU, one kernel launch per frame, " + (f"replayed from a HIP graph of {gframes} frames" if graph is not None else "plain stream launches")
+            if world > 1:
+                parallelism = f"{world} independent replicas (every GPU renders whole frames of its own; the screen split could not run: see split_error), " + parallelism[7:]
+        replicas = world if not use_comm else 1          # > 1 only after a failed split: every rank rendered its own K frames
         result = {
             "metric": "Mrays/s (primary rays), 1920x1080" if (W, H) == (1920, 1080) else f"Mrays/s (primary rays), {W}x{H}",
-            "value": round(rays * args.steps / elapsed / 1e6, 2),
+            "value": round(replicas * rays * args.steps / elapsed / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if replicas > 1 else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -1163,6 +1194,10 @@ def main(argv=None):
                                    "what": "ONE GPU doing what that rank does per frame (render its bands, grouped send/recv with itself) plus the assembly "
                                            "(in a rehearsal the one GPU is also the assembling rank 0); "
                                            "value / ms_per_step are the per-rank pipeline rate of the split, not a frame rate of this machine"}
+        if split_error is not None:
+            result["split_error"] = split_error
+            result["split_fallback"] = ("the screen split (rto_comm_*: RCCL) could not run; the frames of this line were rendered WHOLE, "
+                                        f"{args.steps} per GPU on {world} GPU(s) independently: value = all GPUs' rays / the slowest GPU's time")
         if roofline is not None:
             result["roofline"] = roofline
         if fpl_leg is not None:

@@ -2334,6 +2334,31 @@ def test_cpp_class_set_devices(orc, scenes):
     rto.freeOctree(root)
 
 
+def test_bench_falls_back_to_replicas_when_the_split_cannot_run():
+    """bench.py at N > 1 drives its frames through rto_comm_* (RCCL).  If the communicator cannot be made or its first batch fails on
+    any rank, every rank renders whole frames on its own GPU and the line says so (`split_error`, `split_fallback`) instead of there
+    being no line: exercised here on one GPU with a one-rank communicator whose probe batch is declared failed; and the healthy
+    one-rank communicator still gives the split's own line."""
+    import json
+    import subprocess
+    import sys
+
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--dim", "64", "--width", "320", "--height", "200",
+            "--cpu-frames", "0", "--ramp-ms", "0", "--orbit-frames", "0", "--dropin-frames", "0", "--no-extras", "--force-comm"]
+    for extra, failed in ((["--inject-split-failure"], True), ([], False)):
+        p = subprocess.run(base + extra, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 1 and d["steps"] == 6 and d["verified_against_oracle"] is True and d["value"] > 0
+        if failed:
+            assert "injected" in d["split_error"] and "WHOLE" in d["split_fallback"] and "one kernel launch per frame" in d["config"]["parallelism"]
+            assert "single_frame_latency" not in d
+        else:
+            assert "split_error" not in d and "screen split over 1 GPUs" in d["config"]["parallelism"] and d["ranks_seen"] == 1
+
+
 def test_bench_line_contract_small_run():
     """bench.py end to end on a small scene: one JSON line with the keys the driver reads, a verified frame, a roofline object
     and a CPU baseline (the default sizes are exercised by the driver itself; this guards the contract, not the numbers)."""
