@@ -1688,9 +1688,12 @@ static int launch_trace(rto_context* c, const RenderParams& P, float4* d_out, hi
                 hipLaunchKernelGGL(k_trace_packed3<MODE>, dim3(lblocks), dim3(kBlock), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             } else {
                 // maskMode 2 (tests): a launch of the mask workgroups alone first, so that every wave of the frame finds the mask complete
+                // two builds of the kernel, chosen by the scene's proof (P.exactGrid): each loop holds only its own form's child tests --
+                // a variant more in that loop costs every wave (round 5: two more copies behind wave-uniform branches: +4 %)
+                auto* kern = Q.exactGrid ? k_trace_lean<MODE, 1> : k_trace_lean<MODE, 0>;
                 if (c->maskMode == 2 && Q.maskBlocks > 0)
-                    hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(Q.maskBlocks), dim3(lean_block(0)), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
-                hipLaunchKernelGGL(k_trace_lean<MODE>, dim3(lblocksLean + Q.maskBlocks), dim3(lean_block(0)), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+                    hipLaunchKernelGGL(kern, dim3(Q.maskBlocks), dim3(lean_block(0)), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
+                hipLaunchKernelGGL(kern, dim3(lblocksLean + Q.maskBlocks), dim3(lean_block(0)), lds, s, Q, c->d_desc, d_out, c->d_steps, c->d_counters);
             }
         }
     } else {
@@ -1816,9 +1819,10 @@ static int launch_trace_batch(rto_context* c, const RenderParams* Ps, int n, flo
     const size_t lds = lds_for_occupancy((size_t)lean_wpb(0) * (Ps[0].depth + 1) * kWave * sizeof(uint2), 0);
     for (int i = 0; i < n; i++) B.P[i].maskLdsBytes = (int)lds;
     const long long waves = (long long)maxWaves * n;
+    auto* kern = B.P[0].exactGrid ? k_trace_lean_batch<MODE, 1> : k_trace_lean_batch<MODE, 0>;       // every frame of a batch: the same scene (see launch_trace)
     if (c->maskMode == 2 && B.P[0].maskBlocks > 0)
-        hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)(B.P[0].maskBlocks * n)), dim3(lean_block(0)), lds, s, B, c->d_desc);
-    hipLaunchKernelGGL(k_trace_lean_batch<MODE>, dim3((unsigned)((waves + lean_wpb(0) - 1) / lean_wpb(0)) + (unsigned)(B.P[0].maskBlocks * n)), dim3(lean_block(0)), lds, s, B, c->d_desc);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B.P[0].maskBlocks * n)), dim3(lean_block(0)), lds, s, B, c->d_desc);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((waves + lean_wpb(0) - 1) / lean_wpb(0)) + (unsigned)(B.P[0].maskBlocks * n)), dim3(lean_block(0)), lds, s, B, c->d_desc);
     RTO_HIP(c, hipGetLastError());
     if (!noEvents) RTO_HIP(c, hipEventRecord(evB, s));
     c->lastA = evA; c->lastB = evB;                       // what rto_last_kernel_ms reads

@@ -1452,7 +1452,9 @@ __device__ __forceinline__ unsigned child_fail_mask_exact(float gx, float gy, fl
     return fail;
 }
 
-template <int MODE>
+// EXACT: 1 / 0 = the launcher knows whether the grid's planes are exact (the host's proof is per scene) and the loop holds only that form's
+// child tests; -1 = decided by the frame's flag at run time (the persistent A/B kernel)
+template <int MODE, int EXACT = -1>
 __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uint2* __restrict__ desc, float4* __restrict__ out,
                                                 int* __restrict__ stepsOut, Counters* __restrict__ counters, uint2* stk,
                                                 const int lane, const int slot) {
@@ -1504,7 +1506,7 @@ __device__ __forceinline__ void trace_tile_lean(const RenderParams& P, const uin
                                   __builtin_isfinite(r.ox) && __builtin_isfinite(r.oy) && __builtin_isfinite(r.oz));
     const bool anyRisky = __builtin_amdgcn_ballot_w64(risky) != 0ull;   // wave-uniform, fixed for the whole traversal
     const bool plainWave = __builtin_amdgcn_ballot_w64(guarded) == 0ull;   // wave-uniform: no ray of this wave needs the folds
-    const bool exactGrid = P.exactGrid != 0;
+    const bool exactGrid = EXACT < 0 ? P.exactGrid != 0 : EXACT != 0;
     // the exact form's v_fma_f32 takes the voxel size from a scalar register and so needs the origin in a vector one: kept there across
     // the loop (three registers) instead of being copied in front of every fma
     float gxv = G.gx, gyv = G.gy, gzv = G.gz;
@@ -1841,7 +1843,7 @@ __global__ __launch_bounds__(kBlock) void k_closest_near_first(RenderParams P, c
 #ifndef RTO_LEAN_WAVES
 #define RTO_LEAN_WAVES 6
 #endif
-template <int MODE>
+template <int MODE, int EXACT>
 __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean(RenderParams P, const uint2* __restrict__ desc,
                                                            float4* __restrict__ out, int* __restrict__ stepsOut,
                                                            Counters* __restrict__ counters) {
@@ -1852,7 +1854,7 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean(RenderPar
     if ((int)blockIdx.x < P.maskBlocks) { mask_block(P, (int)blockIdx.x, reinterpret_cast<unsigned*>(lds_stack), P.maskLdsBytes >> 2); return; }        // the first workgroups build the occupancy mask
     const int slot = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - P.maskBlocks) * (int)(blockDim.x >> 6) + wave);
     if (slot >= P.launchWaves) return;
-    trace_tile_lean<MODE>(P, desc, out, stepsOut, counters, stk, lane, slot);
+    trace_tile_lean<MODE, EXACT>(P, desc, out, stepsOut, counters, stk, lane, slot);
 }
 
 // Several frames in ONE launch (rto_render_batch_device, and every rank of the multi-GPU split: its parts of a batch of
@@ -1866,7 +1868,7 @@ struct RenderBatch {
     float4* out[kMaxBatch];
     int n;
 };
-template <int MODE>
+template <int MODE, int EXACT>
 __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_batch(RenderBatch B, const uint2* __restrict__ desc) {
     extern __shared__ uint2 lds_stack[];   // [wave][level][lane]
     const int lane = threadIdx.x & 63;
@@ -1878,7 +1880,7 @@ __global__ __launch_bounds__(kBlock, RTO_LEAN_WAVES) void k_trace_lean_batch(Ren
     const RenderParams& P = B.P[f];
     uint2* stk = lds_stack + (size_t)wave * (P.depth + 1) * kWave + lane;
     if (slot >= P.launchWaves) return;
-    trace_tile_lean<MODE>(P, desc, B.out[f], nullptr, nullptr, stk, lane, slot);
+    trace_tile_lean<MODE, EXACT>(P, desc, B.out[f], nullptr, nullptr, stk, lane, slot);
 }
 
 // Persistent-threads form of the default kernel (RTO_KERNEL_PACKED_PERSISTENT): the grid only fills the machine, every

@@ -62,9 +62,10 @@ def body(asm_text, fragment):
 def test_hot_kernels_keep_their_register_and_scratch_budgets(asm):
     meta = kernel_meta(asm)
     assert len(meta) > 60
-    lean0 = meta[find(meta, "12k_trace_leanILi0EE")[0]]
-    assert lean0["scratch"] == 0 and lean0["vgpr_spill"] == 0
-    assert lean0["vgpr"] <= 80                                     # 6 waves per SIMD (512 / 6 = 85, allocated by 8)
+    for exact in (0, 1):                                           # the two builds of the default kernel: general / exact-grid child tests
+        lean0 = meta[find(meta, f"12k_trace_leanILi0ELi{exact}EE")[0]]
+        assert lean0["scratch"] == 0 and lean0["vgpr_spill"] == 0
+        assert lean0["vgpr"] <= 80                                 # 6 waves per SIMD (512 / 6 = 85, allocated by 8)
     for frag in ("k_trace_lean_batch", "22k_trace_lean_triangles", "28k_trace_lean_triangles_batch", "12k_probe_skip",
                  "24k_octree_ray_skip_packed", "13k_skip_render", "20k_closest_near_first", "11k_cull_desc", "13k_order_build",
                  "23k_trace_lean_persistent"):
@@ -99,7 +100,7 @@ def _handoff(ins):
     return ins[prev + 1:bar], ins[bar + 1:], ins[:prev]
 
 
-@pytest.mark.parametrize("kernel", ["12k_trace_leanILi0EE", "22k_trace_lean_trianglesILi0ELb0EE", "13k_skip_render"])
+@pytest.mark.parametrize("kernel", ["12k_trace_leanILi0ELi1EE", "12k_trace_leanILi0ELi0EE", "22k_trace_lean_trianglesILi0ELb0EE", "13k_skip_render"])
 def test_mask_handoff_has_the_gfx950_form_design_quotes(asm, kernel):
     """every stamp an sc1 store; s_waitcnt vmcnt(0) in front of the barrier; behind it lane 0: write-back, wait, ticket
     (returning atomic), wait; the last ticket: write-back, wait, sc1 flag store.  Consumer: sc1 poll, wait, sc1 load of the word."""
